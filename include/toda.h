@@ -1,0 +1,185 @@
+/*
+ * toda.h — C ABI of libtoda_hip.so, the MI355X (gfx950) implementation of the
+ * sparse LiDAR-detection hot path of rasd3/TODA (an OpenPCDet fork).
+ *
+ * The reference reaches this arithmetic through the third-party `spconv`
+ * package (not vendored, not pinned).  Every entry point below names the
+ * reference call site it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`;
+ *     small geometry arrays (range, vsize, shape, ksize, ...) are HOST arrays
+ *     read during the call.
+ *   - the caller owns all memory, including workspaces; nothing here allocates
+ *     or frees device memory and nothing synchronises the device.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).
+ *   - return value: 0 on success, a negative TODA_E* code on failure; the
+ *     message is available from toda_last_error() (thread local).
+ *   - sizes that live on the device (`*_dev`) are int32 scalars; a kernel that
+ *     takes both `n` and `n_dev` uses min(n, *n_dev) rows when n_dev != NULL,
+ *     so index-building phases can be chained without a host round trip.
+ *   - indices are int32 rows of (b, z, y, x); spatial shapes are (D, H, W).
+ *   - neighbour tables are k-major: nbr[k * n_rows + row], -1 = no neighbour,
+ *     k = (kz * KY + ky) * KX + kx.
+ *   - weights use the spconv-2 layout [Cout][kz][ky][kx][Cin]
+ *     (pcdet/models/detectors/detector3d_template.py:337-348 converts v1 layouts).
+ */
+#ifndef TODA_H_
+#define TODA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TODA_OK 0
+#define TODA_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define TODA_EWORKSPACE (-2) /* workspace too small                       */
+#define TODA_ELAUNCH (-3)  /* HIP launch or runtime error                 */
+
+const char* toda_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int toda_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Hard voxelisation.  Replaces spconv Point2VoxelCPU3d.point_to_voxel /
+ * VoxelGenerator.generate as called from
+ * pcdet/datasets/processor/data_processor.py:44-60,115-143.
+ * Sequential semantics (voxel ids in order of first appearance, first
+ * `max_pts` points kept per voxel, voxels past `max_voxels` dropped) are
+ * reproduced exactly.  `points` is [n, c] fp32, xyz in columns 0..2.
+ * Outputs sized for max_voxels: voxels [max_voxels, max_pts, c] (zero padded
+ * for rows < *m_dev), coords_zyx [max_voxels, 3], num_pts [max_voxels].
+ * ---------------------------------------------------------------------- */
+size_t toda_voxelize_workspace_bytes(int n_points, int max_voxels);
+int toda_voxelize_hard(const float* points, int n, int c,
+                       const float* range_host /*[6] x0 y0 z0 x1 y1 z1*/,
+                       const float* vsize_host /*[3] xyz*/,
+                       const int32_t* grid_host /*[3] xyz cells*/,
+                       int max_pts, int max_voxels,
+                       float* voxels, int32_t* coords_zyx, int32_t* num_pts,
+                       int32_t* m_dev, void* ws, size_t ws_bytes, void* stream);
+
+/* MeanVFE: pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31.
+ * out[v, :] = sum_p voxels[v, p, :] / max(num_pts[v], 1); num_pts is fp32
+ * because load_data_to_gpu (pcdet/models/__init__.py:23-34) casts it. */
+int toda_mean_vfe_fwd(const float* voxels, const float* num_pts, int m, int p, int c,
+                      float* out, void* stream);
+int toda_mean_vfe_bwd(const float* grad_out, const float* num_pts, int m, int p, int c,
+                      float* grad_voxels, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Grid index: a bitmap + popcount-rank dictionary over the (b, z, y, x)
+ * lattice of one sparse level.  rank(coord) is the position of the site in
+ * ascending ((b*D+z)*H+y)*W+x order, which is the canonical row order of
+ * every index set this library generates.  Replaces spconv's hash table
+ * (SparseConvTensor.indice_dict users, pcdet/models/backbones_3d/
+ * spconv_backbone.py:77-117).
+ * ---------------------------------------------------------------------- */
+size_t toda_gridindex_bytes(int batch, const int32_t* shape_host /*[3] D H W*/);
+/* Build the index of an existing coordinate list (any row order).
+ * rowof[rank] = row.  Coordinates must be unique and in range. */
+int toda_gridindex_from_coords(const int32_t* idx, int n, const int32_t* n_dev,
+                               int batch, const int32_t* shape_host,
+                               void* gi, int32_t* rowof, void* stream);
+/* Build the index of the OUTPUT set of a strided sparse convolution
+ * (spconv.SparseConv3d, spconv_backbone.py:14-15,113-114) and emit its
+ * coordinates in canonical order.  idx_out has room for out_cap rows. */
+int toda_gridindex_from_conv(const int32_t* idx_in, int n_in, const int32_t* n_in_dev,
+                             int batch, const int32_t* shape_in_host,
+                             const int32_t* ksize_host, const int32_t* stride_host,
+                             const int32_t* pad_host, const int32_t* shape_out_host,
+                             void* gi_out, int32_t* idx_out, int32_t* n_out_dev,
+                             int out_cap, void* stream);
+
+/* Rulebook of spconv.SubMConv3d (spconv_backbone.py:12,78): out sites = in
+ * sites.  nbr[k*n + o] = input row at o + (k - centre) * dilation or -1.
+ * rowof may be NULL when rows are already in canonical order.
+ * pair_cnt[K] (device) receives the number of valid pairs per offset. */
+int toda_rulebook_subm(const int32_t* idx, int n, int batch, const int32_t* shape_host,
+                       const int32_t* ksize_host, const int32_t* dilation_host,
+                       const void* gi, const int32_t* rowof,
+                       int32_t* nbr, int32_t* pair_cnt, void* stream);
+/* Rulebook of spconv.SparseConv3d: nbr_o2i[k*n_out + o] = input row feeding
+ * output o through offset k; nbr_i2o[k*n_in + i] = output row fed by input i
+ * through offset k (used by dgrad). */
+int toda_rulebook_conv(const int32_t* idx_in, int n_in, int batch,
+                       const int32_t* shape_in_host, const int32_t* ksize_host,
+                       const int32_t* stride_host, const int32_t* pad_host,
+                       const int32_t* shape_out_host, const void* gi_out, int n_out,
+                       int32_t* nbr_o2i, int32_t* nbr_i2o, int32_t* pair_cnt, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Sparse convolution arithmetic (spconv SubMConv3d / SparseConv3d forward and
+ * the autograd backward reached from tools/train_utils/train_utils.py:55).
+ * All three are gather -> fp32 MFMA GEMM -> store, output stationary, no
+ * atomics in fwd/dgrad.
+ * ---------------------------------------------------------------------- */
+/* Re-order weights [Cout][K][Cin] into the MFMA fragment order the kernels
+ * read.  transpose=0: operand for fwd (gathers Cin, produces Cout).
+ * transpose=1: operand for dgrad (gathers Cout, produces Cin); flip_k=1
+ * additionally reverses the offset order (SubM dgrad reuses the forward
+ * table through the point symmetry of the stencil). */
+size_t toda_spconv_packed_weight_floats(int k_vol, int c_gather, int c_produce);
+int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int cin,
+                            int transpose, int flip_k, float* wp, void* stream);
+/* out[o, :] = bias + sum_k Wp[k] . in[nbr[k*n_out + o], :]   (rows with nbr<0 skipped) */
+int toda_spconv_gather_gemm(const float* in, int c_gather, const float* wp,
+                            const int32_t* nbr, int n_out, int k_vol, int c_produce,
+                            const float* bias /*nullable*/, float* out, void* stream);
+/* dw[co][k][ci] = sum_o in[nbr[k*n_out+o], ci] * dout[o, co] */
+size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout);
+int toda_spconv_wgrad(const float* in, const float* dout, const int32_t* nbr,
+                      int n_out, int k_vol, int cin, int cout, float* dw,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* SparseConvTensor.dense() as used by HeightCompression
+ * (pcdet/models/backbones_2d/map_to_bev/height_compression.py:21-23):
+ * dense[b, c, z, y, x] = feat[row, c]; the caller views it as [B, C*D, H, W].
+ * fwd zero-fills `dense` itself. */
+int toda_sparse_to_dense_fwd(const float* feat, const int32_t* idx, int n, int c,
+                             int batch, const int32_t* shape_host, float* dense, void* stream);
+int toda_sparse_to_dense_bwd(const float* grad_dense, const int32_t* idx, int n, int c,
+                             int batch, const int32_t* shape_host, float* grad_feat, void* stream);
+
+/* PointPillarScatter (pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py:14-37):
+ * canvas[b, c, y, x] = pillar[row, c] for coords (b, z=0, y, x). */
+int toda_pillar_scatter_fwd(const float* feat, const int32_t* idx, int n, int c,
+                            int batch, int ny, int nx, float* canvas, void* stream);
+int toda_pillar_scatter_bwd(const float* grad_canvas, const int32_t* idx, int n, int c,
+                            int batch, int ny, int nx, float* grad_feat, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused per-channel statistics / normalise+ReLU over the active rows of a
+ * sparse level: the nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU pair of
+ * post_act_block (spconv_backbone.py:8-27).
+ * ---------------------------------------------------------------------- */
+/* sums[0:c] = sum_rows x, sums[c:2c] = sum_rows x*x  (fp32 pairwise per block, fp64 merge) */
+int toda_rows_moments(const float* x, int n, int c, double* sums /*[2c], zeroed by the call*/,
+                      void* stream);
+/* y = relu?(x * scale[c] + shift[c] (+ residual)) */
+int toda_rows_affine_act(const float* x, const float* scale, const float* shift,
+                         const float* residual /*nullable*/, int n, int c, int relu,
+                         float* y, void* stream);
+
+/* ------------------------------------------------------------------------
+ * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,
+ * pcdet/models/model_utils/centernet_utils.py:9-69): gaussian heat-maps,
+ * regression targets, flat indices and masks for one head group.
+ * gt_boxes [B, G, 8] = (x y z dx dy dz heading cls_in_head(1-based, 0 = pad)).
+ * ---------------------------------------------------------------------- */
+int toda_center_assign(const float* gt_boxes, int batch, int n_gt, int code_size,
+                       int num_classes, int fm_w, int fm_h,
+                       const float* range_host /*[6]*/, const float* vsize_host /*[3]*/,
+                       int fm_stride, int max_objs, float gaussian_overlap, int min_radius,
+                       float* heatmap /*[B, num_classes, fm_h, fm_w], zero-filled by the call*/,
+                       float* ret_boxes /*[B, max_objs, code_size]*/,
+                       int64_t* inds /*[B, max_objs]*/, int64_t* mask /*[B, max_objs]*/,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TODA_H_ */

@@ -1,0 +1,506 @@
+/*
+ * toda_oracle.c — CPU restatement of the sparse hot path of rasd3/TODA.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product
+ * (toda_amd/) never does and fails loudly without libtoda_hip.so.
+ *
+ * What it restates: the reference reaches this arithmetic through the
+ * third-party `spconv` package (un-vendored, unpinned: reference setup.py:48,
+ * docker/Dockerfile:55, docs/INSTALL.md:9), so the algorithm here is the
+ * published spconv-native one (sequential first-come hard voxeliser, hashed
+ * rulebook, per-offset gather -> GEMM -> scatter-add), anchored on the
+ * reference's call sites:
+ *   voxeliser      pcdet/datasets/processor/data_processor.py:36-60,115-143
+ *   MeanVFE        pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31
+ *   SubM / Sparse  pcdet/models/backbones_3d/spconv_backbone.py:8-27,77-117
+ *   .dense()       pcdet/models/backbones_2d/map_to_bev/height_compression.py:21-23
+ *   pillar scatter pcdet/models/backbones_2d/map_to_bev/pointpillar_scatter.py:14-37
+ *   centre targets pcdet/models/dense_heads/center_head.py:103-219,
+ *                  pcdet/models/model_utils/centernet_utils.py:9-69
+ *
+ * PARITY PINNING: the reference has no tests or golden vectors for this path
+ * and spconv cannot be imported here, so the sparse part is "parity unpinned"
+ * by the reference itself; it is pinned instead by (i) equivalence with masked
+ * dense torch conv3d + autograd (tests/test_oracle_dense.py) and (ii) the
+ * hand-checkable micro cases of SURVEY.md B.5 (tests/test_oracle_micro.py).
+ * oracle_center_assign is pinned by golden vectors captured from the
+ * reference's own CenterHead.assign_targets (tests/golden/).
+ *
+ * Formats are those of include/toda.h (k-major neighbour tables, canonical
+ * ascending (b,z,y,x) order for generated index sets).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+/* ------------------------------------------------------------------ hash */
+typedef struct {
+    int64_t* keys;
+    int32_t* vals;
+    size_t cap; /* power of two */
+} omap;
+
+static int omap_init(omap* m, size_t n) {
+    size_t cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    m->cap = cap;
+    m->keys = (int64_t*)malloc(cap * sizeof(int64_t));
+    m->vals = (int32_t*)malloc(cap * sizeof(int32_t));
+    if (!m->keys || !m->vals) return -1;
+    for (size_t i = 0; i < cap; ++i) m->keys[i] = -1;
+    return 0;
+}
+static void omap_free(omap* m) {
+    free(m->keys);
+    free(m->vals);
+}
+static inline size_t omap_slot(const omap* m, int64_t key) {
+    uint64_t h = (uint64_t)key * 0x9E3779B97F4A7C15ull;
+    size_t s = (size_t)(h >> 20) & (m->cap - 1);
+    while (m->keys[s] != -1 && m->keys[s] != key) s = (s + 1) & (m->cap - 1);
+    return s;
+}
+static inline int32_t omap_get(const omap* m, int64_t key) {
+    size_t s = omap_slot(m, key);
+    return m->keys[s] == key ? m->vals[s] : -1;
+}
+/* returns existing value or inserts val and returns -1 */
+static inline int32_t omap_put_if_absent(omap* m, int64_t key, int32_t val) {
+    size_t s = omap_slot(m, key);
+    if (m->keys[s] == key) return m->vals[s];
+    m->keys[s] = key;
+    m->vals[s] = val;
+    return -1;
+}
+
+static inline int64_t lin_key(int b, int z, int y, int x, const int32_t* shape) {
+    return (((int64_t)b * shape[0] + z) * shape[1] + y) * shape[2] + x;
+}
+
+/* ------------------------------------------------------------ voxeliser */
+/* sequential; spconv >= 1.2 `continue` behaviour at the cap. */
+int oracle_voxelize_hard(const float* pts, int n, int c, const float* range,
+                         const float* vsize, const int32_t* grid /*xyz*/, int max_pts,
+                         int max_voxels, float* voxels, int32_t* coords_zyx,
+                         int32_t* num_pts, int32_t* m_out) {
+    omap map;
+    if (omap_init(&map, (size_t)(n < max_voxels ? n : max_voxels) + 1)) return -1;
+    int m = 0;
+    memset(voxels, 0, (size_t)max_voxels * max_pts * c * sizeof(float));
+    memset(num_pts, 0, (size_t)max_voxels * sizeof(int32_t));
+    for (int i = 0; i < n; ++i) {
+        const float* p = pts + (size_t)i * c;
+        int cc[3];
+        int ok = 1;
+        for (int j = 0; j < 3; ++j) {
+            float f = floorf((p[j] - range[j]) / vsize[j]);
+            /* NaN fails both comparisons below and is dropped */
+            if (!(f >= 0.0f) || !(f < (float)grid[j])) {
+                ok = 0;
+                break;
+            }
+            cc[j] = (int)f;
+        }
+        if (!ok) continue;
+        int64_t key = ((int64_t)cc[2] * grid[1] + cc[1]) * grid[0] + cc[0];
+        int32_t vid = omap_get(&map, key);
+        if (vid < 0) {
+            if (m >= max_voxels) continue;
+            vid = m++;
+            omap_put_if_absent(&map, key, vid);
+            coords_zyx[3 * vid + 0] = cc[2];
+            coords_zyx[3 * vid + 1] = cc[1];
+            coords_zyx[3 * vid + 2] = cc[0];
+        }
+        if (num_pts[vid] < max_pts) {
+            memcpy(voxels + ((size_t)vid * max_pts + num_pts[vid]) * c, p, c * sizeof(float));
+            num_pts[vid]++;
+        }
+    }
+    *m_out = m;
+    omap_free(&map);
+    return 0;
+}
+
+/* mean_vfe.py:26-28 */
+void oracle_mean_vfe_fwd(const float* voxels, const float* num_pts, int m, int p, int c,
+                         float* out) {
+    for (int v = 0; v < m; ++v) {
+        float nrm = num_pts[v] < 1.0f ? 1.0f : num_pts[v];
+        for (int j = 0; j < c; ++j) {
+            float s = 0.0f;
+            for (int q = 0; q < p; ++q) s += voxels[((size_t)v * p + q) * c + j];
+            out[(size_t)v * c + j] = s / nrm;
+        }
+    }
+}
+/* every slot (padded ones too) receives g / max(n,1) */
+void oracle_mean_vfe_bwd(const float* gout, const float* num_pts, int m, int p, int c,
+                         float* gvox) {
+    for (int v = 0; v < m; ++v) {
+        float nrm = num_pts[v] < 1.0f ? 1.0f : num_pts[v];
+        for (int q = 0; q < p; ++q)
+            for (int j = 0; j < c; ++j)
+                gvox[((size_t)v * p + q) * c + j] = gout[(size_t)v * c + j] / nrm;
+    }
+}
+
+/* ------------------------------------------------------------- rulebooks */
+/* SURVEY.md B.2 */
+int oracle_rulebook_subm(const int32_t* idx, int n, int batch, const int32_t* shape,
+                         const int32_t* ks, const int32_t* dil, int32_t* nbr,
+                         int32_t* pair_cnt) {
+    (void)batch;
+    omap map;
+    if (omap_init(&map, (size_t)n + 1)) return -1;
+    for (int i = 0; i < n; ++i)
+        omap_put_if_absent(&map, lin_key(idx[4 * i], idx[4 * i + 1], idx[4 * i + 2], idx[4 * i + 3], shape), i);
+    int K = ks[0] * ks[1] * ks[2];
+    for (int k = 0; k < K; ++k) pair_cnt[k] = 0;
+    for (int kz = 0; kz < ks[0]; ++kz)
+        for (int ky = 0; ky < ks[1]; ++ky)
+            for (int kx = 0; kx < ks[2]; ++kx) {
+                int k = (kz * ks[1] + ky) * ks[2] + kx;
+                int oz = (kz - ks[0] / 2) * dil[0], oy = (ky - ks[1] / 2) * dil[1],
+                    ox = (kx - ks[2] / 2) * dil[2];
+                for (int o = 0; o < n; ++o) {
+                    int b = idx[4 * o], z = idx[4 * o + 1] + oz, y = idx[4 * o + 2] + oy,
+                        x = idx[4 * o + 3] + ox;
+                    int32_t r = -1;
+                    if (z >= 0 && z < shape[0] && y >= 0 && y < shape[1] && x >= 0 && x < shape[2])
+                        r = omap_get(&map, lin_key(b, z, y, x, shape));
+                    nbr[(size_t)k * n + o] = r;
+                    if (r >= 0) pair_cnt[k]++;
+                }
+            }
+    omap_free(&map);
+    return 0;
+}
+
+static int cmp_i64(const void* a, const void* b) {
+    int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* for input coordinate i and kernel tap k along one axis: output coordinate or -1 */
+static inline int out_coord(int i, int k, int s, int p, int out_dim) {
+    int t = i + p - k;
+    if (t < 0 || t % s != 0) return -1;
+    t /= s;
+    return t < out_dim ? t : -1;
+}
+
+/* output index set in canonical ascending order; returns n_out or -1 */
+int oracle_conv_out_indices(const int32_t* idx_in, int n_in, int batch,
+                            const int32_t* shape_in, const int32_t* ks, const int32_t* st,
+                            const int32_t* pd, const int32_t* shape_out, int32_t* idx_out,
+                            int cap) {
+    (void)batch;
+    (void)shape_in;
+    int K = ks[0] * ks[1] * ks[2];
+    int64_t* keys = (int64_t*)malloc((size_t)n_in * K * sizeof(int64_t) + 8);
+    if (!keys) return -1;
+    size_t cnt = 0;
+    for (int i = 0; i < n_in; ++i) {
+        const int32_t* c = idx_in + 4 * i;
+        for (int kz = 0; kz < ks[0]; ++kz) {
+            int zo = out_coord(c[1], kz, st[0], pd[0], shape_out[0]);
+            if (zo < 0) continue;
+            for (int ky = 0; ky < ks[1]; ++ky) {
+                int yo = out_coord(c[2], ky, st[1], pd[1], shape_out[1]);
+                if (yo < 0) continue;
+                for (int kx = 0; kx < ks[2]; ++kx) {
+                    int xo = out_coord(c[3], kx, st[2], pd[2], shape_out[2]);
+                    if (xo < 0) continue;
+                    keys[cnt++] = lin_key(c[0], zo, yo, xo, shape_out);
+                }
+            }
+        }
+    }
+    qsort(keys, cnt, sizeof(int64_t), cmp_i64);
+    int n_out = 0;
+    for (size_t j = 0; j < cnt; ++j) {
+        if (j && keys[j] == keys[j - 1]) continue;
+        if (n_out >= cap) {
+            free(keys);
+            return -1;
+        }
+        int64_t key = keys[j];
+        int x = (int)(key % shape_out[2]);
+        key /= shape_out[2];
+        int y = (int)(key % shape_out[1]);
+        key /= shape_out[1];
+        int z = (int)(key % shape_out[0]);
+        key /= shape_out[0];
+        idx_out[4 * n_out + 0] = (int32_t)key;
+        idx_out[4 * n_out + 1] = z;
+        idx_out[4 * n_out + 2] = y;
+        idx_out[4 * n_out + 3] = x;
+        n_out++;
+    }
+    free(keys);
+    return n_out;
+}
+
+int oracle_rulebook_conv(const int32_t* idx_in, int n_in, int batch, const int32_t* shape_in,
+                         const int32_t* ks, const int32_t* st, const int32_t* pd,
+                         const int32_t* shape_out, const int32_t* idx_out, int n_out,
+                         int32_t* nbr_o2i, int32_t* nbr_i2o, int32_t* pair_cnt) {
+    (void)batch;
+    (void)shape_in;
+    omap map;
+    if (omap_init(&map, (size_t)n_out + 1)) return -1;
+    for (int o = 0; o < n_out; ++o)
+        omap_put_if_absent(&map, lin_key(idx_out[4 * o], idx_out[4 * o + 1], idx_out[4 * o + 2], idx_out[4 * o + 3], shape_out), o);
+    int K = ks[0] * ks[1] * ks[2];
+    for (size_t j = 0; j < (size_t)K * n_out; ++j) nbr_o2i[j] = -1;
+    for (size_t j = 0; j < (size_t)K * n_in; ++j) nbr_i2o[j] = -1;
+    for (int k = 0; k < K; ++k) pair_cnt[k] = 0;
+    for (int i = 0; i < n_in; ++i) {
+        const int32_t* c = idx_in + 4 * i;
+        for (int kz = 0; kz < ks[0]; ++kz) {
+            int zo = out_coord(c[1], kz, st[0], pd[0], shape_out[0]);
+            if (zo < 0) continue;
+            for (int ky = 0; ky < ks[1]; ++ky) {
+                int yo = out_coord(c[2], ky, st[1], pd[1], shape_out[1]);
+                if (yo < 0) continue;
+                for (int kx = 0; kx < ks[2]; ++kx) {
+                    int xo = out_coord(c[3], kx, st[2], pd[2], shape_out[2]);
+                    if (xo < 0) continue;
+                    int k = (kz * ks[1] + ky) * ks[2] + kx;
+                    int32_t o = omap_get(&map, lin_key(c[0], zo, yo, xo, shape_out));
+                    if (o < 0) {
+                        omap_free(&map);
+                        return -2;
+                    }
+                    nbr_o2i[(size_t)k * n_out + o] = i;
+                    nbr_i2o[(size_t)k * n_in + i] = o;
+                    pair_cnt[k]++;
+                }
+            }
+        }
+    }
+    omap_free(&map);
+    return 0;
+}
+
+/* ------------------------------------------- per-offset gather/GEMM/scatter */
+/* w is [Cout][K][Cin] (spconv-2 layout).  out[o] = bias + sum_k W_k in[nbr[k][o]] */
+void oracle_spconv_fwd(const float* in, int cin, const float* w, const int32_t* nbr, int n_out,
+                       int K, int cout, const float* bias, float* out) {
+#pragma omp parallel for schedule(static)
+    for (int o = 0; o < n_out; ++o)
+        for (int co = 0; co < cout; ++co) out[(size_t)o * cout + co] = bias ? bias[co] : 0.0f;
+    float* wk = (float*)malloc((size_t)cin * cout * sizeof(float)); /* [Cin][Cout] */
+    for (int k = 0; k < K; ++k) {
+        for (int ci = 0; ci < cin; ++ci)
+            for (int co = 0; co < cout; ++co)
+                wk[(size_t)ci * cout + co] = w[((size_t)co * K + k) * cin + ci];
+        const int32_t* nk = nbr + (size_t)k * n_out;
+#pragma omp parallel for schedule(static)
+        for (int o = 0; o < n_out; ++o) {
+            int i = nk[o];
+            if (i < 0) continue;
+            const float* a = in + (size_t)i * cin;
+            float* y = out + (size_t)o * cout;
+            for (int ci = 0; ci < cin; ++ci) {
+                float av = a[ci];
+                const float* wr = wk + (size_t)ci * cout;
+                for (int co = 0; co < cout; ++co) y[co] += av * wr[co];
+            }
+        }
+    }
+    free(wk);
+}
+
+/* din[i] = sum over pairs (i,o,k) of W_k^T dout[o].  nbr_i2o is [K][n_in]
+ * (for SubM pass the forward table and flip_k = 1). */
+void oracle_spconv_dgrad(const float* dout, int cout, const float* w, const int32_t* nbr_i2o,
+                         int n_in, int K, int cin, int flip_k, float* din) {
+    memset(din, 0, (size_t)n_in * cin * sizeof(float));
+    for (int k = 0; k < K; ++k) {
+        int kw = flip_k ? K - 1 - k : k;
+        const int32_t* nk = nbr_i2o + (size_t)k * n_in;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n_in; ++i) {
+            int o = nk[i];
+            if (o < 0) continue;
+            const float* g = dout + (size_t)o * cout;
+            float* d = din + (size_t)i * cin;
+            for (int co = 0; co < cout; ++co) {
+                float gv = g[co];
+                const float* wr = w + ((size_t)co * K + kw) * cin;
+                for (int ci = 0; ci < cin; ++ci) d[ci] += gv * wr[ci];
+            }
+        }
+    }
+}
+
+/* dw[co][k][ci] = sum_o in[nbr[k][o]][ci] * dout[o][co]; fp64 accumulation */
+void oracle_spconv_wgrad(const float* in, const float* dout, const int32_t* nbr, int n_out, int K,
+                         int cin, int cout, float* dw) {
+#pragma omp parallel for schedule(dynamic)
+    for (int k = 0; k < K; ++k) {
+        double* acc = (double*)calloc((size_t)cin * cout, sizeof(double));
+        const int32_t* nk = nbr + (size_t)k * n_out;
+        for (int o = 0; o < n_out; ++o) {
+            int i = nk[o];
+            if (i < 0) continue;
+            const float* a = in + (size_t)i * cin;
+            const float* g = dout + (size_t)o * cout;
+            for (int co = 0; co < cout; ++co) {
+                double gv = g[co];
+                double* ar = acc + (size_t)co * cin;
+                for (int ci = 0; ci < cin; ++ci) ar[ci] += gv * a[ci];
+            }
+        }
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                dw[((size_t)co * K + k) * cin + ci] = (float)acc[(size_t)co * cin + ci];
+        free(acc);
+    }
+}
+
+/* SURVEY.md B.6 */
+void oracle_sparse_to_dense_fwd(const float* feat, const int32_t* idx, int n, int c, int batch,
+                                const int32_t* shape, float* dense) {
+    size_t vol = (size_t)shape[0] * shape[1] * shape[2];
+    memset(dense, 0, (size_t)batch * c * vol * sizeof(float));
+    for (int r = 0; r < n; ++r) {
+        const int32_t* q = idx + 4 * r;
+        size_t sp = ((size_t)q[1] * shape[1] + q[2]) * shape[2] + q[3];
+        for (int j = 0; j < c; ++j) dense[((size_t)q[0] * c + j) * vol + sp] = feat[(size_t)r * c + j];
+    }
+}
+void oracle_sparse_to_dense_bwd(const float* gdense, const int32_t* idx, int n, int c, int batch,
+                                const int32_t* shape, float* gfeat) {
+    (void)batch;
+    size_t vol = (size_t)shape[0] * shape[1] * shape[2];
+    for (int r = 0; r < n; ++r) {
+        const int32_t* q = idx + 4 * r;
+        size_t sp = ((size_t)q[1] * shape[1] + q[2]) * shape[2] + q[3];
+        for (int j = 0; j < c; ++j) gfeat[(size_t)r * c + j] = gdense[((size_t)q[0] * c + j) * vol + sp];
+    }
+}
+
+/* pointpillar_scatter.py:14-37: index = z + y*nx + x with nz == 1 */
+void oracle_pillar_scatter_fwd(const float* feat, const int32_t* idx, int n, int c, int batch,
+                               int ny, int nx, float* canvas) {
+    size_t vol = (size_t)ny * nx;
+    memset(canvas, 0, (size_t)batch * c * vol * sizeof(float));
+    for (int r = 0; r < n; ++r) {
+        const int32_t* q = idx + 4 * r;
+        size_t sp = (size_t)q[1] + (size_t)q[2] * nx + q[3];
+        for (int j = 0; j < c; ++j) canvas[((size_t)q[0] * c + j) * vol + sp] = feat[(size_t)r * c + j];
+    }
+}
+
+/* ------------------------------------------------------ BN1d helper pieces */
+void oracle_rows_moments(const float* x, int n, int c, double* sums) {
+    for (int j = 0; j < 2 * c; ++j) sums[j] = 0.0;
+    for (int r = 0; r < n; ++r)
+        for (int j = 0; j < c; ++j) {
+            double v = x[(size_t)r * c + j];
+            sums[j] += v;
+            sums[c + j] += v * v;
+        }
+}
+void oracle_rows_affine_act(const float* x, const float* scale, const float* shift,
+                            const float* residual, int n, int c, int relu, float* y) {
+    for (int r = 0; r < n; ++r)
+        for (int j = 0; j < c; ++j) {
+            float v = x[(size_t)r * c + j] * scale[j] + shift[j];
+            if (residual) v += residual[(size_t)r * c + j];
+            if (relu && v < 0.0f) v = 0.0f;
+            y[(size_t)r * c + j] = v;
+        }
+}
+
+/* ------------------------------------------------- CenterHead target assign */
+/* centernet_utils.py:9-35, evaluated in fp32 in torch's left-to-right order */
+static float gaussian_radius_f32(float height, float width, double min_overlap) {
+    float b1 = height + width;
+    float c1 = width * height * (float)(1 - min_overlap) / (float)(1 + min_overlap);
+    float sq1 = sqrtf(b1 * b1 - 4.0f * c1);
+    float r1 = (b1 + sq1) / 2.0f;
+    float b2 = 2.0f * (height + width);
+    float c2 = (float)(1 - min_overlap) * width * height;
+    float sq2 = sqrtf(b2 * b2 - 16.0f * c2);
+    float r2 = (b2 + sq2) / 2.0f;
+    double a3 = 4 * min_overlap;
+    float b3 = (float)(-2 * min_overlap) * (height + width);
+    float c3 = (float)(min_overlap - 1) * width * height;
+    float sq3 = sqrtf(b3 * b3 - (float)(4 * a3) * c3);
+    float r3 = (b3 + sq3) / 2.0f;
+    float r = r1 < r2 ? r1 : r2;
+    return r < r3 ? r : r3;
+}
+
+/* center_head.py:103-157 for every sample of one head group.  gt class column
+ * (last) is already remapped to 1..num_classes within this head, 0 = skip. */
+void oracle_center_assign(const float* gt, int batch, int n_gt, int code, int num_classes,
+                          int fm_w, int fm_h, const float* range, const float* vsize,
+                          int fm_stride, int max_objs, float overlap, int min_radius,
+                          float* heatmap, float* ret_boxes, int64_t* inds, int64_t* mask) {
+    int rb = code; /* ret_boxes width = gt width - 1 + 1 */
+    memset(heatmap, 0, (size_t)batch * num_classes * fm_h * fm_w * sizeof(float));
+    memset(ret_boxes, 0, (size_t)batch * max_objs * rb * sizeof(float));
+    memset(inds, 0, (size_t)batch * max_objs * sizeof(int64_t));
+    memset(mask, 0, (size_t)batch * max_objs * sizeof(int64_t));
+    for (int b = 0; b < batch; ++b) {
+        int k = 0; /* position in the per-head compacted list */
+        for (int g = 0; g < n_gt; ++g) {
+            const float* box = gt + ((size_t)b * n_gt + g) * code;
+            int cls = (int)box[code - 1];
+            if (cls < 1 || cls > num_classes) continue;
+            int kk = k++;
+            if (kk >= max_objs) break;
+            float cx = (box[0] - range[0]) / vsize[0] / (float)fm_stride;
+            float cy = (box[1] - range[1]) / vsize[1] / (float)fm_stride;
+            float mx = (float)((double)fm_w - 0.5), my = (float)((double)fm_h - 0.5);
+            cx = cx < 0.0f ? 0.0f : (cx > mx ? mx : cx);
+            cy = cy < 0.0f ? 0.0f : (cy > my ? my : cy);
+            int ix = (int)cx, iy = (int)cy;
+            float dx = box[3] / vsize[0] / (float)fm_stride;
+            float dy = box[4] / vsize[1] / (float)fm_stride;
+            float rf = gaussian_radius_f32(dx, dy, (double)overlap);
+            int radius = (int)rf;
+            if (radius < min_radius) radius = min_radius;
+            if (dx <= 0.0f || dy <= 0.0f) continue;
+            if (!(0 <= ix && ix <= fm_w && 0 <= iy && iy <= fm_h)) continue;
+            /* draw_gaussian_to_heatmap: float64 gaussian, cast to fp32, max-blend */
+            float* hm = heatmap + ((size_t)b * num_classes + (cls - 1)) * fm_h * fm_w;
+            int diameter = 2 * radius + 1;
+            double sigma = (double)diameter / 6.0;
+            int left = ix < radius ? ix : radius;
+            int right = (fm_w - ix) < (radius + 1) ? (fm_w - ix) : (radius + 1);
+            int top = iy < radius ? iy : radius;
+            int bottom = (fm_h - iy) < (radius + 1) ? (fm_h - iy) : (radius + 1);
+            for (int yy = -top; yy < bottom; ++yy)
+                for (int xx = -left; xx < right; ++xx) {
+                    double h = exp(-(double)(xx * xx + yy * yy) / (2.0 * sigma * sigma));
+                    if (h < DBL_EPSILON * 1.0) h = 0.0;
+                    float hv = (float)h;
+                    float* cell = hm + (size_t)(iy + yy) * fm_w + (ix + xx);
+                    if (hv > *cell) *cell = hv;
+                }
+            inds[(size_t)b * max_objs + kk] = (int64_t)iy * fm_w + ix;
+            mask[(size_t)b * max_objs + kk] = 1;
+            float* rbx = ret_boxes + ((size_t)b * max_objs + kk) * rb;
+            rbx[0] = cx - (float)ix;
+            rbx[1] = cy - (float)iy;
+            rbx[2] = box[2];
+            rbx[3] = logf(box[3]);
+            rbx[4] = logf(box[4]);
+            rbx[5] = logf(box[5]);
+            rbx[6] = cosf(box[6]);
+            rbx[7] = sinf(box[6]);
+            for (int e = 8; e < rb; ++e) rbx[e] = box[e - 1];
+        }
+    }
+}
+
+int oracle_abi_version(void) { return 1; }

@@ -173,7 +173,7 @@ int toda_rows_affine_act(const float* x, const float* scale, const float* shift,
 int toda_center_assign(const float* gt_boxes, int batch, int n_gt, int code_size,
                        int num_classes, int fm_w, int fm_h,
                        const float* range_host /*[6]*/, const float* vsize_host /*[3]*/,
-                       int fm_stride, int max_objs, float gaussian_overlap, int min_radius,
+                       int fm_stride, int max_objs, double gaussian_overlap, int min_radius,
                        float* heatmap /*[B, num_classes, fm_h, fm_w], zero-filled by the call*/,
                        float* ret_boxes /*[B, max_objs, code_size]*/,
                        int64_t* inds /*[B, max_objs]*/, int64_t* mask /*[B, max_objs]*/,

@@ -211,7 +211,7 @@ def center_assign(gt_boxes, num_classes, fm_w, fm_h, pc_range, voxel_size, fm_st
     inds = np.empty((batch, max_objs), np.int64)
     mask = np.empty((batch, max_objs), np.int64)
     lib().oracle_center_assign.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib().oracle_center_assign(_p(gt), batch, n_gt, code, int(num_classes), int(fm_w), int(fm_h),
                                _p(_f32(pc_range)), _p(_f32(voxel_size)), int(fm_stride), int(max_objs),

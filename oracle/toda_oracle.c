@@ -443,7 +443,7 @@ static float gaussian_radius_f32(float height, float width, double min_overlap) 
  * (last) is already remapped to 1..num_classes within this head, 0 = skip. */
 void oracle_center_assign(const float* gt, int batch, int n_gt, int code, int num_classes,
                           int fm_w, int fm_h, const float* range, const float* vsize,
-                          int fm_stride, int max_objs, float overlap, int min_radius,
+                          int fm_stride, int max_objs, double overlap, int min_radius,
                           float* heatmap, float* ret_boxes, int64_t* inds, int64_t* mask) {
     int rb = code; /* ret_boxes width = gt width - 1 + 1 */
     memset(heatmap, 0, (size_t)batch * num_classes * fm_h * fm_w * sizeof(float));
@@ -466,7 +466,7 @@ void oracle_center_assign(const float* gt, int batch, int n_gt, int code, int nu
             int ix = (int)cx, iy = (int)cy;
             float dx = box[3] / vsize[0] / (float)fm_stride;
             float dy = box[4] / vsize[1] / (float)fm_stride;
-            float rf = gaussian_radius_f32(dx, dy, (double)overlap);
+            float rf = gaussian_radius_f32(dx, dy, overlap);
             int radius = (int)rf;
             if (radius < min_radius) radius = min_radius;
             if (dx <= 0.0f || dy <= 0.0f) continue;

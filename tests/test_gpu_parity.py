@@ -1,0 +1,282 @@
+"""GPU parity: every HIP entry point (through the C ABI) against the CPU oracle on seeded inputs.
+Integer / index results must be bit exact; fp32 arithmetic within the tolerance written per test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def lidar_points(n, c, pc_range, seed):
+    rng = np.random.default_rng(seed)
+    r = np.asarray(pc_range, np.float32)
+    pts = rng.uniform(-0.05, 1.05, (n, c)).astype(np.float32)  # ~10% outside the range
+    pts[:, :3] = r[:3] + pts[:, :3] * (r[3:] - r[:3])
+    # concentrate half of the points so that voxels overflow max_pts
+    half = n // 2
+    pts[:half, :3] = r[:3] + (pts[:half, :3] - r[:3]) * np.float32(0.05)
+    return pts[rng.permutation(n)]
+
+
+VOX_CASES = [
+    # n, c, range, voxel, P, cap
+    (20000, 4, [0, -39.68, -3, 69.12, 39.68, 1], [0.16, 0.16, 4], 32, 16000),
+    (60000, 5, [-51.2, -51.2, -5, 51.2, 51.2, 3], [0.1, 0.1, 0.2], 10, 60000),
+    (50000, 5, [-75.2, -75.2, -2, 75.2, 75.2, 4], [0.1, 0.1, 0.15], 5, 3000),  # cap is hit
+    (7, 4, [0, 0, 0, 4, 4, 2], [1, 1, 1], 2, 3),
+]
+
+
+@pytest.mark.parametrize("n,c,rng,vs,P,cap", VOX_CASES)
+def test_voxelize_bit_exact(n, c, rng, vs, P, cap):
+    from toda_amd import ops
+
+    pts = lidar_points(n, c, rng, seed=n)
+    v0, c0, n0 = O.voxelize_hard(pts, rng, vs, P, cap)
+    v1, c1, n1 = ops.voxelize(dev(pts), rng, vs, P, cap)
+    assert c1.shape[0] == c0.shape[0]
+    assert np.array_equal(c1.cpu().numpy(), c0)
+    assert np.array_equal(n1.cpu().numpy(), n0)
+    assert np.array_equal(v1.cpu().numpy(), v0)  # copies of input rows: bit exact
+
+
+def test_voxelize_empty_and_all_outside():
+    from toda_amd import ops
+
+    rng, vs = [0, 0, 0, 4, 4, 2], [1, 1, 1]
+    v, c, n = ops.voxelize(torch.zeros((0, 4), device="cuda"), rng, vs, 3, 10)
+    assert v.shape == (0, 3, 4) and c.shape == (0, 3)
+    pts = np.full((100, 4), -5.0, np.float32)
+    v, c, n = ops.voxelize(dev(pts), rng, vs, 3, 10)
+    assert v.shape[0] == 0
+
+
+def test_voxelize_batch_adds_batch_column():
+    from toda_amd import ops
+
+    rng, vs = [-51.2, -51.2, -5, 51.2, 51.2, 3], [0.1, 0.1, 0.2]
+    clouds = [lidar_points(5000 + 1000 * b, 5, rng, seed=10 + b) for b in range(3)]
+    v, c, n = ops.voxelize_batch([dev(p) for p in clouds], rng, vs, 10, 60000)
+    off = 0
+    for b, p in enumerate(clouds):
+        v0, c0, n0 = O.voxelize_hard(p, rng, vs, 10, 60000)
+        m = len(c0)
+        assert np.array_equal(c.cpu().numpy()[off:off + m, 0], np.full(m, b))
+        assert np.array_equal(c.cpu().numpy()[off:off + m, 1:], c0)
+        assert np.array_equal(v.cpu().numpy()[off:off + m], v0)
+        off += m
+    assert off == len(c)
+
+
+def test_mean_vfe_fwd_bwd():
+    from toda_amd import ops
+
+    rng = np.random.default_rng(0)
+    vox = rng.standard_normal((1000, 5, 5)).astype(np.float32)
+    num = rng.integers(0, 6, 1000).astype(np.float32)
+    for v in range(1000):
+        vox[v, int(num[v]):] = 0
+    x = dev(vox).requires_grad_(True)
+    out = ops.mean_vfe(x, dev(num))
+    assert np.array_equal(out.detach().cpu().numpy(), O.mean_vfe_fwd(vox, num))  # same summation order
+    g = rng.standard_normal((1000, 5)).astype(np.float32)
+    out.backward(dev(g))
+    assert np.array_equal(x.grad.cpu().numpy(), O.mean_vfe_bwd(g, num, 5))
+
+
+@pytest.mark.parametrize("shape,batch,npb,ks,dil", [
+    ([41, 160, 176], 2, 4000, 3, 1),
+    ([5, 9, 11], 3, 150, 3, 1),
+    ([11, 32, 32], 1, 700, (3, 1, 3), (1, 1, 2)),
+])
+def test_rulebook_subm_bit_exact(shape, batch, npb, ks, dil):
+    from toda_amd import ops
+
+    idx, _ = H.clustered_sparse(batch, shape, npb, 1, seed=7)
+    nbr0, cnt0 = O.rulebook_subm(idx, batch, shape, ks, dil)
+    rb, gi = ops.build_subm_rulebook(dev(idx), batch, shape, ks, dil)
+    assert np.array_equal(rb.nbr_fwd.cpu().numpy(), nbr0)
+    assert np.array_equal(rb.pair_cnt.cpu().numpy(), cnt0)
+
+
+CONV_GEOMS = [
+    ((3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
+    ((3, 1, 1), (2, 1, 1), (0, 0, 0)),
+]
+
+
+@pytest.mark.parametrize("ks,st,pd", CONV_GEOMS)
+def test_rulebook_conv_bit_exact(ks, st, pd):
+    from toda_amd import ops
+
+    shape, batch = [21, 96, 88], 2
+    idx, _ = H.clustered_sparse(batch, shape, 3000, 1, seed=8)
+    io0, sho0, o2i0, i2o0, cnt0 = O.rulebook_conv(idx, batch, shape, ks, st, pd)
+    io1, sho1, rb, gi = ops.build_conv_rulebook(dev(idx), batch, shape, ks, st, pd)
+    assert sho1 == sho0
+    assert np.array_equal(io1.cpu().numpy(), io0)  # canonical ascending order
+    assert np.array_equal(rb.nbr_fwd.cpu().numpy(), o2i0)
+    assert np.array_equal(rb.nbr_bwd.cpu().numpy(), i2o0)
+    assert np.array_equal(rb.pair_cnt.cpu().numpy(), cnt0)
+    # the output set's grid index serves the following SubM layer with rowof = identity
+    nbr0, cnt1 = O.rulebook_subm(io0, batch, sho0)
+    rb2, _ = ops.build_subm_rulebook(io1, batch, sho1, 3, 1, grid_index=gi)
+    assert np.array_equal(rb2.nbr_fwd.cpu().numpy(), nbr0)
+    assert np.array_equal(rb2.pair_cnt.cpu().numpy(), cnt1)
+
+
+CHANNELS = [(5, 16), (4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (24, 48)]
+
+
+@pytest.mark.parametrize("cin,cout", CHANNELS)
+def test_subm_conv_fwd_dgrad_wgrad(cin, cout):
+    """fp32 MFMA vs the oracle's per-offset gather/GEMM/scatter: |err| <= 1e-4 * scale (north star: 1e-3)."""
+    from toda_amd import ops
+
+    shape, batch = [9, 40, 44], 2
+    idx, feat = H.clustered_sparse(batch, shape, 1100, cin, seed=cin * 131 + cout)
+    rng = np.random.default_rng(1)
+    w = (rng.standard_normal((cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    nbr0, _ = O.rulebook_subm(idx, batch, shape)
+    out0 = O.spconv_fwd(feat, w, nbr0, bias)
+    g = rng.standard_normal(out0.shape).astype(np.float32)
+    din0 = O.spconv_dgrad(g, w, nbr0, flip_k=True)
+    dw0 = O.spconv_wgrad(feat, g, nbr0, w.shape)
+
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    x, wt, bt = dev(feat).requires_grad_(True), dev(w).requires_grad_(True), dev(bias).requires_grad_(True)
+    out = ops.sparse_conv(x, wt, bt, rb)
+    out.backward(dev(g))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out0, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), din0, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), dw0, rtol=1e-4, atol=1e-4 * np.abs(dw0).max())
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), g.sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("ks,st,pd", CONV_GEOMS)
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 128)])
+def test_strided_conv_fwd_dgrad_wgrad(ks, st, pd, cin, cout):
+    from toda_amd import ops
+
+    shape, batch = [11, 48, 40], 2
+    idx, feat = H.clustered_sparse(batch, shape, 1500, cin, seed=3)
+    rng = np.random.default_rng(2)
+    K = int(np.prod(ks))
+    w = (rng.standard_normal((cout,) + ks + (cin,)) / np.sqrt(K * cin)).astype(np.float32)
+    io0, sho0, o2i0, i2o0, _ = O.rulebook_conv(idx, batch, shape, ks, st, pd)
+    out0 = O.spconv_fwd(feat, w, o2i0)
+    g = rng.standard_normal(out0.shape).astype(np.float32)
+    din0 = O.spconv_dgrad(g, w, i2o0, flip_k=False)
+    dw0 = O.spconv_wgrad(feat, g, o2i0, w.shape)
+
+    io1, sho1, rb, _ = ops.build_conv_rulebook(dev(idx), batch, shape, ks, st, pd)
+    x, wt = dev(feat).requires_grad_(True), dev(w).requires_grad_(True)
+    out = ops.sparse_conv(x, wt, None, rb)
+    out.backward(dev(g))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out0, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), din0, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), dw0, rtol=1e-4, atol=1e-4 * np.abs(dw0).max())
+
+
+def test_conv_linearity_and_determinism_at_scale():
+    """Size-independent properties at a Waymo-like row count (no oracle run needed)."""
+    from toda_amd import ops
+
+    shape, batch = [41, 400, 400], 2
+    idx, feat = H.clustered_sparse(batch, shape, 60000, 16, seed=11)
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    w = dev(np.random.default_rng(3).standard_normal((32, 3, 3, 3, 16)).astype(np.float32) * 0.05)
+    x1, x2 = dev(feat), dev(feat[::-1].copy())
+    y1 = ops.sparse_conv(x1, w, None, rb)
+    y2 = ops.sparse_conv(x2, w, None, rb)
+    y12 = ops.sparse_conv(x1 + 2 * x2, w, None, rb)
+    assert torch.allclose(y12, y1 + 2 * y2, rtol=1e-4, atol=1e-4)
+    assert torch.equal(ops.sparse_conv(x1, w, None, rb), y1)  # deterministic: no atomics
+    # pair symmetry of SubM tables: nbr[k][o] = i  <=>  nbr[K-1-k][i] = o
+    nbr = rb.nbr_fwd
+    K = nbr.shape[0]
+    o = torch.arange(nbr.shape[1], device="cuda", dtype=torch.int32)
+    for k in (0, 5, 13, 20):
+        valid = nbr[k] >= 0
+        assert torch.equal(nbr[K - 1 - k][nbr[k][valid].long()], o[valid])
+    assert int(rb.pair_cnt[13]) == nbr.shape[1]
+
+
+@pytest.mark.parametrize("c", [16, 128, 20])
+def test_sparse_to_dense_fwd_bwd(c):
+    from toda_amd import ops
+
+    shape, batch = [2, 47, 53], 3
+    idx, feat = H.random_sparse(batch, shape, 1500, c, seed=5, sort=True)
+    x = dev(feat).requires_grad_(True)
+    d = ops.sparse_to_dense(x, dev(idx), batch, shape)
+    d0 = O.sparse_to_dense_fwd(feat, idx, batch, shape)
+    assert np.array_equal(d.detach().cpu().numpy(), d0)
+    g = np.random.default_rng(6).standard_normal(d0.shape).astype(np.float32)
+    d.backward(dev(g))
+    assert np.array_equal(x.grad.cpu().numpy(), O.sparse_to_dense_bwd(g, idx, shape))
+    # height compression view: channel = c*D + d
+    bev = d.view(batch, c * shape[0], shape[1], shape[2])
+    r = idx[0]
+    assert bev[r[0], 3 * shape[0] + r[1], r[2], r[3]].item() == feat[0, 3]
+
+
+def test_pillar_scatter():
+    from toda_amd import ops
+
+    ny, nx, batch, c = 62, 54, 2, 64
+    idx, feat = H.random_sparse(batch, [1, ny, nx], 900, c, seed=9)
+    x = dev(feat).requires_grad_(True)
+    canvas = ops.pillar_scatter(x, dev(idx), batch, ny, nx)
+    assert np.array_equal(canvas.detach().cpu().numpy(), O.pillar_scatter_fwd(feat, idx, batch, ny, nx))
+    canvas.sum().backward()
+    assert torch.equal(x.grad, torch.ones_like(x))
+
+
+def test_rows_moments_and_affine():
+    from toda_amd import ops
+
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((33333, 64)) * 2 + 0.5).astype(np.float32)
+    s = ops.rows_moments(dev(x)).cpu().numpy()
+    np.testing.assert_allclose(s, O.rows_moments(x), rtol=1e-5)
+    sc, sh = rng.standard_normal(64).astype(np.float32), rng.standard_normal(64).astype(np.float32)
+    res = rng.standard_normal(x.shape).astype(np.float32)
+    y = ops.rows_affine_act(dev(x), dev(sc), dev(sh), dev(res), relu=True).cpu().numpy()
+    np.testing.assert_allclose(y, O.rows_affine_act(x, sc, sh, res, True), rtol=1e-6, atol=1e-6)
+
+
+def test_center_assign_vs_oracle():
+    from toda_amd import ops
+
+    rng = np.random.default_rng(12)
+    B, G = 2, 40
+    pc_range, vs = [-75.2, -75.2, -2, 75.2, 75.2, 4], [0.1, 0.1, 0.15]
+    gt = np.zeros((B, G, 8), np.float32)
+    for b in range(B):
+        k = 30 - 7 * b
+        gt[b, :k, 0:2] = rng.uniform(-80, 80, (k, 2))  # some centres outside -> clamped
+        gt[b, :k, 2] = rng.uniform(-1, 2, k)
+        gt[b, :k, 3:6] = rng.uniform(0.5, 6, (k, 3))
+        gt[b, :k, 6] = rng.uniform(-3.14, 3.14, k)
+        gt[b, :k, 7] = rng.integers(0, 4, k)  # 0 = class of another head
+    gt[0, 3, 3] = 0.0  # degenerate box: skipped but keeps its slot
+    hm0, rb0, in0, mk0 = O.center_assign(gt, 3, 188, 188, pc_range, vs, 8, 500, 0.1, 2)
+    hm1, rb1, in1, mk1 = ops.center_assign(dev(gt), 3, 188, 188, pc_range, vs, 8, 500, 0.1, 2)
+    assert np.array_equal(in1.cpu().numpy(), in0)
+    assert np.array_equal(mk1.cpu().numpy(), mk0)
+    np.testing.assert_allclose(hm1.cpu().numpy(), hm0, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rb1.cpu().numpy(), rb0, rtol=1e-6, atol=1e-6)

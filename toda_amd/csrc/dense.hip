@@ -1,0 +1,195 @@
+// Sparse -> dense scatter (SparseConvTensor.dense() / PointPillarScatter) and the per-channel
+// row statistics / affine+ReLU passes of the BatchNorm1d+ReLU pair, for gfx950.
+// All HBM-bandwidth work.  The scatter moves a [64 rows x 32 channels] tile through LDS so that
+// feature reads are 128-byte row segments and dense writes run along x (consecutive canonical
+// rows are x-neighbours), instead of 4-byte accesses strided by a whole channel plane.
+#include "common.h"
+
+namespace toda {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DN_BLOCK = 256;
+constexpr int DN_ROWS = 64;
+constexpr int DN_CH = 32;
+
+// spatial offset of row r inside one channel plane; plane(b, c) = (b*C + c) * vol
+struct DenseGeom {
+    int D, H, W;  // pillar scatter: D = 1, H = ny, W = nx
+    int pillar;   // index = z + y*W + x (pointpillar_scatter.py:27)
+};
+
+__device__ __forceinline__ long long spatial_offset(const int4 q, const DenseGeom& g) {
+    if (g.pillar) return (long long)q.y + (long long)q.z * g.W + q.w;
+    return ((long long)q.y * g.H + q.z) * g.W + q.w;
+}
+
+template <bool FWD>
+__global__ void __launch_bounds__(DN_BLOCK)
+dense_tile_kernel(float* __restrict__ feat, const int4* __restrict__ idx, int n, int c, DenseGeom g,
+                  float* __restrict__ dense) {
+    __shared__ float tile[DN_CH][DN_ROWS + 1];
+    __shared__ long long base[DN_ROWS];  // plane-0 offset of each row: b*C*vol + spatial
+    const int row0 = blockIdx.x * DN_ROWS, c0 = blockIdx.y * DN_CH;
+    const long long vol = (long long)g.D * g.H * g.W;
+    if (threadIdx.x < DN_ROWS) {
+        const int r = row0 + threadIdx.x;
+        long long b = -1;
+        if (r < n) {
+            const int4 q = idx[r];
+            b = (long long)q.x * c * vol + spatial_offset(q, g);
+        }
+        base[threadIdx.x] = b;
+    }
+    const int fr = threadIdx.x >> 2, fc = (threadIdx.x & 3) * 8;  // feature side: 64 rows x (4 x 8 channels)
+    const int dr = threadIdx.x & 63, dc = threadIdx.x >> 6;       // dense side: row fastest
+    if (FWD) {
+        if (row0 + fr < n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = c0 + fc + j;
+                tile[fc + j][fr] = ch < c ? feat[(size_t)(row0 + fr) * c + ch] : 0.f;
+            }
+        }
+        __syncthreads();
+        const long long b = base[dr];
+        if (b >= 0) {
+#pragma unroll
+            for (int j = 0; j < DN_CH / 4; ++j) {
+                const int ch = dc + 4 * j;
+                if (c0 + ch < c) dense[b + (long long)(c0 + ch) * vol] = tile[ch][dr];
+            }
+        }
+    } else {
+        __syncthreads();
+        const long long b = base[dr];
+#pragma unroll
+        for (int j = 0; j < DN_CH / 4; ++j) {
+            const int ch = dc + 4 * j;
+            tile[ch][dr] = (b >= 0 && c0 + ch < c) ? dense[b + (long long)(c0 + ch) * vol] : 0.f;
+        }
+        __syncthreads();
+        if (row0 + fr < n) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = c0 + fc + j;
+                if (ch < c) feat[(size_t)(row0 + fr) * c + ch] = tile[fc + j][fr];
+            }
+        }
+    }
+}
+
+// per-channel sum and sum of squares over n rows.  Thread t owns channel t % c for a stripe of
+// rows; fp32 inside the thread (<= rows_per_block/(256/c) terms), fp64 across threads and blocks.
+constexpr int MOM_ROWS = 1024;
+__global__ void __launch_bounds__(DN_BLOCK)
+rows_moments_kernel(const float* __restrict__ x, int n, int c, double* __restrict__ sums) {
+    __shared__ double sh[2 * DN_BLOCK];
+    const int lanes_per_row = c;  // c <= 256 and 256 % c == 0 is required by the caller
+    const int rows_par = DN_BLOCK / lanes_per_row;
+    const int ch = threadIdx.x % lanes_per_row, rsub = threadIdx.x / lanes_per_row;
+    const int row_begin = blockIdx.x * MOM_ROWS;
+    const int row_end = min(n, row_begin + MOM_ROWS);
+    float s = 0.f, s2 = 0.f;
+    for (int r = row_begin + rsub; r < row_end; r += rows_par) {
+        const float v = x[(size_t)r * c + ch];
+        s += v;
+        s2 += v * v;
+    }
+    sh[threadIdx.x] = s;
+    sh[DN_BLOCK + threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < c) {
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < rows_par; ++j) {
+            a += sh[j * lanes_per_row + threadIdx.x];
+            b += sh[DN_BLOCK + j * lanes_per_row + threadIdx.x];
+        }
+        atomicAdd(&sums[threadIdx.x], a);
+        atomicAdd(&sums[c + threadIdx.x], b);
+    }
+}
+
+__global__ void __launch_bounds__(DN_BLOCK)
+rows_affine_act_kernel(const f32x4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                       const f32x4* __restrict__ res, long long n4, int c, int relu, f32x4* __restrict__ y) {
+    const long long t = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
+    if (t >= n4) return;
+    const int ch = (int)((t * 4) % c);
+    f32x4 v = x[t];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] * scale[ch + j] + shift[ch + j];
+    if (res) {
+        const f32x4 rr = res[t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+    }
+    if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    y[t] = v;
+}
+
+static int scatter_common(bool fwd, float* feat, const int32_t* idx, int n, int c, int batch, DenseGeom g,
+                          float* dense, hipStream_t s) {
+    TODA_CHECK_ARG(n >= 0 && c >= 1 && batch >= 1, "sparse<->dense: bad sizes n=%d c=%d batch=%d", n, c, batch);
+    const size_t total = (size_t)batch * c * g.D * g.H * g.W;
+    if (fwd) TODA_HIP(hipMemsetAsync(dense, 0, total * sizeof(float), s));
+    if (n == 0) return TODA_OK;
+    const dim3 grid(cdiv(n, DN_ROWS), cdiv(c, DN_CH));
+    if (fwd)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_tile_kernel<true>), grid, dim3(DN_BLOCK), 0, s, feat, (const int4*)idx, n,
+                           c, g, dense);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(dense_tile_kernel<false>), grid, dim3(DN_BLOCK), 0, s, feat, (const int4*)idx, n,
+                           c, g, dense);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+}  // namespace toda
+
+using namespace toda;
+
+extern "C" int toda_sparse_to_dense_fwd(const float* feat, const int32_t* idx, int n, int c, int batch,
+                                        const int32_t* shape_host, float* dense, void* stream) {
+    const DenseGeom g{shape_host[0], shape_host[1], shape_host[2], 0};
+    return scatter_common(true, const_cast<float*>(feat), idx, n, c, batch, g, dense, (hipStream_t)stream);
+}
+extern "C" int toda_sparse_to_dense_bwd(const float* grad_dense, const int32_t* idx, int n, int c, int batch,
+                                        const int32_t* shape_host, float* grad_feat, void* stream) {
+    const DenseGeom g{shape_host[0], shape_host[1], shape_host[2], 0};
+    return scatter_common(false, grad_feat, idx, n, c, batch, g, const_cast<float*>(grad_dense), (hipStream_t)stream);
+}
+extern "C" int toda_pillar_scatter_fwd(const float* feat, const int32_t* idx, int n, int c, int batch, int ny, int nx,
+                                       float* canvas, void* stream) {
+    const DenseGeom g{1, ny, nx, 1};
+    return scatter_common(true, const_cast<float*>(feat), idx, n, c, batch, g, canvas, (hipStream_t)stream);
+}
+extern "C" int toda_pillar_scatter_bwd(const float* grad_canvas, const int32_t* idx, int n, int c, int batch, int ny,
+                                       int nx, float* grad_feat, void* stream) {
+    const DenseGeom g{1, ny, nx, 1};
+    return scatter_common(false, grad_feat, idx, n, c, batch, g, const_cast<float*>(grad_canvas), (hipStream_t)stream);
+}
+
+extern "C" int toda_rows_moments(const float* x, int n, int c, double* sums, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TODA_CHECK_ARG(c >= 1 && c <= DN_BLOCK && DN_BLOCK % c == 0, "rows_moments: channels must divide 256 (got %d)", c);
+    TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
+    if (n <= 0) return TODA_OK;
+    hipLaunchKernelGGL(rows_moments_kernel, dim3(cdiv(n, MOM_ROWS)), dim3(DN_BLOCK), 0, s, x, n, c, sums);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_rows_affine_act(const float* x, const float* scale, const float* shift, const float* residual,
+                                    int n, int c, int relu, float* y, void* stream) {
+    TODA_CHECK_ARG(c >= 4 && c % 4 == 0, "rows_affine_act: channels must be a multiple of 4 (got %d)", c);
+    if (n <= 0) return TODA_OK;
+    const long long n4 = (long long)n * c / 4;
+    hipLaunchKernelGGL(rows_affine_act_kernel, dim3(cdiv(n4, DN_BLOCK)), dim3(DN_BLOCK), 0, (hipStream_t)stream,
+                       (const f32x4*)x, scale, shift, (const f32x4*)residual, n4, c, relu, (f32x4*)y);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}

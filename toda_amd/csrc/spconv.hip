@@ -1,0 +1,392 @@
+// Sparse convolution arithmetic for gfx950: weight packing, gather -> fp32-MFMA GEMM -> store
+// (forward and dgrad share one kernel), and wgrad.
+//
+// Formulation: OUTPUT STATIONARY.  A wave owns 16*RT output rows and all produced channels; for
+// each kernel offset k it gathers the neighbour rows named by the k-major table nbr[k][row]
+// straight from HBM/L2 into MFMA A-fragments (16-byte loads, no LDS round trip), multiplies by
+// the offset's weight slice (pre-packed in fragment order, 1 KiB coalesced loads that every wave
+// shares through L1/L2) with v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD) and keeps the
+// sums in registers until one vectorised store.  No atomics, deterministic, every output row is
+// written once; offsets none of whose 16*RT rows has a neighbour are skipped wave-uniformly.
+//
+// MFMA operand maps (cdna_hip_programming.md §3): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], D: col = lane&15, row = 4*(lane>>4) + reg.
+// Two layout tricks remove all shuffles:
+//   * k-permutation: lane (r, g) loads 4 CONSECUTIVE gathered channels 16q+4g..+3 as one float4;
+//     MFMA step (q, j) therefore contracts over channel 16q+4g+j in lane group g, and the packed
+//     weights are laid out with the same permutation.
+//   * channel-interleaved N tiles: column c of tile n is produced channel NT*c + n, so a lane's
+//     NT accumulators for one row are NT consecutive channels -> one 16/32-byte store.
+#include "common.h"
+
+namespace toda {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SC_BLOCK = 256;
+
+static int tiles_pow2(int channels) {
+    int t = (channels + 15) / 16, p = 1;
+    while (p < t) p <<= 1;
+    return p;
+}
+
+// wp[(((k*Q + q)*NT + n)*64 + lane)*4 + j]
+__global__ void __launch_bounds__(SC_BLOCK)
+pack_weight_kernel(const float* __restrict__ w, int cout, int K, int cin, int transpose, int flip_k, int Q, int NT,
+                   float* __restrict__ wp) {
+    const long long e = (long long)blockIdx.x * SC_BLOCK + threadIdx.x;
+    const long long total = (long long)K * Q * NT * 256;
+    if (e >= total) return;
+    const int j = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    long long t = e >> 8;
+    const int n = (int)(t % NT);
+    t /= NT;
+    const int q = (int)(t % Q);
+    const int k = (int)(t / Q);
+    const int c = lane & 15, g = lane >> 4;
+    const int gch = 16 * q + 4 * g + j;  // gathered channel
+    const int pch = NT * c + n;          // produced channel
+    const int kk = flip_k ? K - 1 - k : k;
+    float v = 0.0f;
+    if (!transpose) {
+        if (gch < cin && pch < cout) v = w[((size_t)pch * K + kk) * cin + gch];
+    } else {
+        if (gch < cout && pch < cin) v = w[((size_t)gch * K + kk) * cin + pch];
+    }
+    wp[e] = v;
+}
+
+template <int Q, int NT, int RT>
+__global__ void __launch_bounds__(SC_BLOCK)
+gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
+                   int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (SC_BLOCK / 64) + (threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = wave * (16 * RT);
+    if (row0 >= n_out) return;  // wave-uniform
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        float b = 0.0f;
+        if (bias && NT * r + n < cp) b = bias[NT * r + n];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][n] = f32x4{b, b, b, b};
+    }
+    const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
+    const bool vec = (cg & 3) == 0;
+
+    for (int k = 0; k < K; ++k) {
+        int src[RT];
+        bool hit[RT];
+        bool any = false;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = row0 + rt * 16 + r;
+            src[rt] = row < n_out ? nbr[(size_t)k * n_out + row] : -1;
+            hit[rt] = __any(src[rt] >= 0);
+            any = any || hit[rt];
+        }
+        if (!any) continue;  // wave-uniform skip of an empty offset
+
+        f32x4 a[RT][Q];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int col = 16 * q + 4 * g;
+                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (src[rt] >= 0) {
+                    const float* p = in + (size_t)src[rt] * cg + col;
+                    if (vec) {
+                        if (col < cg) v = *reinterpret_cast<const f32x4*>(p);
+                    } else {
+                        if (col + 0 < cg) v[0] = p[0];
+                        if (col + 1 < cg) v[1] = p[1];
+                        if (col + 2 < cg) v[2] = p[2];
+                        if (col + 3 < cg) v[3] = p[3];
+                    }
+                }
+                a[rt][q] = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 b = wp4[(((size_t)k * Q + q) * NT + n) * 64 + lane];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    if (hit[rt]) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[j], acc[rt][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    const bool full = cp == 16 * NT;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + rt * 16 + 4 * g + reg;
+            if (row >= n_out) continue;
+            float* dst = out + (size_t)row * cp + NT * r;
+            if (full) {
+                if constexpr (NT == 1) {
+                    dst[0] = acc[rt][0][reg];
+                } else if constexpr (NT == 2) {
+                    *reinterpret_cast<float2*>(dst) = make_float2(acc[rt][0][reg], acc[rt][1][reg]);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NT; n += 4)
+                        *reinterpret_cast<f32x4*>(dst + n) =
+                            f32x4{acc[rt][n][reg], acc[rt][n + 1][reg], acc[rt][n + 2][reg], acc[rt][n + 3][reg]};
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    if (NT * r + n < cp) dst[n] = acc[rt][n][reg];
+            }
+        }
+    }
+}
+
+// wgrad: dW[co][k][ci] = sum_o in[nbr[k][o]][ci] * dout[o][co].  Grid (row chunk, offset, channel
+// sub-block); the contraction runs over rows (4 per MFMA step, one per lane group).  The same
+// channel interleave as above turns the operand loads into MTB/NTB-wide vector loads.  Partial
+// sums go to a slab per chunk (plain stores) and a second kernel adds the slabs in fixed order:
+// deterministic, no float atomics.
+template <int MTB, int NTB>
+__global__ void __launch_bounds__(SC_BLOCK)
+wgrad_kernel(const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
+             const int* __restrict__ nbr, int n_out, int K, int rows_per_chunk, int MT, int NT, int nsub_n,
+             float* __restrict__ slab) {
+    __shared__ float red[MTB * NTB * 4 * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ii = lane & 15, g = lane >> 4;
+    const int chunk = blockIdx.x, k = blockIdx.y;
+    const int m0 = (blockIdx.z / nsub_n) * MTB, n0 = (blockIdx.z % nsub_n) * NTB;
+    const int row_begin = chunk * rows_per_chunk;
+    const int row_end = min(n_out, row_begin + rows_per_chunk);
+    const bool exact_a = cin == 16 * MT, exact_b = cout == 16 * NT;
+
+    f32x4 acc[MTB][NTB];
+#pragma unroll
+    for (int m = 0; m < MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int base = row_begin; base < row_end; base += 16) {
+        const int o = base + wv * 4 + g;
+        const int i = o < row_end ? nbr[(size_t)k * n_out + o] : -1;
+        if (!__any(i >= 0)) continue;
+        float a[MTB], b[NTB];
+#pragma unroll
+        for (int m = 0; m < MTB; ++m) a[m] = 0.f;
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) b[n] = 0.f;
+        if (i >= 0) {
+            const float* pa = in + (size_t)i * cin + MT * ii + m0;
+            const float* pb = dout + (size_t)o * cout + NT * ii + n0;
+            if (exact_a) {
+                if constexpr (MTB == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pa);
+                    a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+                } else if constexpr (MTB == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(pa);
+                    a[0] = v.x; a[1] = v.y;
+                } else {
+                    a[0] = pa[0];
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MTB; ++m)
+                    if (MT * ii + m0 + m < cin) a[m] = pa[m];
+            }
+            if (exact_b) {
+                if constexpr (NTB == 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(pb);
+                    b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
+                } else if constexpr (NTB == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(pb);
+                    b[0] = v.x; b[1] = v.y;
+                } else {
+                    b[0] = pb[0];
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+                    if (NT * ii + n0 + n < cout) b[n] = pb[n];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MTB; ++m)
+#pragma unroll
+            for (int n = 0; n < NTB; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+
+    // fold the 4 waves of the block in fixed order 0+1+2+3
+    for (int src = 1; src < SC_BLOCK / 64; ++src) {
+        if (wv == src) {
+#pragma unroll
+            for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) red[((m * NTB + n) * 4 + reg) * 64 + lane] = acc[m][n][reg];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[m][n][reg] += red[((m * NTB + n) * 4 + reg) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wv != 0) return;
+    // D: col = lane&15 -> cout tile column, row = 4*(lane>>4)+reg -> cin tile row
+    float* dst = slab + (size_t)chunk * cout * K * cin;
+#pragma unroll
+    for (int m = 0; m < MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ci = MT * (4 * g + reg) + m0 + m;
+                const int co = NT * ii + n0 + n;
+                if (ci < cin && co < cout) dst[((size_t)co * K + k) * cin + ci] = acc[m][n][reg];
+            }
+}
+
+__global__ void __launch_bounds__(SC_BLOCK)
+wgrad_reduce_kernel(const float* __restrict__ slab, int chunks, long long elems, float* __restrict__ dw) {
+    const long long e = (long long)blockIdx.x * SC_BLOCK + threadIdx.x;
+    if (e >= elems) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += slab[(size_t)c * elems + e];
+    dw[e] = s;
+}
+
+static void wgrad_plan(int n_out, int* chunks, int* rows_per_chunk) {
+    int ch = n_out / 2048;
+    if (ch < 1) ch = 1;
+    if (ch > 96) ch = 96;
+    int rpc = (n_out + ch - 1) / ch;
+    rpc = (rpc + 15) / 16 * 16;
+    if (rpc < 16) rpc = 16;
+    *rows_per_chunk = rpc;
+    *chunks = n_out > 0 ? (n_out + rpc - 1) / rpc : 1;
+}
+
+}  // namespace toda
+
+using namespace toda;
+
+extern "C" size_t toda_spconv_packed_weight_floats(int k_vol, int c_gather, int c_produce) {
+    return (size_t)k_vol * tiles_pow2(c_gather) * tiles_pow2(c_produce) * 256;
+}
+
+extern "C" int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int cin, int transpose, int flip_k,
+                                       float* wp, void* stream) {
+    TODA_CHECK_ARG(cout >= 1 && cin >= 1 && k_vol >= 1, "pack_weight: bad shape");
+    const int cgather = transpose ? cout : cin, cprod = transpose ? cin : cout;
+    TODA_CHECK_ARG(cgather <= 128 && cprod <= 128, "pack_weight: channels > 128 unsupported (gather %d, produce %d)",
+                   cgather, cprod);
+    const int Q = tiles_pow2(cgather), NT = tiles_pow2(cprod);
+    const long long total = (long long)k_vol * Q * NT * 256;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(total, SC_BLOCK)), dim3(SC_BLOCK), 0, (hipStream_t)stream, w, cout,
+                       k_vol, cin, transpose, flip_k, Q, NT, wp);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_spconv_gather_gemm(const float* in, int c_gather, const float* wp, const int32_t* nbr, int n_out,
+                                       int k_vol, int c_produce, const float* bias, float* out, void* stream) {
+    TODA_CHECK_ARG(c_gather >= 1 && c_gather <= 128 && c_produce >= 1 && c_produce <= 128,
+                   "gather_gemm: channels must be in [1,128] (gather %d, produce %d)", c_gather, c_produce);
+    TODA_CHECK_ARG(n_out >= 0 && k_vol >= 1, "gather_gemm: bad sizes");
+    if (n_out == 0) return TODA_OK;
+    const int Q = tiles_pow2(c_gather), NT = tiles_pow2(c_produce);
+    hipStream_t s = (hipStream_t)stream;
+#define GG(QQ, NN, RR)                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR>),                                             \
+                       dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, c_gather, wp, nbr, \
+                       n_out, k_vol, c_produce, bias, out)
+#define GG_ROW(QQ)                 \
+    switch (NT) {                  \
+        case 1: GG(QQ, 1, 2); break; \
+        case 2: GG(QQ, 2, 2); break; \
+        case 4: GG(QQ, 4, 2); break; \
+        default: GG(QQ, 8, 1); break; \
+    }
+    switch (Q) {
+        case 1: GG_ROW(1); break;
+        case 2: GG_ROW(2); break;
+        case 4: GG_ROW(4); break;
+        default: GG_ROW(8); break;
+    }
+#undef GG_ROW
+#undef GG
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout) {
+    int chunks, rpc;
+    wgrad_plan(n_out, &chunks, &rpc);
+    return align_up((size_t)chunks * k_vol * cin * cout * sizeof(float), 256);
+}
+
+extern "C" int toda_spconv_wgrad(const float* in, const float* dout, const int32_t* nbr, int n_out, int k_vol, int cin,
+                                 int cout, float* dw, void* ws, size_t ws_bytes, void* stream) {
+    TODA_CHECK_ARG(cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128, "wgrad: channels must be in [1,128]");
+    TODA_CHECK_ARG(n_out >= 0 && k_vol >= 1, "wgrad: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const long long elems = (long long)cout * k_vol * cin;
+    if (n_out == 0) {
+        TODA_HIP(hipMemsetAsync(dw, 0, elems * sizeof(float), s));
+        return TODA_OK;
+    }
+    int chunks, rpc;
+    wgrad_plan(n_out, &chunks, &rpc);
+    const size_t need = (size_t)chunks * elems * sizeof(float);
+    if (ws_bytes < need) {
+        set_error("wgrad: workspace %zu < required %zu", ws_bytes, need);
+        return TODA_EWORKSPACE;
+    }
+    const int MT = tiles_pow2(cin), NT = tiles_pow2(cout);
+    const int mtb = MT < 4 ? MT : 4, ntb = NT < 4 ? NT : 4;
+    const int nsub_m = MT / mtb, nsub_n = NT / ntb;
+    float* slab = (float*)ws;
+    const dim3 grid(chunks, k_vol, nsub_m * nsub_n);
+#define WG(MM, NN)                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN>), grid, dim3(SC_BLOCK), 0, s, in, cin, dout, cout, nbr,   \
+                       n_out, k_vol, rpc, MT, NT, nsub_n, slab)
+#define WG_ROW(MM)             \
+    switch (ntb) {             \
+        case 1: WG(MM, 1); break; \
+        case 2: WG(MM, 2); break; \
+        default: WG(MM, 4); break; \
+    }
+    switch (mtb) {
+        case 1: WG_ROW(1); break;
+        case 2: WG_ROW(2); break;
+        default: WG_ROW(4); break;
+    }
+#undef WG_ROW
+#undef WG
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slab, chunks, elems, dw);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}

@@ -1,0 +1,107 @@
+"""ctypes binding of libtoda_hip.so (the C ABI of include/toda.h).
+
+There is no CPU fallback: if the shared library is missing, cannot be loaded, or an entry point
+reports an error, a RuntimeError is raised.  Tensors are marshalled as raw device pointers and the
+current HIP stream; the library never allocates device memory.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtoda_hip.so")
+
+_vp, _i, _sz, _dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_double
+
+# name -> (restype, argtypes); must list every symbol include/toda.h declares
+SIGNATURES = {
+    "toda_last_error": (C.c_char_p, []),
+    "toda_abi_version": (_i, []),
+    "toda_voxelize_workspace_bytes": (_sz, [_i, _i]),
+    "toda_voxelize_hard": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "toda_mean_vfe_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "toda_mean_vfe_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "toda_gridindex_bytes": (_sz, [_i, _vp]),
+    "toda_gridindex_from_coords": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "toda_gridindex_from_conv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "toda_rulebook_subm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "toda_rulebook_conv": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "toda_spconv_packed_weight_floats": (_sz, [_i, _i, _i]),
+    "toda_spconv_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "toda_spconv_gather_gemm": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "toda_spconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "toda_spconv_wgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "toda_sparse_to_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "toda_sparse_to_dense_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "toda_pillar_scatter_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "toda_pillar_scatter_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "toda_rows_moments": (_i, [_vp, _i, _i, _vp, _vp]),
+    "toda_rows_affine_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "toda_center_assign": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _dbl, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libtoda_hip.so (once) and attach prototypes.  Raises RuntimeError when unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  toda_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().toda_last_error().decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a CUDA tensor (None -> NULL).  Refuses host tensors loudly."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("toda_amd ops need tensors on the GPU (there is no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError("toda_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def host_i32(vals):
+    arr = (C.c_int32 * len(vals))(*[int(v) for v in vals])
+    return arr
+
+
+def host_f32(vals):
+    arr = (C.c_float * len(vals))(*[float(v) for v in vals])
+    return arr
+
+
+def hptr(arr):
+    return C.cast(arr, C.c_void_p)

@@ -1,0 +1,366 @@
+"""Torch-facing operators over libtoda_hip.so: tensors in, tensors out, autograd where the
+reference differentiates (spconv convs, .dense(), MeanVFE).  Everything here runs on the GPU
+through the C ABI; host tensors raise (toda_amd.lib.ptr).
+"""
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+def grid_size_xyz(pc_range, voxel_size):
+    """reference data_processor.py:117-118: round((hi - lo) / voxel) in float64, xyz order."""
+    r = np.asarray(pc_range, dtype=np.float64)
+    return np.round((r[3:6] - r[0:3]) / np.asarray(voxel_size, dtype=np.float64)).astype(np.int64)
+
+
+# ----------------------------------------------------------------------------- voxelisation
+def voxelize_raw(points, pc_range, voxel_size, max_pts, max_voxels):
+    """One sample, no host sync.  Returns buffers sized for the cap and the device-side count."""
+    lib = L.load()
+    assert points.dtype == torch.float32 and points.dim() == 2
+    n, c = points.shape
+    dev = points.device
+    cap = int(min(max_voxels, max(n, 1)))
+    voxels = torch.empty((cap, max_pts, c), dtype=torch.float32, device=dev)
+    coords = torch.empty((cap, 3), dtype=torch.int32, device=dev)
+    num = torch.empty((cap,), dtype=torch.int32, device=dev)
+    m_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.toda_voxelize_workspace_bytes(n, cap)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    rng, vs = L.host_f32(pc_range), L.host_f32(voxel_size)
+    grid = L.host_i32(grid_size_xyz(pc_range, voxel_size))
+    rc = lib.toda_voxelize_hard(L.ptr(points.contiguous()), n, c, L.hptr(rng), L.hptr(vs), L.hptr(grid), int(max_pts),
+                                cap, L.ptr(voxels), L.ptr(coords), L.ptr(num), L.ptr(m_dev), L.ptr(ws), ws_bytes,
+                                L.stream())
+    L.check(rc, "toda_voxelize_hard")
+    return voxels, coords, num, m_dev
+
+
+def voxelize(points, pc_range, voxel_size, max_pts, max_voxels):
+    """One sample -> (voxels [M,P,C], coords_zyx [M,3] int32, num_points [M] int32)."""
+    voxels, coords, num, m_dev = voxelize_raw(points, pc_range, voxel_size, max_pts, max_voxels)
+    m = int(m_dev.item())
+    return voxels[:m], coords[:m], num[:m]
+
+
+def voxelize_batch(points_list, pc_range, voxel_size, max_pts, max_voxels):
+    """All samples of a batch with ONE host sync.  Mirrors voxelise + collate_batch
+    (reference dataset.py:161-178): coords gain the batch column -> (b, z, y, x)."""
+    raws = [voxelize_raw(p, pc_range, voxel_size, max_pts, max_voxels) for p in points_list]
+    counts = torch.cat([r[3] for r in raws]).tolist()  # the one sync
+    vox, coords, nums = [], [], []
+    for b, ((v, c, n, _), m) in enumerate(zip(raws, counts)):
+        vox.append(v[:m])
+        nums.append(n[:m])
+        cb = torch.empty((m, 4), dtype=torch.int32, device=c.device)
+        cb[:, 0] = b
+        cb[:, 1:] = c[:m]
+        coords.append(cb)
+    return torch.cat(vox), torch.cat(coords), torch.cat(nums)
+
+
+class _MeanVFE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, voxels, num_points):
+        lib = L.load()
+        m, p, c = voxels.shape
+        voxels = voxels.contiguous()
+        num_f = num_points.to(torch.float32).contiguous()
+        out = torch.empty((m, c), dtype=torch.float32, device=voxels.device)
+        L.check(lib.toda_mean_vfe_fwd(L.ptr(voxels), L.ptr(num_f), m, p, c, L.ptr(out), L.stream()), "toda_mean_vfe_fwd")
+        ctx.save_for_backward(num_f)
+        ctx.shape = (m, p, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (num_f,) = ctx.saved_tensors
+        m, p, c = ctx.shape
+        g = torch.empty((m, p, c), dtype=torch.float32, device=gout.device)
+        L.check(L.load().toda_mean_vfe_bwd(L.ptr(gout.contiguous()), L.ptr(num_f), m, p, c, L.ptr(g), L.stream()),
+                "toda_mean_vfe_bwd")
+        return g, None
+
+
+def mean_vfe(voxels, num_points):
+    return _MeanVFE.apply(voxels, num_points)
+
+
+# ------------------------------------------------------------------------------- rulebooks
+class GridIndex:
+    """Bitmap + rank dictionary of one sparse level (device workspace)."""
+
+    def __init__(self, batch, shape, device):
+        self.batch, self.shape = int(batch), [int(s) for s in shape]
+        self._shape_c = L.host_i32(self.shape)
+        nbytes = L.load().toda_gridindex_bytes(self.batch, L.hptr(self._shape_c))
+        self.buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.rowof = None  # None = rows already in canonical order
+
+    @classmethod
+    def from_coords(cls, indices, batch, shape):
+        gi = cls(batch, shape, indices.device)
+        n = indices.shape[0]
+        gi.rowof = torch.empty((max(n, 1),), dtype=torch.int32, device=indices.device)
+        rc = L.load().toda_gridindex_from_coords(L.ptr(indices), n, None, gi.batch, L.hptr(gi._shape_c), L.ptr(gi.buf),
+                                                 L.ptr(gi.rowof), L.stream())
+        L.check(rc, "toda_gridindex_from_coords")
+        return gi
+
+
+class Rulebook:
+    """Neighbour tables of one indice_key (what spconv keeps in SparseConvTensor.indice_dict)."""
+
+    def __init__(self, kind, ksize, n_in, n_out, nbr_fwd, nbr_bwd, flip_bwd, pair_cnt, **geom):
+        self.kind = kind  # 'subm' | 'conv'
+        self.ksize = ksize
+        self.k_vol = int(ksize[0] * ksize[1] * ksize[2])
+        self.n_in, self.n_out = n_in, n_out
+        self.nbr_fwd = nbr_fwd    # [K, n_out]: input row per output row and offset
+        self.nbr_bwd = nbr_bwd    # [K, n_in]: output row per input row and offset (dgrad)
+        self.flip_bwd = flip_bwd  # SubM: dgrad reuses nbr_fwd with the offsets reversed
+        self.pair_cnt = pair_cnt  # [K] int32 on device
+        self.geom = geom
+
+    def num_pairs(self):
+        return int(self.pair_cnt.sum().item())
+
+
+def conv_out_shape(shape, ksize, stride, padding):
+    return [(int(s) + 2 * p - k) // t + 1 for s, k, t, p in zip(shape, ksize, stride, padding)]
+
+
+def build_subm_rulebook(indices, batch, shape, ksize=3, dilation=1, grid_index=None):
+    lib = L.load()
+    ks, dl = _triple(ksize), _triple(dilation)
+    indices = indices.contiguous()
+    assert indices.dtype == torch.int32 and indices.shape[1] == 4
+    n = indices.shape[0]
+    if grid_index is None:
+        grid_index = GridIndex.from_coords(indices, batch, shape)
+    K = ks[0] * ks[1] * ks[2]
+    nbr = torch.empty((K, n), dtype=torch.int32, device=indices.device)
+    cnt = torch.empty((K,), dtype=torch.int32, device=indices.device)
+    ks_c, dl_c = L.host_i32(ks), L.host_i32(dl)
+    rc = lib.toda_rulebook_subm(L.ptr(indices), n, int(batch), L.hptr(grid_index._shape_c), L.hptr(ks_c), L.hptr(dl_c),
+                                L.ptr(grid_index.buf), L.ptr(grid_index.rowof), L.ptr(nbr), L.ptr(cnt), L.stream())
+    L.check(rc, "toda_rulebook_subm")
+    return Rulebook("subm", ks, n, n, nbr, nbr, True, cnt, dilation=dl), grid_index
+
+
+def build_conv_rulebook(indices, batch, shape, ksize, stride, padding):
+    """Strided sparse conv: returns (out_indices, out_shape, rulebook, grid index of the output set)."""
+    lib = L.load()
+    ks, st, pd = _triple(ksize), _triple(stride), _triple(padding)
+    indices = indices.contiguous()
+    assert indices.dtype == torch.int32 and indices.shape[1] == 4
+    n_in = indices.shape[0]
+    shape = [int(s) for s in shape]
+    out_shape = conv_out_shape(shape, ks, st, pd)
+    dev = indices.device
+    gi_out = GridIndex(batch, out_shape, dev)
+    # every input reaches at most prod(ceil(k/s)) outputs per axis; also bounded by the lattice
+    per_in = 1
+    for k, s in zip(ks, st):
+        per_in *= -(-k // s)
+    cap = int(min(n_in * per_in, batch * out_shape[0] * out_shape[1] * out_shape[2]))
+    idx_out = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
+    n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+    shi, sho = L.host_i32(shape), L.host_i32(out_shape)
+    ks_c, st_c, pd_c = L.host_i32(ks), L.host_i32(st), L.host_i32(pd)
+    rc = lib.toda_gridindex_from_conv(L.ptr(indices), n_in, None, int(batch), L.hptr(shi), L.hptr(ks_c), L.hptr(st_c),
+                                      L.hptr(pd_c), L.hptr(sho), L.ptr(gi_out.buf), L.ptr(idx_out), L.ptr(n_out_dev),
+                                      cap, L.stream())
+    L.check(rc, "toda_gridindex_from_conv")
+    n_out = int(n_out_dev.item())  # host sync: table sizes depend on it
+    if n_out > cap:
+        raise RuntimeError(f"strided rulebook: {n_out} outputs exceed the bound {cap}")
+    idx_out = idx_out[:n_out]
+    K = ks[0] * ks[1] * ks[2]
+    o2i = torch.empty((K, n_out), dtype=torch.int32, device=dev)
+    i2o = torch.empty((K, n_in), dtype=torch.int32, device=dev)
+    cnt = torch.empty((K,), dtype=torch.int32, device=dev)
+    rc = lib.toda_rulebook_conv(L.ptr(indices), n_in, int(batch), L.hptr(shi), L.hptr(ks_c), L.hptr(st_c), L.hptr(pd_c),
+                                L.hptr(sho), L.ptr(gi_out.buf), n_out, L.ptr(o2i), L.ptr(i2o), L.ptr(cnt), L.stream())
+    L.check(rc, "toda_rulebook_conv")
+    rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=st, padding=pd)
+    return idx_out, out_shape, rb, gi_out
+
+
+# --------------------------------------------------------------------------- sparse conv
+def pack_weight(weight, transpose, flip_k):
+    """weight [Cout, kz, ky, kx, Cin] -> MFMA fragment order (see csrc/spconv.hip)."""
+    lib = L.load()
+    cout, cin = weight.shape[0], weight.shape[-1]
+    K = weight.numel() // (cout * cin)
+    cg, cp = (cout, cin) if transpose else (cin, cout)
+    n = lib.toda_spconv_packed_weight_floats(K, cg, cp)
+    wp = torch.empty((n,), dtype=torch.float32, device=weight.device)
+    rc = lib.toda_spconv_pack_weight(L.ptr(weight.contiguous()), cout, K, cin, int(transpose), int(flip_k), L.ptr(wp),
+                                     L.stream())
+    L.check(rc, "toda_spconv_pack_weight")
+    return wp
+
+
+def gather_gemm(feat, wp, nbr, c_produce, bias=None):
+    lib = L.load()
+    K, n_out = nbr.shape
+    out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
+    rc = lib.toda_spconv_gather_gemm(L.ptr(feat), feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce,
+                                     L.ptr(bias), L.ptr(out), L.stream())
+    L.check(rc, "toda_spconv_gather_gemm")
+    return out
+
+
+def wgrad(feat, dout, nbr, wshape):
+    lib = L.load()
+    K, n_out = nbr.shape
+    cout, cin = wshape[0], wshape[-1]
+    dw = torch.empty(wshape, dtype=torch.float32, device=feat.device)
+    ws_bytes = lib.toda_spconv_wgrad_workspace_bytes(n_out, K, cin, cout)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=feat.device)
+    rc = lib.toda_spconv_wgrad(L.ptr(feat), L.ptr(dout), L.ptr(nbr), n_out, K, cin, cout, L.ptr(dw), L.ptr(ws),
+                               ws_bytes, L.stream())
+    L.check(rc, "toda_spconv_wgrad")
+    return dw
+
+
+class _SparseConv(torch.autograd.Function):
+    """out = conv(features; weight, bias, rulebook).  Backward = dgrad (same gather-GEMM kernel on
+    the transposed table and transposed packed weights) + wgrad, as autograd does through spconv
+    (reference tools/train_utils/train_utils.py:55)."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, rb, wp_fwd):
+        features = features.contiguous()
+        if wp_fwd is None:
+            wp_fwd = pack_weight(weight, False, False)
+        out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
+        ctx.save_for_backward(features, weight)
+        ctx.rb = rb
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        features, weight = ctx.saved_tensors
+        rb = ctx.rb
+        gout = gout.contiguous()
+        gfeat = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wp_t = pack_weight(weight, True, rb.flip_bwd)
+            gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None)
+        if ctx.needs_input_grad[1]:
+            gw = wgrad(features, gout, rb.nbr_fwd, tuple(weight.shape))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gout.sum(0)
+        return gfeat, gw, gb, None, None
+
+
+def sparse_conv(features, weight, bias, rulebook, packed_weight=None):
+    return _SparseConv.apply(features, weight, bias, rulebook, packed_weight)
+
+
+# ------------------------------------------------------------------------ sparse <-> dense
+class _ToDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, indices, batch, shape):
+        lib = L.load()
+        n, c = features.shape
+        shape = [int(s) for s in shape]
+        dense = torch.empty((batch, c, *shape), dtype=torch.float32, device=features.device)
+        sh = L.host_i32(shape)
+        rc = lib.toda_sparse_to_dense_fwd(L.ptr(features.contiguous()), L.ptr(indices), n, c, batch, L.hptr(sh),
+                                          L.ptr(dense), L.stream())
+        L.check(rc, "toda_sparse_to_dense_fwd")
+        ctx.save_for_backward(indices)
+        ctx.meta = (n, c, batch, shape)
+        return dense
+
+    @staticmethod
+    def backward(ctx, gdense):
+        (indices,) = ctx.saved_tensors
+        n, c, batch, shape = ctx.meta
+        g = torch.empty((n, c), dtype=torch.float32, device=gdense.device)
+        sh = L.host_i32(shape)
+        rc = L.load().toda_sparse_to_dense_bwd(L.ptr(gdense.contiguous()), L.ptr(indices), n, c, batch, L.hptr(sh),
+                                               L.ptr(g), L.stream())
+        L.check(rc, "toda_sparse_to_dense_bwd")
+        return g, None, None, None
+
+
+def sparse_to_dense(features, indices, batch, shape):
+    return _ToDense.apply(features, indices.contiguous(), int(batch), shape)
+
+
+class _PillarScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, indices, batch, ny, nx):
+        n, c = features.shape
+        canvas = torch.empty((batch, c, ny, nx), dtype=torch.float32, device=features.device)
+        rc = L.load().toda_pillar_scatter_fwd(L.ptr(features.contiguous()), L.ptr(indices), n, c, batch, ny, nx,
+                                              L.ptr(canvas), L.stream())
+        L.check(rc, "toda_pillar_scatter_fwd")
+        ctx.save_for_backward(indices)
+        ctx.meta = (n, c, batch, ny, nx)
+        return canvas
+
+    @staticmethod
+    def backward(ctx, gcanvas):
+        (indices,) = ctx.saved_tensors
+        n, c, batch, ny, nx = ctx.meta
+        g = torch.empty((n, c), dtype=torch.float32, device=gcanvas.device)
+        rc = L.load().toda_pillar_scatter_bwd(L.ptr(gcanvas.contiguous()), L.ptr(indices), n, c, batch, ny, nx, L.ptr(g),
+                                              L.stream())
+        L.check(rc, "toda_pillar_scatter_bwd")
+        return g, None, None, None, None
+
+
+def pillar_scatter(features, indices, batch, ny, nx):
+    return _PillarScatter.apply(features, indices.contiguous(), int(batch), int(ny), int(nx))
+
+
+# ------------------------------------------------------------------- BN1d building blocks
+def rows_moments(x):
+    n, c = x.shape
+    sums = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
+    L.check(L.load().toda_rows_moments(L.ptr(x.contiguous()), n, c, L.ptr(sums), L.stream()), "toda_rows_moments")
+    return sums
+
+
+def rows_affine_act(x, scale, shift, residual=None, relu=True):
+    n, c = x.shape
+    y = torch.empty_like(x)
+    rc = L.load().toda_rows_affine_act(L.ptr(x.contiguous()), L.ptr(scale.contiguous()), L.ptr(shift.contiguous()),
+                                       L.ptr(residual), n, c, int(bool(relu)), L.ptr(y), L.stream())
+    L.check(rc, "toda_rows_affine_act")
+    return y
+
+
+# --------------------------------------------------------------- CenterHead target assign
+def center_assign(gt_boxes, num_classes, fm_w, fm_h, pc_range, voxel_size, fm_stride, max_objs=500, overlap=0.1,
+                  min_radius=2):
+    """gt_boxes [B, G, code] with the class column already remapped to 1..num_classes of this head
+    (0 = not in this head / padding).  Returns heatmap, ret_boxes, inds (int64), mask (int64)."""
+    lib = L.load()
+    gt = gt_boxes.to(torch.float32).contiguous()
+    batch, n_gt, code = gt.shape
+    dev = gt.device
+    hm = torch.empty((batch, num_classes, fm_h, fm_w), dtype=torch.float32, device=dev)
+    rb = torch.empty((batch, max_objs, code), dtype=torch.float32, device=dev)
+    inds = torch.empty((batch, max_objs), dtype=torch.int64, device=dev)
+    mask = torch.empty((batch, max_objs), dtype=torch.int64, device=dev)
+    rng, vs = L.host_f32(pc_range), L.host_f32(voxel_size)
+    rc = lib.toda_center_assign(L.ptr(gt), batch, n_gt, code, int(num_classes), int(fm_w), int(fm_h), L.hptr(rng),
+                                L.hptr(vs), int(fm_stride), int(max_objs), float(overlap), int(min_radius), L.ptr(hm),
+                                L.ptr(rb), L.ptr(inds), L.ptr(mask), L.stream())
+    L.check(rc, "toda_center_assign")
+    return hm, rb, inds, mask

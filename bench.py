@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py — training samples/s of the TODA LiDAR-detection hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one batch of synthetic clouds that are already resident in
+HBM: GPU voxelisation + MeanVFE -> VoxelBackBone8x (rulebooks + sparse convs) -> HeightCompression
+-> BaseBEVBackbone -> CenterHead (GPU target assignment, losses) -> backward -> grad-norm clip ->
+Adam one-cycle step.  Workload at every N: BASELINE.json configs[2]/[3] (CenterPoint-Voxel on
+180k-point Waymo-shape clouds, 2 samples per GPU, fp32) — the configuration the "training
+samples/s" metric is quoted on; scenes are sharded across ranks (weak scaling), the only exchange
+is the gradient all-reduce.  One JSON line on rank 0 (contract in the task prompt) carrying
+`roofline` (dominant hand-written kernel, HIP events inside the timed region) and `cpu_baseline`
+(the CPU oracle port + torch-CPU dense part, timed on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from toda_amd import ops  # noqa: E402
+from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file  # noqa: E402
+from toda_amd.pcdet.datasets import SyntheticLidarDataset  # noqa: E402
+from toda_amd.pcdet.models import build_network, voxelize_on_gpu  # noqa: E402
+from toda_amd.tools.train_utils.optimization import build_optimizer, build_scheduler  # noqa: E402
+
+WORKLOADS = {
+    # name: (yaml, samples per GPU, description)
+    "c3": ("toda_amd/tools/cfgs/models/centerpoint_voxel_waymo.yaml", 2,
+           "CenterPoint-Voxel fwd+bwd+optimizer, synthetic 180k-pt Waymo-shape clouds, bs 2 per GPU"),
+    "c5": ("toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml", 2,
+           "TODA stage-1 CenterPoint (VoxelResBackBone8x), mixed 180k/35k-pt clouds, bs 2 per GPU"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA peak (dense)
+
+
+def load_cfg(path):
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(ROOT, path), cfg)
+    return cfg
+
+
+def make_device_batches(dataset, per_gpu, n_batches, rank, device):
+    """Collated batches with `points` / `gt_boxes` already on the device (inputs resident in HBM)."""
+    batches = []
+    for b in range(n_batches):
+        base = (rank * n_batches + b) * per_gpu
+        samples = [dataset[(base + i) % len(dataset)] for i in range(per_gpu)]
+        col = dataset.collate_batch(samples)
+        out = {"batch_size": col["batch_size"], "points_per_sample": col["points_per_sample"]}
+        out["points"] = torch.from_numpy(col["points"]).float().to(device)
+        out["gt_boxes"] = torch.from_numpy(col["gt_boxes"]).float().to(device)
+        batches.append(out)
+    return batches
+
+
+class KernelTimer:
+    """HIP-event timing of one operator family on the current stream (the stream the C ABI is
+    launched on).  Wraps toda_amd.ops.gather_gemm: label = (rows, K, c_in, c_out)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+        self._orig = ops.gather_gemm
+
+        def timed(feat, wp, nbr, c_produce, bias=None):
+            if not self.enabled:
+                return self._orig(feat, wp, nbr, c_produce, bias)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._orig(feat, wp, nbr, c_produce, bias)
+            e1.record()
+            self.records.append((e0, e1, nbr, feat.shape[0], feat.shape[1], c_produce))
+            return out
+
+        ops.gather_gemm = timed
+
+    def summary(self):
+        """Per launch shape: mean ms, algorithmic bytes and flops (valid pairs counted exactly)."""
+        groups, pair_cache = {}, {}
+        for e0, e1, nbr, n_src, cg, cp in self.records:
+            key = (nbr.data_ptr(), n_src, cg, cp)
+            if nbr.data_ptr() not in pair_cache:
+                pair_cache[nbr.data_ptr()] = int((nbr >= 0).sum().item())
+            g = groups.setdefault(key, {"ms": [], "pairs": pair_cache[nbr.data_ptr()], "n_out": nbr.shape[1],
+                                        "K": nbr.shape[0], "n_src": n_src, "cg": cg, "cp": cp})
+            g["ms"].append(e0.elapsed_time(e1))
+        return groups
+
+
+def run_gpu(args, rank, world, device):
+    yaml_path, per_gpu, desc = WORKLOADS[args.workload]
+    cfg = load_cfg(yaml_path)
+    dataset = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    torch.manual_seed(1234)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), dataset).to(device)
+    model.train()
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    total_steps = max(args.steps + args.warmup, 10)
+    scheduler, _ = build_scheduler(optimizer, total_steps, 1, -1, cfg.OPTIMIZATION)
+    net = model
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
+    batches = make_device_batches(dataset, per_gpu, args.batches, rank, device)
+    params = [p for p in net.parameters() if p.requires_grad]
+    clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
+    timer = KernelTimer()
+
+    def step(it):
+        scheduler.step(it)
+        optimizer.zero_grad()
+        batch = dict(batches[it % len(batches)])
+        voxelize_on_gpu(batch, dataset.voxel_cfg)
+        ret, tb, _ = model(batch)
+        loss = ret["loss"].mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, clip)
+        optimizer.step()
+        net.update_global_step()
+        return loss
+
+    for it in range(args.warmup):
+        loss = step(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for it in range(args.warmup, args.warmup + args.steps):
+        loss = step(it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+    assert np.isfinite(final_loss), "training diverged"
+    return {"elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
+            "dataset": dataset, "model": net}
+
+
+def roofline_from_timer(timer):
+    """Dominant gather-GEMM launch shape (largest total time inside the timed region)."""
+    groups = timer.summary()
+    if not groups:
+        return None, []
+    rows = []
+    for g in groups.values():
+        ms = float(np.mean(g["ms"]))
+        # B = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*Pairs ; FLOPs = 2*Pairs*Cin*Cout
+        bytes_alg = 4.0 * (g["n_src"] * g["cg"] + g["n_out"] * g["cp"] + g["K"] * g["cg"] * g["cp"]) + 8.0 * g["pairs"]
+        flops = 2.0 * g["pairs"] * g["cg"] * g["cp"]
+        t_hbm, t_mfma = bytes_alg / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
+        rows.append({"n_out": g["n_out"], "K": g["K"], "c_gather": g["cg"], "c_produce": g["cp"], "pairs": g["pairs"],
+                     "launches": len(g["ms"]), "ms": ms, "total_ms": float(np.sum(g["ms"])), "bytes": bytes_alg,
+                     "flops": flops, "bound": "hbm" if t_hbm >= t_mfma else "mfma",
+                     "frac": max(t_hbm, t_mfma) / (ms * 1e-3)})
+    rows.sort(key=lambda r: -r["total_ms"])
+    d = rows[0]
+    if d["bound"] == "hbm":
+        achieved, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+    roof = {"bound": d["bound"], "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": f"gather_gemm_kernel rows={d['n_out']} K={d['K']} {d['c_gather']}->{d['c_produce']} pairs={d['pairs']}",
+            "avg_launch_ms": round(d["ms"], 4)}
+    return roof, rows
+
+
+def cpu_baseline(cfg, n_points=180000):
+    """The same train step on the host cores: CPU oracle for the sparse part (oracle/, "port"), torch
+    CPU for the dense part, on a BOUNDED sample: ONE full-size scene (bs 1), two train steps."""
+    from oracle.cpu_backend import oracle_backend
+    from toda_amd.pcdet.models import model_fn_decorator
+
+    cfg = copy.deepcopy(cfg)
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = n_points
+    dataset = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    torch.manual_seed(1234)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), dataset)
+    model.train()
+    optimizer = build_optimizer(model, cfg.OPTIMIZATION)
+    fn = model_fn_decorator()
+    batch = dataset.collate_batch([dataset[0]])
+    times = []
+    with oracle_backend():
+        for it in range(2):
+            t0 = time.perf_counter()
+            optimizer.zero_grad()
+            ret = fn(model, dict(batch))
+            ret.loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+            optimizer.step()
+            times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(1.0 / best, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 scene of {n_points} points (bs 1 instead of 2), best of 2 full train steps, "
+                      f"{best:.2f} s/step; sparse part = oracle/ C port (OpenMP), dense part = torch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batches", type=int, default=2, help="distinct pre-generated batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="also print the per-shape gather-GEMM table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    res = run_gpu(args, rank, world, device)
+    if rank == 0:
+        per_gpu = res["per_gpu"]
+        total_samples = args.steps * per_gpu * world
+        roof, rows = roofline_from_timer(res["timer"])
+        if args.layers:
+            for r in rows:
+                print(json.dumps(r), file=sys.stderr)
+        line = {
+            "metric": "LiDAR training samples/sec", "value": round(total_samples / res["elapsed"], 3),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": res["desc"], "global_batch": per_gpu * world, "points_per_cloud": 180000,
+                       "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(res["cfg"])
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""DataProcessor (reference pcdet/datasets/processor/data_processor.py:63-211): the per-sample
+queue range-mask -> shuffle -> voxelise, selected by NAME from the DATA_PROCESSOR list.
+
+transform_points_to_voxels has two modes (config key VOXELIZE_ON, default 'gpu_batch'):
+  'gpu_batch'  defer to the training process: the model function voxelises the whole batch on the
+               MI355X (toda_amd.pcdet.models.voxelize_on_gpu) - no [M,P,C] tensor crosses PCIe;
+  'sample'     voxelise here through the spconv-style generator (toda_amd.spconv.utils), which
+               also runs on the GPU; use with num_workers=0."""
+from functools import partial
+
+import numpy as np
+
+from ...utils import common_utils
+
+
+def mask_boxes_outside_range(boxes, limit_range, min_num_corners=1):
+    """Keep boxes with >= min_num_corners BEV corners inside the x/y range (reference
+    box_utils.mask_boxes_outside_range_numpy)."""
+    if boxes.shape[0] == 0:
+        return np.zeros((0,), dtype=bool)
+    half = boxes[:, 3:5] / 2
+    signs = np.array([[1, 1], [1, -1], [-1, -1], [-1, 1]], dtype=boxes.dtype)
+    local = signs[None] * half[:, None, :]                        # [N, 4, 2]
+    c, s = np.cos(boxes[:, 6]), np.sin(boxes[:, 6])
+    rot = np.stack([np.stack([c, -s], -1), np.stack([s, c], -1)], -2)  # [N, 2, 2]
+    corners = np.einsum("nij,nkj->nki", rot, local) + boxes[:, None, 0:2]
+    inside = ((corners >= np.asarray(limit_range[0:2])) & (corners <= np.asarray(limit_range[3:5]))).all(-1)
+    return inside.sum(1) >= min_num_corners
+
+
+class DataProcessor:
+    def __init__(self, processor_configs, point_cloud_range, training, num_point_features):
+        self.point_cloud_range = np.asarray(point_cloud_range, dtype=np.float32)
+        self.training = training
+        self.num_point_features = num_point_features
+        self.mode = "train" if training else "test"
+        self.grid_size = self.voxel_size = None
+        self.voxel_cfg = None
+        self.voxel_generator = None
+        self.data_processor_queue = [getattr(self, c.NAME)(config=c) for c in processor_configs]
+
+    def mask_points_and_boxes_outside_range(self, data_dict=None, config=None):
+        if data_dict is None:
+            return partial(self.mask_points_and_boxes_outside_range, config=config)
+        if data_dict.get("points") is not None:
+            keep = common_utils.mask_points_by_range(data_dict["points"], self.point_cloud_range)
+            data_dict["points"] = data_dict["points"][keep]
+        if data_dict.get("gt_boxes") is not None and config.REMOVE_OUTSIDE_BOXES and self.training:
+            keep = mask_boxes_outside_range(data_dict["gt_boxes"], self.point_cloud_range,
+                                            min_num_corners=config.get("min_num_corners", 1))
+            data_dict["gt_boxes"] = data_dict["gt_boxes"][keep]
+        return data_dict
+
+    def shuffle_points(self, data_dict=None, config=None):
+        if data_dict is None:
+            return partial(self.shuffle_points, config=config)
+        if config.SHUFFLE_ENABLED[self.mode]:
+            rng = data_dict.get("_rng")
+            n = data_dict["points"].shape[0]
+            order = rng.permutation(n) if rng is not None else np.random.permutation(n)
+            data_dict["points"] = data_dict["points"][order]
+        return data_dict
+
+    def _bind_voxel_geometry(self, config):
+        extent = (self.point_cloud_range[3:6] - self.point_cloud_range[0:3]).astype(np.float64)
+        self.grid_size = np.round(extent / np.array(config.VOXEL_SIZE, dtype=np.float64)).astype(np.int64)
+        self.voxel_size = list(config.VOXEL_SIZE)
+        self.voxel_cfg = {
+            "point_cloud_range": [float(v) for v in self.point_cloud_range],
+            "voxel_size": [float(v) for v in config.VOXEL_SIZE],
+            "max_points_per_voxel": int(config.MAX_POINTS_PER_VOXEL),
+            "max_num_voxels": int(config.MAX_NUMBER_OF_VOXELS[self.mode]),
+        }
+
+    def transform_points_to_voxels_placeholder(self, data_dict=None, config=None):
+        if data_dict is None:
+            self._bind_voxel_geometry(config)
+            return partial(self.transform_points_to_voxels_placeholder, config=config)
+        return data_dict
+
+    def transform_points_to_voxels(self, data_dict=None, config=None):
+        if data_dict is None:
+            self._bind_voxel_geometry(config)
+            return partial(self.transform_points_to_voxels, config=config)
+        if config.get("VOXELIZE_ON", "gpu_batch") == "gpu_batch":
+            return data_dict
+        if self.voxel_generator is None:  # built lazily, as the reference does (pickling)
+            from .... import spconv
+            self.voxel_generator = spconv.utils.VoxelGenerator(
+                voxel_size=self.voxel_cfg["voxel_size"], point_cloud_range=self.voxel_cfg["point_cloud_range"],
+                max_num_points=self.voxel_cfg["max_points_per_voxel"], max_voxels=self.voxel_cfg["max_num_voxels"])
+        voxels, coords, num = self.voxel_generator.generate(np.ascontiguousarray(data_dict["points"], np.float32))
+        if not data_dict["use_lead_xyz"]:
+            voxels = voxels[..., 3:]
+        data_dict.update(voxels=voxels, voxel_coords=coords, voxel_num_points=num)
+        return data_dict
+
+    def forward(self, data_dict):
+        for step in self.data_processor_queue:
+            data_dict = step(data_dict=data_dict)
+        return data_dict

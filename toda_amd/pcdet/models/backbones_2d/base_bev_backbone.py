@@ -1,0 +1,65 @@
+"""BaseBEVBackbone (reference pcdet/models/backbones_2d/base_bev_backbone.py:7-112): per level a
+strided 3x3 conv (explicit ZeroPad2d) + LAYER_NUMS 3x3 convs, each conv -> BN(eps 1e-3, mom .01)
+-> ReLU; per level an up-sampling deblock; concatenation over channels.  Module indices inside
+`blocks[i]` / `deblocks[i]` match the reference so state_dicts are interchangeable."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
+
+
+class BaseBEVBackbone(nn.Module):
+    def __init__(self, model_cfg, input_channels):
+        super().__init__()
+        self.model_cfg = model_cfg
+        layer_nums = list(model_cfg.get("LAYER_NUMS", None) or [])
+        layer_strides = list(model_cfg.get("LAYER_STRIDES", None) or [])
+        num_filters = list(model_cfg.get("NUM_FILTERS", None) or [])
+        assert len(layer_nums) == len(layer_strides) == len(num_filters)
+        up_strides = list(model_cfg.get("UPSAMPLE_STRIDES", None) or [])
+        up_filters = list(model_cfg.get("NUM_UPSAMPLE_FILTERS", None) or [])
+        assert len(up_strides) == len(up_filters)
+
+        self.blocks, self.deblocks = nn.ModuleList(), nn.ModuleList()
+        c_prev = input_channels
+        for lvl, (n_layers, stride, width) in enumerate(zip(layer_nums, layer_strides, num_filters)):
+            seq = [nn.ZeroPad2d(1), nn.Conv2d(c_prev, width, 3, stride=stride, padding=0, bias=False), _bn(width),
+                   nn.ReLU()]
+            for _ in range(n_layers):
+                seq += [nn.Conv2d(width, width, 3, padding=1, bias=False), _bn(width), nn.ReLU()]
+            self.blocks.append(nn.Sequential(*seq))
+            c_prev = width
+            if up_strides:
+                s = up_strides[lvl]
+                if s >= 1:
+                    up = nn.ConvTranspose2d(width, up_filters[lvl], s, stride=s, bias=False)
+                else:
+                    k = int(np.round(1 / s))
+                    up = nn.Conv2d(width, up_filters[lvl], k, stride=k, bias=False)
+                self.deblocks.append(nn.Sequential(up, _bn(up_filters[lvl]), nn.ReLU()))
+        c_cat = sum(up_filters)
+        if len(up_strides) > len(layer_nums):
+            s = up_strides[-1]
+            self.deblocks.append(nn.Sequential(nn.ConvTranspose2d(c_cat, c_cat, s, stride=s, bias=False), _bn(c_cat),
+                                               nn.ReLU()))
+        self.num_bev_features = c_cat
+
+    def forward(self, data_dict):
+        x = data_dict["spatial_features"]
+        h0 = x.shape[2]
+        ups = []
+        for lvl, block in enumerate(self.blocks):
+            x = block(x)
+            data_dict[f"spatial_features_{int(h0 / x.shape[2])}x"] = x
+            ups.append(self.deblocks[lvl](x) if len(self.deblocks) > 0 else x)
+        if len(ups) > 1:
+            x = torch.cat(ups, dim=1)
+        elif len(ups) == 1:
+            x = ups[0]
+        if len(self.deblocks) > len(self.blocks):
+            x = self.deblocks[-1](x)
+        data_dict["spatial_features_2d"] = x
+        return data_dict

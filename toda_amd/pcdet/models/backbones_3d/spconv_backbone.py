@@ -1,0 +1,134 @@
+"""VoxelBackBone8x / VoxelResBackBone8x (reference pcdet/models/backbones_3d/spconv_backbone.py:
+69-293) over the MI355X sparse-conv operators.  Module names and nesting reproduce the
+reference's state_dict keys (conv_input.0.weight, conv2.0.0.weight, conv1.0.conv1.weight, ...)."""
+from functools import partial
+
+import torch.nn as nn
+
+from ...utils.spconv_utils import replace_feature, spconv
+
+
+def post_act_block(in_channels, out_channels, kernel_size, indice_key=None, stride=1, padding=0, conv_type="subm",
+                   norm_fn=None):
+    """conv -> norm -> ReLU as one SparseSequential (keys .0 / .1)."""
+    if conv_type == "subm":
+        conv = spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=False, indice_key=indice_key)
+    elif conv_type == "spconv":
+        conv = spconv.SparseConv3d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False,
+                                   indice_key=indice_key)
+    elif conv_type == "inverseconv":
+        conv = spconv.SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False)
+    else:
+        raise NotImplementedError(conv_type)
+    return spconv.SparseSequential(conv, norm_fn(out_channels), nn.ReLU())
+
+
+class SparseBasicBlock(spconv.SparseModule):
+    """Two SubM convs (with bias) + BN, identity shortcut, ReLU after the sum."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, norm_fn=None, downsample=None, indice_key=None):
+        super().__init__()
+        assert norm_fn is not None
+        self.conv1 = spconv.SubMConv3d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=True,
+                                       indice_key=indice_key)
+        self.bn1 = norm_fn(planes)
+        self.relu = nn.ReLU()
+        self.conv2 = spconv.SubMConv3d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=True,
+                                       indice_key=indice_key)
+        self.bn2 = norm_fn(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        y = self.conv1(x)
+        y = replace_feature(y, self.relu(self.bn1(y.features)))
+        y = self.conv2(y)
+        y = replace_feature(y, self.bn2(y.features))
+        return replace_feature(y, self.relu(y.features + shortcut.features))
+
+
+def _emit(batch_dict, out, stages):
+    batch_dict.update({
+        "encoded_spconv_tensor": out,
+        "encoded_spconv_tensor_stride": 8,
+        "multi_scale_3d_features": {f"x_conv{i + 1}": s for i, s in enumerate(stages)},
+        "multi_scale_3d_strides": {f"x_conv{i + 1}": 2 ** i for i in range(len(stages))},
+    })
+    return batch_dict
+
+
+class _Backbone8xBase(nn.Module):
+    def _input_tensor(self, batch_dict):
+        return spconv.SparseConvTensor(
+            features=batch_dict["voxel_features"],
+            indices=batch_dict["voxel_coords"].int(),
+            spatial_shape=self.sparse_shape,
+            batch_size=batch_dict["batch_size"],
+        )
+
+    def forward(self, batch_dict):
+        x = self.conv_input(self._input_tensor(batch_dict))
+        stages = []
+        for stage in (self.conv1, self.conv2, self.conv3, self.conv4):
+            x = stage(x)
+            stages.append(x)
+        return _emit(batch_dict, self.conv_out(x), stages)
+
+
+class VoxelBackBone8x(_Backbone8xBase):
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        gx, gy, gz = (int(v) for v in grid_size)
+        self.sparse_shape = [gz + 1, gy, gx]
+        blk = partial(post_act_block, norm_fn=norm_fn)
+
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key="subm1"), norm_fn(16), nn.ReLU())
+        self.conv1 = spconv.SparseSequential(blk(16, 16, 3, padding=1, indice_key="subm1"))
+        widths = {2: (16, 32, 1), 3: (32, 64, 1), 4: (64, 64, (0, 1, 1))}
+        for lvl, (cin, cout, pad) in widths.items():
+            setattr(self, f"conv{lvl}", spconv.SparseSequential(
+                blk(cin, cout, 3, stride=2, padding=pad, indice_key=f"spconv{lvl}", conv_type="spconv"),
+                blk(cout, cout, 3, padding=1, indice_key=f"subm{lvl}"),
+                blk(cout, cout, 3, padding=1, indice_key=f"subm{lvl}"),
+            ))
+        last_pad = self.model_cfg.get("last_pad", 0)
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(64, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key="spconv_down2"),
+            norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+        self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 64}
+
+
+class VoxelResBackBone8x(_Backbone8xBase):
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        gx, gy, gz = (int(v) for v in grid_size)
+        self.sparse_shape = [gz + 1, gy, gx]
+        blk = partial(post_act_block, norm_fn=norm_fn)
+        res = partial(SparseBasicBlock, norm_fn=norm_fn)
+
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, 16, 3, padding=1, bias=False, indice_key="subm1"), norm_fn(16), nn.ReLU())
+        self.conv1 = spconv.SparseSequential(res(16, 16, indice_key="res1"), res(16, 16, indice_key="res1"))
+        widths = {2: (16, 32, 1), 3: (32, 64, 1), 4: (64, 128, (0, 1, 1))}
+        for lvl, (cin, cout, pad) in widths.items():
+            setattr(self, f"conv{lvl}", spconv.SparseSequential(
+                blk(cin, cout, 3, stride=2, padding=pad, indice_key=f"spconv{lvl}", conv_type="spconv"),
+                res(cout, cout, indice_key=f"res{lvl}"),
+                res(cout, cout, indice_key=f"res{lvl}"),
+            ))
+        last_pad = self.model_cfg.get("last_pad", 0)
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv3d(128, 128, (3, 1, 1), stride=(2, 1, 1), padding=last_pad, bias=False,
+                                indice_key="spconv_down2"),
+            norm_fn(128), nn.ReLU())
+        self.num_point_features = 128
+        self.backbone_channels = {"x_conv1": 16, "x_conv2": 32, "x_conv3": 64, "x_conv4": 128}

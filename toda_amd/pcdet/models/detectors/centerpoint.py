@@ -1,0 +1,23 @@
+"""CenterPoint (reference pcdet/models/detectors/centerpoint.py:5-63)."""
+from .detector3d_template import Detector3DTemplate
+
+
+class CenterPoint(Detector3DTemplate):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+        self.module_list = self.build_networks()
+
+    def forward(self, batch_dict):
+        for module in self.module_list:
+            batch_dict = module(batch_dict)
+        if self.training:
+            loss, tb_dict, disp_dict = self.get_training_loss()
+            return {"loss": loss}, tb_dict, disp_dict
+        return self.post_processing(batch_dict)
+
+    def get_training_loss(self):
+        loss_rpn, tb_dict = self.dense_head.get_loss()
+        return loss_rpn, {"loss_rpn": loss_rpn.detach(), **tb_dict}, {}
+
+    def post_processing(self, batch_dict):
+        return batch_dict["final_box_dicts"], {}

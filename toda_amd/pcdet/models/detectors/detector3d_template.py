@@ -1,0 +1,170 @@
+"""Detector3DTemplate (reference pcdet/models/detectors/detector3d_template.py:14-411): module
+topology, registry-driven builders, checkpoint loading with the spconv-1.x -> 2.x weight layout
+conversion.  Only the voxel / pillar single-stage topology is populated (pfe / point_head /
+roi_head builders return None: out of scope)."""
+import os
+
+import torch
+import torch.nn as nn
+
+from ...utils.spconv_utils import find_all_spconv_keys
+from .. import backbones_2d, backbones_3d, dense_heads
+from ..backbones_2d import map_to_bev
+from ..backbones_3d import vfe
+
+
+class Detector3DTemplate(nn.Module):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.dataset = dataset
+        self.class_names = dataset.class_names
+        self.register_buffer("global_step", torch.LongTensor(1).zero_())
+        self.module_topology = ["vfe", "backbone_3d", "map_to_bev_module", "pfe", "backbone_2d", "dense_head",
+                                "point_head", "roi_head"]
+
+    @property
+    def mode(self):
+        return "TRAIN" if self.training else "TEST"
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def build_networks(self):
+        enc = self.dataset.point_feature_encoder
+        info = {
+            "module_list": [],
+            "num_rawpoint_features": enc.num_point_features,
+            "num_point_features": enc.num_point_features,
+            "grid_size": self.dataset.grid_size,
+            "point_cloud_range": self.dataset.point_cloud_range,
+            "voxel_size": self.dataset.voxel_size,
+            "depth_downsample_factor": getattr(self.dataset, "depth_downsample_factor", None),
+        }
+        for name in self.module_topology:
+            module, info = getattr(self, f"build_{name}")(model_info_dict=info)
+            self.add_module(name, module)
+        return info["module_list"]
+
+    def _section(self, key):
+        return self.model_cfg.get(key, None)
+
+    def build_vfe(self, model_info_dict):
+        cfg = self._section("VFE")
+        if cfg is None:
+            return None, model_info_dict
+        m = vfe.__all__[cfg.NAME](
+            model_cfg=cfg, num_point_features=model_info_dict["num_rawpoint_features"],
+            point_cloud_range=model_info_dict["point_cloud_range"], voxel_size=model_info_dict["voxel_size"],
+            grid_size=model_info_dict["grid_size"], depth_downsample_factor=model_info_dict["depth_downsample_factor"])
+        model_info_dict["num_point_features"] = m.get_output_feature_dim()
+        model_info_dict["module_list"].append(m)
+        return m, model_info_dict
+
+    def build_backbone_3d(self, model_info_dict):
+        cfg = self._section("BACKBONE_3D")
+        if cfg is None:
+            return None, model_info_dict
+        m = backbones_3d.__all__[cfg.NAME](
+            model_cfg=cfg, input_channels=model_info_dict["num_point_features"],
+            grid_size=model_info_dict["grid_size"], voxel_size=model_info_dict["voxel_size"],
+            point_cloud_range=model_info_dict["point_cloud_range"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_point_features"] = m.num_point_features
+        model_info_dict["backbone_channels"] = getattr(m, "backbone_channels", None)
+        return m, model_info_dict
+
+    def build_map_to_bev_module(self, model_info_dict):
+        cfg = self._section("MAP_TO_BEV")
+        if cfg is None:
+            return None, model_info_dict
+        m = map_to_bev.__all__[cfg.NAME](model_cfg=cfg, grid_size=model_info_dict["grid_size"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_bev_features"] = m.num_bev_features
+        return m, model_info_dict
+
+    def build_backbone_2d(self, model_info_dict):
+        cfg = self._section("BACKBONE_2D")
+        if cfg is None:
+            return None, model_info_dict
+        m = backbones_2d.__all__[cfg.NAME](model_cfg=cfg, input_channels=model_info_dict["num_bev_features"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_bev_features"] = m.num_bev_features
+        return m, model_info_dict
+
+    def build_dense_head(self, model_info_dict):
+        cfg = self._section("DENSE_HEAD")
+        if cfg is None:
+            return None, model_info_dict
+        m = dense_heads.__all__[cfg.NAME](
+            model_cfg=cfg, input_channels=model_info_dict["num_bev_features"],
+            num_class=self.num_class if not cfg.CLASS_AGNOSTIC else 1, class_names=self.class_names,
+            grid_size=model_info_dict["grid_size"], point_cloud_range=model_info_dict["point_cloud_range"],
+            predict_boxes_when_training=bool(self.model_cfg.get("ROI_HEAD", False)),
+            voxel_size=model_info_dict.get("voxel_size", False))
+        model_info_dict["module_list"].append(m)
+        return m, model_info_dict
+
+    def _unsupported(self, key, model_info_dict):
+        if self._section(key) is not None:
+            raise NotImplementedError(f"MODEL.{key} belongs to two-stage / point detectors: out of scope (DESIGN.md)")
+        return None, model_info_dict
+
+    def build_pfe(self, model_info_dict):
+        return self._unsupported("PFE", model_info_dict)
+
+    def build_point_head(self, model_info_dict):
+        return self._unsupported("POINT_HEAD", model_info_dict)
+
+    def build_roi_head(self, model_info_dict):
+        return self._unsupported("ROI_HEAD", model_info_dict)
+
+    def forward(self, **kwargs):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------- checkpoints
+    def _load_state_dict(self, model_state_disk, *, strict=True):
+        """Accept spconv-1.x weights [kz,ky,kx,Cin,Cout] into our spconv-2.x [Cout,kz,ky,kx,Cin]
+        parameters (reference :330-359); keys whose shape still differs are skipped."""
+        state = self.state_dict()
+        spconv_keys = find_all_spconv_keys(self)
+        update = {}
+        for key, val in model_state_disk.items():
+            if key in spconv_keys and key in state and state[key].shape != val.shape:
+                if val.dim() == 5:
+                    native = val.transpose(-1, -2)           # [k,k,k,Cout,Cin]
+                    if native.shape == state[key].shape:
+                        val = native.contiguous()
+                    else:
+                        implicit = val.permute(4, 0, 1, 2, 3)  # [Cout,k,k,k,Cin]
+                        if implicit.shape == state[key].shape:
+                            val = implicit.contiguous()
+            if key in state and state[key].shape == val.shape:
+                update[key] = val
+        if strict:
+            self.load_state_dict(update)
+        else:
+            state.update(update)
+            self.load_state_dict(state)
+        return state, update
+
+    def load_params_from_file(self, filename, logger=None, to_cpu=False):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None)
+        state, update = self._load_state_dict(ckpt["model_state"], strict=False)
+        if logger is not None:
+            for key in state:
+                if key not in update:
+                    logger.info(f"Not updated weight {key}: {tuple(state[key].shape)}")
+            logger.info(f"==> Done (loaded {len(update)}/{len(state)})")
+
+    def load_params_with_optimizer(self, filename, to_cpu=False, optimizer=None, logger=None):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError(filename)
+        ckpt = torch.load(filename, map_location=torch.device("cpu") if to_cpu else None)
+        self._load_state_dict(ckpt["model_state"], strict=True)
+        if optimizer is not None and ckpt.get("optimizer_state") is not None:
+            optimizer.load_state_dict(ckpt["optimizer_state"])
+        return ckpt.get("it", 0.0), ckpt.get("epoch", -1)

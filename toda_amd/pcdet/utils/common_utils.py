@@ -1,0 +1,92 @@
+"""Small host utilities shared by the trainers (reference pcdet/utils/common_utils.py)."""
+import logging
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def check_numpy_to_torch(x):
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(x).float(), True
+    return x, False
+
+
+def limit_period(val, offset=0.5, period=np.pi):
+    val, is_numpy = check_numpy_to_torch(val)
+    ans = val - torch.floor(val / period + offset) * period
+    return ans.numpy() if is_numpy else ans
+
+
+def mask_points_by_range(points, limit_range):
+    """x/y only, both ends inclusive (reference common_utils.py:60-63; z is NOT tested)."""
+    return (points[:, 0] >= limit_range[0]) & (points[:, 0] <= limit_range[3]) \
+        & (points[:, 1] >= limit_range[1]) & (points[:, 1] <= limit_range[4])
+
+
+def set_random_seed(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+
+
+def create_logger(log_file=None, rank=0, log_level=logging.INFO):
+    logger = logging.getLogger(__name__)
+    logger.setLevel(log_level if rank == 0 else "ERROR")
+    logger.handlers.clear()
+    fmt = logging.Formatter("%(asctime)s  %(levelname)5s  %(message)s")
+    console = logging.StreamHandler()
+    console.setLevel(log_level if rank == 0 else "ERROR")
+    console.setFormatter(fmt)
+    logger.addHandler(console)
+    if log_file is not None:
+        fh = logging.FileHandler(filename=log_file)
+        fh.setLevel(log_level if rank == 0 else "ERROR")
+        fh.setFormatter(fmt)
+        logger.addHandler(fh)
+    logger.propagate = False
+    return logger
+
+
+def get_dist_info(return_gpu_per_machine=False):
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world = 0, 1
+    if return_gpu_per_machine:
+        return rank, world, max(torch.cuda.device_count(), 1)
+    return rank, world
+
+
+def init_dist_pytorch(tcp_port=None, local_rank=None, backend="nccl"):
+    """torchrun / torch.distributed.launch rendezvous (reference common_utils.py:161-176).
+    backend 'nccl' is RCCL on ROCm.  Rank / world size come from the environment."""
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if tcp_port is not None:
+            os.environ.setdefault("MASTER_PORT", str(tcp_port))
+        dist.init_process_group(backend=backend)
+    return dist.get_world_size(), dist.get_rank()
+
+
+class AverageMeter:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = 0.0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count

@@ -1,0 +1,120 @@
+"""SparseConvolution family: SubMConv3d / SparseConv3d with spconv-2 parameter names and weight
+layout [Cout, kz, ky, kx, Cin], so reference checkpoints load key-for-key
+(reference detector3d_template.py:330-359).  Arithmetic: toda_amd.ops -> libtoda_hip.so."""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .core import SparseConvTensor
+from .modules import SparseModule
+
+
+def _triple(v):
+    return [int(x) for x in v] if isinstance(v, (list, tuple)) else [int(v)] * 3
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 algo=None, fp32_accum=None, name=None):
+        super().__init__()
+        if ndim != 3:
+            raise NotImplementedError("only 3-D sparse convolution is on this path")
+        if groups != 1 or transposed:
+            raise NotImplementedError("groups != 1 / transposed sparse conv are not on this path")
+        if inverse:
+            raise NotImplementedError("SparseInverseConv3d (UNetV2 only) is out of scope, see DESIGN.md")
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _triple(kernel_size)
+        self.stride, self.padding, self.dilation = _triple(stride), _triple(padding), _triple(dilation)
+        self.subm, self.inverse, self.transposed = subm, inverse, transposed
+        self.indice_key = indice_key
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+        self._packed = None  # (version, data_ptr, packed forward weights)
+
+    def reset_parameters(self):
+        # same recipe as torch's _ConvNd: kaiming_uniform(a=sqrt(5)) over fan_in = K * Cin
+        fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        bound = math.sqrt(6.0 / ((1 + 5.0) * fan_in))
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                b = 1.0 / math.sqrt(fan_in)
+                self.bias.uniform_(-b, b)
+
+    def extra_repr(self):
+        s = f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}"
+        s += f", padding={self.padding}, subm={self.subm}, indice_key={self.indice_key}"
+        return s + (", bias=False" if self.bias is None else "")
+
+    def _packed_forward_weight(self):
+        w = self.weight
+        tag = (w._version, w.data_ptr())
+        if self._packed is None or self._packed[0] != tag:
+            with torch.no_grad():
+                self._packed = (tag, ops.pack_weight(w.detach(), False, False))
+        return self._packed[1]
+
+    def _rulebook(self, x):
+        """Find or build the rulebook; returns (rulebook, out_indices, out_shape, out_grid_index)."""
+        cached = x.find_indice_pair(self.indice_key)
+        if self.subm:
+            if cached is not None and cached["n_in"] == x.indices.shape[0] and cached["kind"] == "subm":
+                return cached["rb"], x.indices, x.spatial_shape, x.grid_index
+            rb, gi = ops.build_subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
+                                             self.dilation, grid_index=x.grid_index)
+            x.grid_index = gi
+            if self.indice_key is not None:
+                x.indice_dict[self.indice_key] = {"kind": "subm", "rb": rb, "n_in": x.indices.shape[0]}
+            return rb, x.indices, x.spatial_shape, gi
+        if cached is not None and cached["kind"] == "conv" and cached["n_in"] == x.indices.shape[0]:
+            return cached["rb"], cached["out_indices"], cached["out_shape"], cached["gi"]
+        if any(d != 1 for d in self.dilation):
+            raise NotImplementedError("dilated strided sparse conv is not on this path")
+        out_idx, out_shape, rb, gi = ops.build_conv_rulebook(x.indices, x.batch_size, x.spatial_shape,
+                                                            self.kernel_size, self.stride, self.padding)
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = {"kind": "conv", "rb": rb, "n_in": x.indices.shape[0],
+                                              "out_indices": out_idx, "out_shape": out_shape, "gi": gi}
+        return rb, out_idx, out_shape, gi
+
+    def forward(self, x):
+        if not isinstance(x, SparseConvTensor):
+            raise TypeError("sparse convolution expects a SparseConvTensor")
+        if x.features.shape[1] != self.in_channels:
+            raise ValueError(f"expected {self.in_channels} input channels, got {x.features.shape[1]}")
+        rb, out_idx, out_shape, gi = self._rulebook(x)
+        packed = self._packed_forward_weight()
+        feats = ops.sparse_conv(x.features, self.weight, self.bias, rb, packed)
+        out = SparseConvTensor(feats, out_idx, out_shape, x.batch_size, indice_dict=x.indice_dict)
+        out.grid_index = gi
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        # stride/padding are accepted and ignored like spconv does for submanifold convs
+        super().__init__(3, in_channels, out_channels, kernel_size, 1, padding, dilation, groups, bias, subm=True,
+                         indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None, algo=None, fp32_accum=None, name=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         subm=False, indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, **kw):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)

@@ -1,0 +1,52 @@
+"""SparseModule / SparseSequential (spconv.SparseSequential as used by post_act_block,
+reference spconv_backbone.py:8-27): dense nn.Modules inside the sequence act on .features."""
+from collections import OrderedDict
+
+import torch.nn as nn
+
+from .core import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """Marker base class: modules that consume and return a SparseConvTensor."""
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for name, module in args[0].items():
+                self.add_module(name, module)
+        else:
+            for i, module in enumerate(args):
+                self.add_module(str(i), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError(f"duplicate module name {name}")
+            self.add_module(name, module)
+
+    def __getitem__(self, i):
+        if not -len(self) <= i < len(self):
+            raise IndexError(i)
+        return list(self._modules.values())[i % len(self)]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        self.add_module(name if name is not None else str(len(self._modules)), module)
+
+    def forward(self, x):
+        for module in self._modules.values():
+            if is_spconv_module(module):
+                x = module(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.features.shape[0] != 0:
+                    x = x.replace_feature(module(x.features))
+            else:
+                x = module(x)
+        return x

@@ -1,0 +1,158 @@
+"""Optimizer + LR schedule of the reference trainers (tools/train_utils/optimization/__init__.py:11-63,
+fastai_optim.py:104-236, learning_schedules_fastai.py:12-79), restated for the GPU:
+
+  adam_onecycle = Adam(betas=(mom, 0.99), eps 1e-8) with DECOUPLED weight decay applied before the
+  step (p *= 1 - wd*lr, BN parameters included), two parameter groups (non-BN leaves / BN leaves),
+  lr and beta1 driven per iteration by a one-cycle cosine schedule.
+
+The reference walks every parameter in Python (one tiny kernel each); here the decay is one
+torch._foreach_mul_ per group and Adam runs in its multi-tensor form."""
+import math
+
+import torch
+import torch.nn as nn
+
+BN_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d, nn.SyncBatchNorm)
+
+
+def split_bn_params(model):
+    """(non-BN leaf params, BN leaf params) in module traversal order, trainable only."""
+    plain, bn = [], []
+
+    def visit(m):
+        kids = list(m.children())
+        if kids:
+            for k in kids:
+                visit(k)
+            return
+        dst = bn if isinstance(m, BN_TYPES) else plain
+        dst.extend(p for p in m.parameters(recurse=False) if p.requires_grad)
+
+    visit(model)
+    # parameters registered directly on non-leaf modules (none in the reference's models)
+    seen = {id(p) for p in plain + bn}
+    plain.extend(p for p in model.parameters() if p.requires_grad and id(p) not in seen)
+    return plain, bn
+
+
+class OneCycleAdam:
+    """The reference's OptimWrapper(Adam, true_wd=True, bn_wd=True) with its `lr` / `mom` properties."""
+
+    def __init__(self, model, wd, betas=(0.9, 0.99), lr=3e-3, fused=None):
+        plain, bn = split_bn_params(model)
+        groups = [{"params": plain, "lr": 0.0}, {"params": bn, "lr": 0.0}]
+        kw = {}
+        if fused is None:
+            fused = all(p.is_cuda for p in plain + bn) and len(plain + bn) > 0
+        if fused:
+            kw["fused"] = True
+        else:
+            kw["foreach"] = True
+        self.opt = torch.optim.Adam(groups, betas=betas, weight_decay=0.0, **kw)
+        self.wd = wd
+        self.true_wd, self.bn_wd = True, True
+        self._beta2 = betas[1]
+        self.lr, self.mom = lr, betas[0]
+
+    # hyper-parameters as properties, like the reference wrapper
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, val):
+        self._lr = float(val)
+        for g in self.opt.param_groups:
+            g["lr"] = self._lr
+
+    @property
+    def mom(self):
+        return self._mom
+
+    @mom.setter
+    def mom(self, val):
+        self._mom = float(val)
+        for g in self.opt.param_groups:
+            g["betas"] = (self._mom, self._beta2)
+
+    @property
+    def param_groups(self):
+        return self.opt.param_groups
+
+    def zero_grad(self, set_to_none=True):
+        self.opt.zero_grad(set_to_none=set_to_none)
+
+    @torch.no_grad()
+    def step(self):
+        factor = 1.0 - self.wd * self._lr
+        for g in self.opt.param_groups:
+            ps = [p for p in g["params"] if p.requires_grad]
+            if ps:
+                torch._foreach_mul_(ps, factor)
+        self.opt.step()
+
+    def state_dict(self):
+        return self.opt.state_dict()
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd)
+
+
+def annealing_cos(start, end, pct):
+    return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
+
+
+class OneCycle:
+    """lr: lr_max/div -> lr_max over the first pct_start of the steps, then -> lr_max/div/1e4;
+    momentum mirrors it moms[0] -> moms[1] -> moms[0].  step(it) sets both on the optimizer."""
+
+    def __init__(self, optimizer, total_step, lr_max, moms, div_factor, pct_start):
+        self.optimizer = optimizer
+        self.total_step = int(total_step)
+        self.lr_max, self.moms, self.div_factor, self.pct_start = lr_max, list(moms), div_factor, pct_start
+        low = lr_max / div_factor
+        split = int(pct_start * self.total_step)
+        # (first step, last step, lr from, lr to, mom from, mom to)
+        self.phases = [(0, split, low, lr_max, self.moms[0], self.moms[1]),
+                       (split, self.total_step, lr_max, low / 1e4, self.moms[1], self.moms[0])]
+        optimizer.lr, optimizer.mom = low, self.moms[0]
+
+    def values(self, step):
+        lr, mom = self.optimizer.lr, self.optimizer.mom
+        for start, end, lr0, lr1, m0, m1 in self.phases:
+            if step >= start:
+                pct = (step - start) / (end - start)
+                lr, mom = annealing_cos(lr0, lr1, pct), annealing_cos(m0, m1, pct)
+        return lr, mom
+
+    def step(self, step):
+        self.optimizer.lr, self.optimizer.mom = self.values(step)
+
+
+def build_optimizer(model, optim_cfg):
+    if optim_cfg.OPTIMIZER == "adam":
+        return torch.optim.Adam(model.parameters(), lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY)
+    if optim_cfg.OPTIMIZER == "sgd":
+        return torch.optim.SGD(model.parameters(), lr=optim_cfg.LR, weight_decay=optim_cfg.WEIGHT_DECAY,
+                               momentum=optim_cfg.MOMENTUM)
+    if optim_cfg.OPTIMIZER == "adam_onecycle":
+        return OneCycleAdam(model, wd=optim_cfg.WEIGHT_DECAY, betas=(0.9, 0.99), lr=3e-3)
+    raise NotImplementedError(optim_cfg.OPTIMIZER)
+
+
+def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch, optim_cfg):
+    total_steps = total_iters_each_epoch * total_epochs
+    if optim_cfg.OPTIMIZER == "adam_onecycle":
+        sched = OneCycle(optimizer, total_steps, optim_cfg.LR, list(optim_cfg.MOMS), optim_cfg.DIV_FACTOR,
+                         optim_cfg.PCT_START)
+        return sched, None
+    decay_steps = [x * total_iters_each_epoch for x in optim_cfg.DECAY_STEP_LIST]
+
+    def factor(cur):
+        f = 1.0
+        for s in decay_steps:
+            if cur >= s:
+                f *= optim_cfg.LR_DECAY
+        return max(f, optim_cfg.LR_CLIP / optim_cfg.LR)
+
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch=last_epoch), None

@@ -1,0 +1,235 @@
+"""Golden vectors captured from the reference's own torch-only modules (tests/golden/*.npz, made by
+tests/golden/capture_reference.py in the build container) against (a) the CPU oracle and (b) this
+repo's host-side mirror of the reference interface.  CPU-only; the GPU twins live in
+tests/test_gpu_golden.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle.cpu_backend import oracle_backend
+from toda_amd.pcdet.config import AttrDict
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def load_weights(module, g, prefix="w."):
+    sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def test_mean_vfe_oracle_matches_reference():
+    g = load("mean_vfe")
+    np.testing.assert_allclose(O.mean_vfe_fwd(g["voxels"], g["num"]), g["out"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(O.mean_vfe_bwd(g["gout"], g["num"], 5), g["gvoxels"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["center_assign_waymo", "center_head"])
+def test_center_assign_oracle_matches_reference(name):
+    g = load(name)
+    fm = g["heatmap"].shape[-1]
+    hm, rb, inds, mask = O.center_assign(g["gt"], 3, fm, fm, g["pc_range"], g["voxel_size"], 8, 500, 0.1, 2)
+    assert np.array_equal(inds, g["inds"])
+    assert np.array_equal(mask, g["masks"])
+    np.testing.assert_allclose(hm, g["heatmap"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(rb, g["target_boxes"], rtol=1e-6, atol=1e-6)
+
+
+def test_center_assign_two_heads_oracle_matches_reference():
+    g = load("center_assign_two_heads")
+    for head, classes in enumerate([[1], [2, 3]]):
+        gt = g["gt"].copy()
+        lut = np.zeros(4, np.float32)
+        for local, c in enumerate(classes):
+            lut[c] = local + 1
+        gt[..., 7] = lut[gt[..., 7].astype(int)]
+        hm, rb, inds, mask = O.center_assign(gt, len(classes), 188, 188, g["pc_range"], g["voxel_size"], 8, 500, 0.1, 2)
+        assert np.array_equal(inds, g[f"inds{head}"])
+        assert np.array_equal(mask, g[f"masks{head}"])
+        np.testing.assert_allclose(hm, g[f"heatmap{head}"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(rb, g[f"target_boxes{head}"], rtol=1e-6, atol=1e-6)
+
+
+BEV_CFG = dict(LAYER_NUMS=[1, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[8, 16], UPSAMPLE_STRIDES=[1, 2],
+               NUM_UPSAMPLE_FILTERS=[16, 16])
+
+
+def test_bev_backbone_matches_reference():
+    from toda_amd.pcdet.models.backbones_2d import BaseBEVBackbone
+
+    g = load("bev_backbone")
+    m = BaseBEVBackbone(AttrDict(BEV_CFG), 12).train()
+    load_weights(m, g)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = m({"spatial_features": x})["spatial_features_2d"]
+    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-5, atol=1e-5)
+    y.backward(torch.from_numpy(g["gy"]))
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-4, atol=1e-5)
+    for n, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.numpy(), g["g." + n], rtol=1e-4, atol=1e-4)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), g["after." + k], rtol=1e-5, atol=1e-6)
+
+
+HEAD_CFG = dict(
+    CLASS_AGNOSTIC=False, CLASS_NAMES_EACH_HEAD=[["Vehicle", "Pedestrian", "Cyclist"]], SHARED_CONV_CHANNEL=16,
+    USE_BIAS_BEFORE_NORM=True, NUM_HM_CONV=2,
+    SEPARATE_HEAD_CFG=dict(HEAD_ORDER=["center", "center_z", "dim", "rot"],
+                           HEAD_DICT=dict(center=dict(out_channels=2, num_conv=2), center_z=dict(out_channels=1, num_conv=2),
+                                          dim=dict(out_channels=3, num_conv=2), rot=dict(out_channels=2, num_conv=2))),
+    TARGET_ASSIGNER_CONFIG=dict(FEATURE_MAP_STRIDE=8, NUM_MAX_OBJS=500, GAUSSIAN_OVERLAP=0.1, MIN_RADIUS=2),
+    LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=2.0, code_weights=[1.0] * 8)),
+    POST_PROCESSING=dict(SCORE_THRESH=0.1, POST_CENTER_LIMIT_RANGE=[-75.2, -75.2, -2, 75.2, 75.2, 4], MAX_OBJ_PER_SAMPLE=500,
+                         NMS_CONFIG=dict(NMS_TYPE="nms_gpu", NMS_THRESH=0.7, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=500)),
+)
+
+
+def build_head(g):
+    from toda_amd.pcdet.models.dense_heads import CenterHead
+
+    head = CenterHead(AttrDict(HEAD_CFG), 24, 3, ["Vehicle", "Pedestrian", "Cyclist"], np.array([128, 128, 40]),
+                      g["pc_range"], list(g["voxel_size"]), predict_boxes_when_training=False).train()
+    load_weights(head, g)
+    return head
+
+
+def test_center_head_forward_targets_loss_backward_match_reference():
+    g = load("center_head")
+    head = build_head(g)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    with oracle_backend():  # target assignment through the CPU oracle (the product uses the HIP kernel)
+        head({"spatial_features_2d": x, "gt_boxes": torch.from_numpy(g["gt"].copy()), "batch_size": 2})
+    td = head.forward_ret_dict["target_dicts"]
+    assert np.array_equal(td["inds"][0].numpy(), g["inds"])
+    assert np.array_equal(td["masks"][0].numpy(), g["masks"])
+    np.testing.assert_allclose(td["heatmaps"][0].numpy(), g["heatmap"], atol=1e-7)
+    for k, v in head.forward_ret_dict["pred_dicts"][0].items():
+        np.testing.assert_allclose(v.detach().numpy(), g["pred." + k], rtol=1e-4, atol=1e-5)
+    loss, tb = head.get_loss()
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * max(1, float(g["loss"]))
+    assert abs(float(tb["hm_loss_head_0"]) - float(g["hm_loss"])) < 1e-4 * max(1, float(g["hm_loss"]))
+    assert abs(float(tb["loc_loss_head_0"]) - float(g["loc_loss"])) < 1e-4 * max(1, float(g["loc_loss"]))
+    loss.backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-3, atol=1e-5)
+    for n, p in head.named_parameters():
+        if "g." + n in g:
+            np.testing.assert_allclose(p.grad.numpy(), g["g." + n], rtol=1e-3, atol=1e-4, err_msg=n)
+
+
+def test_focal_loss_branch_free_form_equals_reference_branches():
+    from toda_amd.pcdet.utils.loss_utils import neg_loss_cornernet
+
+    pred = torch.rand(2, 3, 8, 8).clamp(1e-4, 1 - 1e-4)
+    gt = torch.rand(2, 3, 8, 8) * 0.9
+    ref_no_pos = -(torch.log(1 - pred) * pred ** 2 * (1 - gt) ** 4).sum()
+    assert torch.allclose(neg_loss_cornernet(pred, gt), ref_no_pos)  # num_pos == 0 branch
+
+
+def test_onecycle_and_decoupled_adam_match_reference():
+    import torch.nn as nn
+    from toda_amd.tools.train_utils.optimization import OneCycle, OneCycleAdam
+
+    g = load("optim_onecycle")
+    model = nn.Sequential(nn.Linear(6, 8), nn.BatchNorm1d(8), nn.ReLU(), nn.Linear(8, 3))
+    load_weights(model, g)
+    opt = OneCycleAdam(model, wd=0.01, fused=False)
+    assert [len(gr["params"]) for gr in opt.param_groups] == list(g["groups"])
+    sched = OneCycle(opt, 100, 1e-3, [0.95, 0.85], 10, 0.4)
+    for it in range(100):
+        sched.step(it)
+        assert abs(opt.lr - g["lrs"][it]) < 1e-12 and abs(opt.mom - g["moms"][it]) < 1e-12
+    sched2 = OneCycle(opt, 10, 3e-3, [0.95, 0.85], 10, 0.4)
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["t"])
+    for it in range(3):
+        sched2.step(it)
+        opt.zero_grad()
+        ((model(x) - t) ** 2).mean().backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+        opt.step()
+        for k, v in model.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[f"s{it}.{k}"], rtol=1e-5, atol=1e-6, err_msg=f"step {it} {k}")
+
+
+def test_anchor_head_losses_match_reference():
+    from toda_amd.pcdet.utils import loss_utils as lu
+
+    g = load("anchor_losses")
+    T = torch.from_numpy
+    focal = lu.SigmoidFocalClassificationLoss(alpha=0.25, gamma=2.0)(T(g["logits"]), T(g["onehot"]), T(g["w"]))
+    np.testing.assert_allclose(focal.numpy(), g["focal"], rtol=1e-5, atol=1e-7)
+    sl1 = lu.WeightedSmoothL1Loss(code_weights=[1, 1, 1, 1, 1, 1, 0.5])(T(g["a"]), T(g["b"]), T(g["w"]))
+    np.testing.assert_allclose(sl1.numpy(), g["sl1"], rtol=1e-5, atol=1e-7)
+    ce = lu.WeightedCrossEntropyLoss()(T(g["d"]), T(g["dt"]), T(g["w"]))
+    np.testing.assert_allclose(ce.numpy(), g["ce"], rtol=1e-5, atol=1e-7)
+
+
+C1_VOXEL = [0.16, 0.16, 4]
+C1_VFE = dict(WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, USE_NORM=True, NUM_FILTERS=[32])
+C1_BEV = dict(LAYER_NUMS=[1, 1, 1], LAYER_STRIDES=[2, 2, 2], NUM_FILTERS=[16, 16, 32], UPSAMPLE_STRIDES=[1, 2, 4],
+              NUM_UPSAMPLE_FILTERS=[16, 16, 16])
+C1_HEAD = dict(
+    CLASS_AGNOSTIC=False, USE_DIRECTION_CLASSIFIER=True, DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2,
+    ANCHOR_GENERATOR_CONFIG=[
+        dict(class_name="Car", anchor_sizes=[[3.9, 1.6, 1.56]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-1.78],
+             align_center=False, feature_map_stride=2, matched_threshold=0.6, unmatched_threshold=0.45),
+        dict(class_name="Pedestrian", anchor_sizes=[[0.8, 0.6, 1.73]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-0.6],
+             align_center=False, feature_map_stride=2, matched_threshold=0.5, unmatched_threshold=0.35),
+        dict(class_name="Cyclist", anchor_sizes=[[1.76, 0.6, 1.73]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-0.6],
+             align_center=False, feature_map_stride=2, matched_threshold=0.5, unmatched_threshold=0.35)],
+    TARGET_ASSIGNER_CONFIG=dict(NAME="AxisAlignedTargetAssigner", POS_FRACTION=-1.0, SAMPLE_SIZE=512,
+                                NORM_BY_NUM_EXAMPLES=False, MATCH_HEIGHT=False, BOX_CODER="ResidualCoder"),
+    LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=2.0, dir_weight=0.2, code_weights=[1.0] * 7)),
+)
+
+
+def test_c1_pointpillar_chain_matches_reference():
+    """BASELINE config 1 (CPU plumbing): PillarVFE -> PointPillarScatter -> BaseBEVBackbone ->
+    AnchorHeadSingle incl. anchors, target assignment, the three losses and backward."""
+    from toda_amd.pcdet.models.backbones_2d import BaseBEVBackbone
+    from toda_amd.pcdet.models.backbones_2d.map_to_bev import PointPillarScatter
+    from toda_amd.pcdet.models.backbones_3d.vfe import PillarVFE
+    from toda_amd.pcdet.models.dense_heads import AnchorHeadSingle
+
+    g = load("c1_pointpillar_chain")
+    grid = np.array([48, 48, 1])
+    vfe = PillarVFE(AttrDict(C1_VFE), 4, C1_VOXEL, g["pc_range"]).train()
+    scatter = PointPillarScatter(AttrDict(NUM_BEV_FEATURES=32), grid)
+    bev = BaseBEVBackbone(AttrDict(C1_BEV), 32).train()
+    head = AnchorHeadSingle(AttrDict(C1_HEAD), 48, 3, ["Car", "Pedestrian", "Cyclist"], grid, g["pc_range"],
+                            predict_boxes_when_training=False).train()
+    load_weights(vfe, g, "vfe.")
+    load_weights(bev, g, "bev.")
+    load_weights(head, g, "head.")
+    np.testing.assert_allclose(torch.cat(head.anchors, dim=-3).numpy(), g["anchors"], rtol=0, atol=1e-6)
+    voxels = torch.from_numpy(g["voxels"]).requires_grad_(True)
+    d = {"voxels": voxels, "voxel_num_points": torch.from_numpy(g["num"]), "voxel_coords": torch.from_numpy(g["coords"]),
+         "gt_boxes": torch.from_numpy(g["gt"].copy()), "batch_size": 2}
+    d = vfe(d)
+    np.testing.assert_allclose(d["pillar_features"].detach().numpy(), g["pillar_features"], rtol=1e-5, atol=1e-6)
+    d = scatter(d)
+    np.testing.assert_allclose(d["spatial_features"].detach().sum(dim=(2, 3)).numpy(), g["spatial_features_sum"], rtol=1e-4,
+                               atol=1e-4)
+    d = head(bev(d))
+    fr = head.forward_ret_dict
+    np.testing.assert_allclose(fr["cls_preds"].detach().numpy(), g["cls_preds"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fr["box_preds"].detach().numpy(), g["box_preds"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(fr["dir_cls_preds"].detach().numpy(), g["dir_preds"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(fr["box_cls_labels"].numpy(), g["box_cls_labels"])
+    np.testing.assert_allclose(fr["box_reg_targets"].numpy(), g["box_reg_targets"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fr["reg_weights"].numpy(), g["reg_weights"], rtol=0, atol=0)
+    loss, tb = head.get_loss()
+    for mine, ref in ((loss, "loss"), (tb["rpn_loss_cls"], "loss_cls"), (tb["rpn_loss_loc"], "loss_loc"),
+                      (tb["rpn_loss_dir"], "loss_dir")):
+        assert abs(float(mine) - float(g[ref])) < 1e-4 * max(1.0, abs(float(g[ref]))), ref
+    loss.backward()
+    np.testing.assert_allclose(voxels.grad.numpy(), g["gvoxels"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(head.conv_cls.weight.grad.numpy(), g["g_conv_cls"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(vfe.pfn_layers[0].linear.weight.grad.numpy(), g["g_pfn"], rtol=1e-3, atol=1e-5)

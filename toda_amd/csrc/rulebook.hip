@@ -138,12 +138,70 @@ gi_decode_kernel(const uint2* __restrict__ cells, long long n_cells, GridDims g,
     }
 }
 
-// SubM: one thread per output site, loop over the K offsets (k-major table => coalesced stores).
-// Per-offset pair counts: wave ballot -> one atomic per wave per offset.
+// per-block per-offset pair counters: wave ballots -> LDS -> one global atomic per block and offset
+__device__ __forceinline__ void count_pairs(bool valid, int k, int* s_cnt) {
+    const unsigned long long vote = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && vote) atomicAdd(&s_cnt[k], __popcll(vote));
+}
+
+// SubM rulebook, one thread per output site.  The K lookups of a site are independent, so they
+// are issued as K back-to-back 8-byte cell loads (then K rowof loads) before anything is consumed:
+// one round trip to L2/MALL per phase instead of one per offset.  k-major table => the stores of
+// a wave are 256 contiguous bytes per offset.
+template <int KZ, int KY, int KX>
 __global__ void __launch_bounds__(RB_BLOCK)
-rb_subm_kernel(const int4* __restrict__ idx, int n, GridDims g, int kz_n, int ky_n, int kx_n, int dz, int dy, int dx,
+rb_subm_kernel(const int4* __restrict__ idx, int n, GridDims g, int dz, int dy, int dx,
                const uint2* __restrict__ cells, const int* __restrict__ rowof, int* __restrict__ nbr,
                int* __restrict__ pair_cnt) {
+    constexpr int K = KZ * KY * KX;
+    __shared__ int s_cnt[K];
+    if (threadIdx.x < K) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int o = blockIdx.x * RB_BLOCK + threadIdx.x;
+    const bool live = o < n;
+    int4 c = make_int4(0, 0, 0, 0);
+    if (live) c = idx[o];
+    uint2 cell[K];
+    unsigned bit[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int kz = k / (KY * KX), ky = (k / KX) % KY, kx = k % KX;
+        const int z = c.y + (kz - KZ / 2) * dz, y = c.z + (ky - KY / 2) * dy, x = c.w + (kx - KX / 2) * dx;
+        const bool ok = live && z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W;
+        cell[k] = make_uint2(0u, 0u);
+        bit[k] = 0u;
+        if (ok) {
+            const long long lin = lin_index(c.x, z, y, x, g);
+            cell[k] = cells[lin >> 5];
+            bit[k] = 1u << (lin & 31);
+        }
+    }
+    int r[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        r[k] = (cell[k].x & bit[k]) ? (int)cell[k].y + __popc(cell[k].x & (bit[k] - 1)) : -1;
+    if (rowof) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (r[k] >= 0) r[k] = rowof[r[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (live) nbr[(size_t)k * n + o] = r[k];
+        count_pairs(r[k] >= 0, k, s_cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x < K && s_cnt[threadIdx.x]) atomicAdd(&pair_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// generic kernel sizes (K <= 64): same structure, runtime loops
+__global__ void __launch_bounds__(RB_BLOCK)
+rb_subm_generic_kernel(const int4* __restrict__ idx, int n, GridDims g, int kz_n, int ky_n, int kx_n, int dz, int dy,
+                       int dx, const uint2* __restrict__ cells, const int* __restrict__ rowof, int* __restrict__ nbr,
+                       int* __restrict__ pair_cnt) {
+    __shared__ int s_cnt[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int o = blockIdx.x * RB_BLOCK + threadIdx.x;
     const bool live = o < n;
     int4 c = make_int4(0, 0, 0, 0);
@@ -162,14 +220,63 @@ rb_subm_kernel(const int4* __restrict__ idx, int n, GridDims g, int kz_n, int ky
                     }
                     nbr[(size_t)k * n + o] = r;
                 }
-                const unsigned long long vote = __ballot(r >= 0);
-                if ((threadIdx.x & 63) == 0 && vote) atomicAdd(&pair_cnt[k], __popcll(vote));
+                count_pairs(r >= 0, k, s_cnt);
             }
+    __syncthreads();
+    if (threadIdx.x < k && s_cnt[threadIdx.x]) atomicAdd(&pair_cnt[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
+// strided conv rulebook, one thread per input site; same issue-all-loads-first structure.
+template <int KZ, int KY, int KX>
 __global__ void __launch_bounds__(RB_BLOCK)
 rb_conv_kernel(const int4* __restrict__ idx, int n_in, ConvGeom cg, const uint2* __restrict__ cells, int n_out,
                int* __restrict__ o2i, int* __restrict__ i2o, int* __restrict__ pair_cnt) {
+    constexpr int K = KZ * KY * KX;
+    __shared__ int s_cnt[K];
+    if (threadIdx.x < K) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
+    const bool live = i < n_in;
+    int4 c = make_int4(0, 0, 0, 0);
+    if (live) c = idx[i];
+    int zo[KZ], yo[KY], xo[KX];
+#pragma unroll
+    for (int a = 0; a < KZ; ++a) zo[a] = out_coord(c.y, a, cg.st[0], cg.pd[0], cg.out.D);
+#pragma unroll
+    for (int a = 0; a < KY; ++a) yo[a] = out_coord(c.z, a, cg.st[1], cg.pd[1], cg.out.H);
+#pragma unroll
+    for (int a = 0; a < KX; ++a) xo[a] = out_coord(c.w, a, cg.st[2], cg.pd[2], cg.out.W);
+    uint2 cell[K];
+    unsigned bit[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int kz = k / (KY * KX), ky = (k / KX) % KY, kx = k % KX;
+        cell[k] = make_uint2(0u, 0u);
+        bit[k] = 0u;
+        if (live && zo[kz] >= 0 && yo[ky] >= 0 && xo[kx] >= 0) {
+            const long long lin = lin_index(c.x, zo[kz], yo[ky], xo[kx], cg.out);
+            cell[k] = cells[lin >> 5];
+            bit[k] = 1u << (lin & 31);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        int o = (cell[k].x & bit[k]) ? (int)cell[k].y + __popc(cell[k].x & (bit[k] - 1)) : -1;
+        if (o >= n_out) o = -1;
+        if (o >= 0) o2i[(size_t)k * n_out + o] = i;
+        if (live) i2o[(size_t)k * n_in + i] = o;
+        count_pairs(o >= 0, k, s_cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x < K && s_cnt[threadIdx.x]) atomicAdd(&pair_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(RB_BLOCK)
+rb_conv_generic_kernel(const int4* __restrict__ idx, int n_in, ConvGeom cg, const uint2* __restrict__ cells, int n_out,
+                       int* __restrict__ o2i, int* __restrict__ i2o, int* __restrict__ pair_cnt) {
+    __shared__ int s_cnt[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
     const bool live = i < n_in;
     int4 c = make_int4(0, 0, 0, 0);
@@ -190,11 +297,12 @@ rb_conv_kernel(const int4* __restrict__ idx, int n_in, ConvGeom cg, const uint2*
                     }
                     i2o[(size_t)k * n_in + i] = o;
                 }
-                const unsigned long long vote = __ballot(o >= 0);
-                if ((threadIdx.x & 63) == 0 && vote) atomicAdd(&pair_cnt[k], __popcll(vote));
+                count_pairs(o >= 0, k, s_cnt);
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < k && s_cnt[threadIdx.x]) atomicAdd(&pair_cnt[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 static int check_geom(const char* who, int batch, const int32_t* shape) {
@@ -292,9 +400,14 @@ extern "C" int toda_rulebook_subm(const int32_t* idx, int n, int batch, const in
     const GiLayout l = gi_layout(batch, shape_host);
     const uint2* cells = (const uint2*)((const char*)gi + l.o_cells);
     const GridDims g{batch, shape_host[0], shape_host[1], shape_host[2]};
-    hipLaunchKernelGGL(rb_subm_kernel, dim3(cdiv(n, RB_BLOCK)), dim3(RB_BLOCK), 0, s, (const int4*)idx, n, g,
-                       ksize_host[0], ksize_host[1], ksize_host[2], dilation_host[0], dilation_host[1],
-                       dilation_host[2], cells, rowof, nbr, pair_cnt);
+    const dim3 grid(cdiv(n, RB_BLOCK)), block(RB_BLOCK);
+    if (ksize_host[0] == 3 && ksize_host[1] == 3 && ksize_host[2] == 3)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_subm_kernel<3, 3, 3>), grid, block, 0, s, (const int4*)idx, n, g,
+                           dilation_host[0], dilation_host[1], dilation_host[2], cells, rowof, nbr, pair_cnt);
+    else
+        hipLaunchKernelGGL(rb_subm_generic_kernel, grid, block, 0, s, (const int4*)idx, n, g, ksize_host[0],
+                           ksize_host[1], ksize_host[2], dilation_host[0], dilation_host[1], dilation_host[2], cells,
+                           rowof, nbr, pair_cnt);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }
@@ -315,8 +428,16 @@ extern "C" int toda_rulebook_conv(const int32_t* idx_in, int n_in, int batch, co
     if (n_in == 0) return TODA_OK;
     const GiLayout l = gi_layout(batch, shape_out_host);
     const uint2* cells = (const uint2*)((const char*)gi_out + l.o_cells);
-    hipLaunchKernelGGL(rb_conv_kernel, dim3(cdiv(n_in, RB_BLOCK)), dim3(RB_BLOCK), 0, s, (const int4*)idx_in, n_in, cg,
-                       cells, n_out, nbr_o2i, nbr_i2o, pair_cnt);
+    const dim3 grid(cdiv(n_in, RB_BLOCK)), block(RB_BLOCK);
+    if (ksize_host[0] == 3 && ksize_host[1] == 3 && ksize_host[2] == 3)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_kernel<3, 3, 3>), grid, block, 0, s, (const int4*)idx_in, n_in, cg,
+                           cells, n_out, nbr_o2i, nbr_i2o, pair_cnt);
+    else if (ksize_host[0] == 3 && ksize_host[1] == 1 && ksize_host[2] == 1)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_kernel<3, 1, 1>), grid, block, 0, s, (const int4*)idx_in, n_in, cg,
+                           cells, n_out, nbr_o2i, nbr_i2o, pair_cnt);
+    else
+        hipLaunchKernelGGL(rb_conv_generic_kernel, grid, block, 0, s, (const int4*)idx_in, n_in, cg, cells, n_out,
+                           nbr_o2i, nbr_i2o, pair_cnt);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

@@ -32,6 +32,11 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """Pin the oracle's OpenMP thread count; returns the count in effect."""
+    return int(lib().oracle_set_threads(int(n)))
+
+
 def _p(a, t=C.c_void_p):
     return a.ctypes.data_as(t) if a is not None else None
 

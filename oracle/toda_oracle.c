@@ -35,6 +35,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------ hash */
 typedef struct {
@@ -288,24 +291,25 @@ int oracle_rulebook_conv(const int32_t* idx_in, int n_in, int batch, const int32
 }
 
 /* ------------------------------------------- per-offset gather/GEMM/scatter */
-/* w is [Cout][K][Cin] (spconv-2 layout).  out[o] = bias + sum_k W_k in[nbr[k][o]] */
+/* w is [Cout][K][Cin] (spconv-2 layout).  out[o] = bias + sum_k W_k in[nbr[k][o]].
+ * Offsets are visited in ascending k for every output row (same summation order as the
+ * classic per-offset gather -> GEMM -> scatter-add loop), rows are spread over OpenMP threads. */
 void oracle_spconv_fwd(const float* in, int cin, const float* w, const int32_t* nbr, int n_out,
                        int K, int cout, const float* bias, float* out) {
-#pragma omp parallel for schedule(static)
-    for (int o = 0; o < n_out; ++o)
-        for (int co = 0; co < cout; ++co) out[(size_t)o * cout + co] = bias ? bias[co] : 0.0f;
-    float* wk = (float*)malloc((size_t)cin * cout * sizeof(float)); /* [Cin][Cout] */
-    for (int k = 0; k < K; ++k) {
+    float* wt = (float*)malloc((size_t)K * cin * cout * sizeof(float)); /* [K][Cin][Cout] */
+    for (int k = 0; k < K; ++k)
         for (int ci = 0; ci < cin; ++ci)
             for (int co = 0; co < cout; ++co)
-                wk[(size_t)ci * cout + co] = w[((size_t)co * K + k) * cin + ci];
-        const int32_t* nk = nbr + (size_t)k * n_out;
+                wt[((size_t)k * cin + ci) * cout + co] = w[((size_t)co * K + k) * cin + ci];
 #pragma omp parallel for schedule(static)
-        for (int o = 0; o < n_out; ++o) {
-            int i = nk[o];
+    for (int o = 0; o < n_out; ++o) {
+        float* y = out + (size_t)o * cout;
+        for (int co = 0; co < cout; ++co) y[co] = bias ? bias[co] : 0.0f;
+        for (int k = 0; k < K; ++k) {
+            int i = nbr[(size_t)k * n_out + o];
             if (i < 0) continue;
             const float* a = in + (size_t)i * cin;
-            float* y = out + (size_t)o * cout;
+            const float* wk = wt + (size_t)k * cin * cout;
             for (int ci = 0; ci < cin; ++ci) {
                 float av = a[ci];
                 const float* wr = wk + (size_t)ci * cout;
@@ -313,55 +317,83 @@ void oracle_spconv_fwd(const float* in, int cin, const float* w, const int32_t* 
             }
         }
     }
-    free(wk);
+    free(wt);
 }
 
 /* din[i] = sum over pairs (i,o,k) of W_k^T dout[o].  nbr_i2o is [K][n_in]
  * (for SubM pass the forward table and flip_k = 1). */
 void oracle_spconv_dgrad(const float* dout, int cout, const float* w, const int32_t* nbr_i2o,
                          int n_in, int K, int cin, int flip_k, float* din) {
-    memset(din, 0, (size_t)n_in * cin * sizeof(float));
-    for (int k = 0; k < K; ++k) {
-        int kw = flip_k ? K - 1 - k : k;
-        const int32_t* nk = nbr_i2o + (size_t)k * n_in;
+    float* wt = (float*)malloc((size_t)K * cin * cout * sizeof(float)); /* [K][Cout][Cin] */
+    for (int k = 0; k < K; ++k)
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                wt[((size_t)k * cout + co) * cin + ci] = w[((size_t)co * K + k) * cin + ci];
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < n_in; ++i) {
-            int o = nk[i];
+    for (int i = 0; i < n_in; ++i) {
+        float* d = din + (size_t)i * cin;
+        for (int ci = 0; ci < cin; ++ci) d[ci] = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            int o = nbr_i2o[(size_t)k * n_in + i];
             if (o < 0) continue;
             const float* g = dout + (size_t)o * cout;
-            float* d = din + (size_t)i * cin;
+            const float* wk = wt + (size_t)(flip_k ? K - 1 - k : k) * cout * cin;
             for (int co = 0; co < cout; ++co) {
                 float gv = g[co];
-                const float* wr = w + ((size_t)co * K + kw) * cin;
+                const float* wr = wk + (size_t)co * cin;
                 for (int ci = 0; ci < cin; ++ci) d[ci] += gv * wr[ci];
             }
         }
     }
+    free(wt);
 }
 
-/* dw[co][k][ci] = sum_o in[nbr[k][o]][ci] * dout[o][co]; fp64 accumulation */
+/* dw[co][k][ci] = sum_o in[nbr[k][o]][ci] * dout[o][co]: fp32 partial sums over blocks of 256
+ * rows, folded into fp64 accumulators (one set per thread, combined at the end). */
 void oracle_spconv_wgrad(const float* in, const float* dout, const int32_t* nbr, int n_out, int K,
                          int cin, int cout, float* dw) {
-#pragma omp parallel for schedule(dynamic)
-    for (int k = 0; k < K; ++k) {
-        double* acc = (double*)calloc((size_t)cin * cout, sizeof(double));
-        const int32_t* nk = nbr + (size_t)k * n_out;
-        for (int o = 0; o < n_out; ++o) {
-            int i = nk[o];
-            if (i < 0) continue;
-            const float* a = in + (size_t)i * cin;
-            const float* g = dout + (size_t)o * cout;
-            for (int co = 0; co < cout; ++co) {
-                double gv = g[co];
-                double* ar = acc + (size_t)co * cin;
-                for (int ci = 0; ci < cin; ++ci) ar[ci] += gv * a[ci];
+    const size_t E = (size_t)K * cout * cin;
+    double* total = (double*)calloc(E, sizeof(double));
+#pragma omp parallel
+    {
+        double* acc = (double*)calloc(E, sizeof(double));
+        float* part = (float*)malloc((size_t)cout * cin * sizeof(float));
+#pragma omp for schedule(static)
+        for (int blk = 0; blk < (n_out + 255) / 256; ++blk) {
+            int o0 = blk * 256, o1 = o0 + 256 < n_out ? o0 + 256 : n_out;
+            for (int k = 0; k < K; ++k) {
+                int used = 0;
+                for (int o = o0; o < o1; ++o) {
+                    int i = nbr[(size_t)k * n_out + o];
+                    if (i < 0) continue;
+                    if (!used) {
+                        memset(part, 0, (size_t)cout * cin * sizeof(float));
+                        used = 1;
+                    }
+                    const float* a = in + (size_t)i * cin;
+                    const float* g = dout + (size_t)o * cout;
+                    for (int co = 0; co < cout; ++co) {
+                        float gv = g[co];
+                        float* pr = part + (size_t)co * cin;
+                        for (int ci = 0; ci < cin; ++ci) pr[ci] += gv * a[ci];
+                    }
+                }
+                if (used) {
+                    double* ak = acc + (size_t)k * cout * cin;
+                    for (size_t e = 0; e < (size_t)cout * cin; ++e) ak[e] += part[e];
+                }
             }
         }
+#pragma omp critical
+        for (size_t e = 0; e < E; ++e) total[e] += acc[e];
+        free(acc);
+        free(part);
+    }
+    for (int k = 0; k < K; ++k)
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
-                dw[((size_t)co * K + k) * cin + ci] = (float)acc[(size_t)co * cin + ci];
-        free(acc);
-    }
+                dw[((size_t)co * K + k) * cin + ci] = (float)total[((size_t)k * cout + co) * cin + ci];
+    free(total);
 }
 
 /* SURVEY.md B.6 */
@@ -504,3 +536,14 @@ void oracle_center_assign(const float* gt, int batch, int n_gt, int code, int nu
 }
 
 int oracle_abi_version(void) { return 1; }
+
+/* number of OpenMP threads the oracle uses (the cpu_baseline leg states it as `cores`) */
+int oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}

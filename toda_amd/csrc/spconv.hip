@@ -17,6 +17,8 @@
 //     weights are laid out with the same permutation.
 //   * channel-interleaved N tiles: column c of tile n is produced channel NT*c + n, so a lane's
 //     NT accumulators for one row are NT consecutive channels -> one 16/32-byte store.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace toda {
@@ -58,7 +60,37 @@ pack_weight_kernel(const float* __restrict__ w, int cout, int K, int cin, int tr
     wp[e] = v;
 }
 
-template <int Q, int NT, int RT>
+// Gather one wave's A fragments for one offset: lane (r, g) of row tile rt reads the 4 channels
+// 16q+4g..+3 of input row src[rt] (zeros when there is no neighbour).
+template <int Q, int RT>
+__device__ __forceinline__ void gather_rows(const float* __restrict__ in, int cg, bool vec, int g, const int (&src)[RT],
+                                            f32x4 (&a)[RT][Q]) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int col = 16 * q + 4 * g;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (src[rt] >= 0) {
+                const float* p = in + (size_t)src[rt] * cg + col;
+                if (vec) {
+                    if (col < cg) v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (col + 0 < cg) v[0] = p[0];
+                    if (col + 1 < cg) v[1] = p[1];
+                    if (col + 2 < cg) v[2] = p[2];
+                    if (col + 3 < cg) v[3] = p[3];
+                }
+            }
+            a[rt][q] = v;
+        }
+    }
+}
+
+// PF = software pipeline depth: with PF the neighbour ids of offset k+2 and the gathered rows of
+// offset k+1 are requested before the MFMAs of offset k issue, so a wave's HBM/L2 round trips run
+// under its own matrix work instead of relying on other waves to cover them.
+template <int Q, int NT, int RT, bool PF>
 __global__ void __launch_bounds__(SC_BLOCK)
 gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
                    int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out) {
@@ -78,55 +110,75 @@ gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict
     }
     const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
     const bool vec = (cg & 3) == 0;
+    int rows[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) rows[rt] = row0 + rt * 16 + r;
 
-    for (int k = 0; k < K; ++k) {
-        int src[RT];
-        bool hit[RT];
-        bool any = false;
+    auto load_ids = [&](int k, int (&dst)[RT]) {
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int row = row0 + rt * 16 + r;
-            src[rt] = row < n_out ? nbr[(size_t)k * n_out + row] : -1;
-            hit[rt] = __any(src[rt] >= 0);
-            any = any || hit[rt];
-        }
-        if (!any) continue;  // wave-uniform skip of an empty offset
-
-        f32x4 a[RT][Q];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int col = 16 * q + 4 * g;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (src[rt] >= 0) {
-                    const float* p = in + (size_t)src[rt] * cg + col;
-                    if (vec) {
-                        if (col < cg) v = *reinterpret_cast<const f32x4*>(p);
-                    } else {
-                        if (col + 0 < cg) v[0] = p[0];
-                        if (col + 1 < cg) v[1] = p[1];
-                        if (col + 2 < cg) v[2] = p[2];
-                        if (col + 3 < cg) v[3] = p[3];
-                    }
-                }
-                a[rt][q] = v;
-            }
-        }
+        for (int rt = 0; rt < RT; ++rt) dst[rt] = (k < K && rows[rt] < n_out) ? nbr[(size_t)k * n_out + rows[rt]] : -1;
+    };
+    auto mma = [&](int k, const f32x4 (&a)[RT][Q], const bool (&hit)[RT]) {
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
+            f32x4 b[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const f32x4 b = wp4[(((size_t)k * Q + q) * NT + n) * 64 + lane];
+            for (int n = 0; n < NT; ++n) b[n] = wp4[(((size_t)k * Q + q) * NT + n) * 64 + lane];
+            // j outermost: consecutive MFMAs hit different accumulators (dependent latency 40 > issue 32)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    if (hit[rt]) {
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[j], acc[rt][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (hit[rt])
+                            acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[n][j], acc[rt][n], 0, 0, 0);
                     }
                 }
             }
+        }
+    };
+
+    if constexpr (PF) {
+        int s0[RT], s1[RT], s2[RT];
+        f32x4 a0[RT][Q], a1[RT][Q];
+        load_ids(0, s0);
+        load_ids(1, s1);
+        gather_rows<Q, RT>(in, cg, vec, g, s0, a0);
+        for (int k = 0; k < K; ++k) {
+            load_ids(k + 2, s2);
+            gather_rows<Q, RT>(in, cg, vec, g, s1, a1);  // rows of offset k+1, in flight during the MFMAs below
+            bool hit[RT];
+            bool any = false;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                hit[rt] = __any(s0[rt] >= 0);
+                any = any || hit[rt];
+            }
+            if (any) mma(k, a0, hit);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                s0[rt] = s1[rt];
+                s1[rt] = s2[rt];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) a0[rt][q] = a1[rt][q];
+            }
+        }
+    } else {
+        for (int k = 0; k < K; ++k) {
+            int src[RT];
+            load_ids(k, src);
+            bool hit[RT];
+            bool any = false;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                hit[rt] = __any(src[rt] >= 0);
+                any = any || hit[rt];
+            }
+            if (!any) continue;  // wave-uniform skip of an empty offset
+            f32x4 a[RT][Q];
+            gather_rows<Q, RT>(in, cg, vec, g, src, a);
+            mma(k, a, hit);
         }
     }
 
@@ -319,16 +371,36 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int c_gather, const floa
     if (n_out == 0) return TODA_OK;
     const int Q = tiles_pow2(c_gather), NT = tiles_pow2(c_produce);
     hipStream_t s = (hipStream_t)stream;
-#define GG(QQ, NN, RR)                                                                                              \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR>),                                             \
+    // tuning knobs for experiments: TODA_GG_RT in {1,2,4} (0 = built-in choice), TODA_GG_PF in {0,1}
+    static const int env_rt = getenv("TODA_GG_RT") ? atoi(getenv("TODA_GG_RT")) : 0;
+    static const int env_pf = getenv("TODA_GG_PF") ? atoi(getenv("TODA_GG_PF")) : 0;
+    int rt_sel = env_rt ? env_rt : (NT >= 8 ? 1 : 2);
+    if (NT >= 8 && rt_sel > 2) rt_sel = 2;
+    if (Q >= 8 && rt_sel > 2) rt_sel = 2;
+#define GG(QQ, NN, RR, PP)                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP>),                                           \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, c_gather, wp, nbr, \
                        n_out, k_vol, c_produce, bias, out)
+#define GG_PF(QQ, NN, RR)        \
+    if (env_pf) {                \
+        GG(QQ, NN, RR, true);    \
+    } else {                     \
+        GG(QQ, NN, RR, false);   \
+    }
+#define GG_RT(QQ, NN)                                  \
+    if (rt_sel == 1) {                                 \
+        GG_PF(QQ, NN, 1)                               \
+    } else if (rt_sel == 2 || QQ >= 8 || NN >= 8) {    \
+        GG_PF(QQ, NN, 2)                               \
+    } else {                                           \
+        GG_PF(QQ, NN, 4)                               \
+    }
 #define GG_ROW(QQ)                 \
     switch (NT) {                  \
-        case 1: GG(QQ, 1, 2); break; \
-        case 2: GG(QQ, 2, 2); break; \
-        case 4: GG(QQ, 4, 2); break; \
-        default: GG(QQ, 8, 1); break; \
+        case 1: GG_RT(QQ, 1); break; \
+        case 2: GG_RT(QQ, 2); break; \
+        case 4: GG_RT(QQ, 4); break; \
+        default: GG_RT(QQ, 8); break; \
     }
     switch (Q) {
         case 1: GG_ROW(1); break;
@@ -337,6 +409,8 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int c_gather, const floa
         default: GG_ROW(8); break;
     }
 #undef GG_ROW
+#undef GG_RT
+#undef GG_PF
 #undef GG
     TODA_LAUNCH_CHECK();
     return TODA_OK;

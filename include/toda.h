@@ -164,6 +164,19 @@ int toda_rows_affine_act(const float* x, const float* scale, const float* shift,
                          const float* residual /*nullable*/, int n, int c, int relu,
                          float* y, void* stream);
 
+/* Batch statistics -> per-channel mean / invstd / scale / shift, plus nn.BatchNorm1d's
+ * running-statistic update (momentum, unbiased running_var).  training == 0: running stats. */
+int toda_bn_finalize(const double* sums /*[2c] from toda_rows_moments*/, int n, int c,
+                     const float* gamma, const float* beta, float* running_mean /*nullable*/,
+                     float* running_var /*nullable*/, float momentum, float eps, int training,
+                     float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* Backward of the same pair: dz = dy * (y > 0) (relu != 0) or dy; sums[0:c] = sum dz,
+ * sums[c:2c] = sum dz * xhat (zeroed and filled by the call; they are d(beta) and d(gamma));
+ * dx = gamma * invstd * (dz - sums[0:c]/n - xhat * sums[c:2c]/n), xhat = (x - mean) * invstd. */
+int toda_rows_bn_bwd(const float* dy, const float* y /*unused when relu == 0*/, const float* x,
+                     const float* mean, const float* invstd, const float* gamma, int n, int c,
+                     int relu, double* sums /*[2c]*/, float* dx, void* stream);
+
 /* ------------------------------------------------------------------------
  * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,
  * pcdet/models/model_utils/centernet_utils.py:9-69): gaussian heat-maps,

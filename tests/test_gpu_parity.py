@@ -280,3 +280,75 @@ def test_center_assign_vs_oracle():
     assert np.array_equal(mk1.cpu().numpy(), mk0)
     np.testing.assert_allclose(hm1.cpu().numpy(), hm0, rtol=0, atol=1e-6)
     np.testing.assert_allclose(rb1.cpu().numpy(), rb0, rtol=1e-6, atol=1e-6)
+
+
+def test_index_plan_equals_lazy_rulebooks():
+    """One-sync index plan of a whole backbone == the rulebooks built lazily layer by layer."""
+    from toda_amd import ops
+
+    shape, batch = [41, 200, 176], 2
+    idx, _ = H.clustered_sparse(batch, shape, 20000, 1, seed=21)
+    steps = [
+        {"kind": "subm", "key": "subm1", "ksize": [3, 3, 3], "dilation": [1, 1, 1]},
+        {"kind": "conv", "key": "spconv2", "ksize": [3, 3, 3], "stride": [2, 2, 2], "padding": [1, 1, 1]},
+        {"kind": "subm", "key": "subm2", "ksize": [3, 3, 3], "dilation": [1, 1, 1]},
+        {"kind": "conv", "key": "spconv3", "ksize": [3, 3, 3], "stride": [2, 2, 2], "padding": [1, 1, 1]},
+        {"kind": "subm", "key": "subm3", "ksize": [3, 3, 3], "dilation": [1, 1, 1]},
+        {"kind": "conv", "key": "spconv4", "ksize": [3, 3, 3], "stride": [2, 2, 2], "padding": [0, 1, 1]},
+        {"kind": "subm", "key": "subm4", "ksize": [3, 3, 3], "dilation": [1, 1, 1]},
+        {"kind": "conv", "key": "spconv_down2", "ksize": [3, 1, 1], "stride": [2, 1, 1], "padding": [0, 0, 0]},
+    ]
+    plan = ops.build_index_plan(dev(idx), batch, shape, steps)
+    cur_idx, cur_shape = idx, shape
+    for st in steps:
+        e = plan[st["key"]]
+        if st["kind"] == "subm":
+            nbr0, cnt0 = O.rulebook_subm(cur_idx, batch, cur_shape)
+            assert np.array_equal(e["rb"].nbr_fwd.cpu().numpy(), nbr0)
+            assert np.array_equal(e["rb"].pair_cnt.cpu().numpy(), cnt0)
+        else:
+            io0, sho0, o2i0, i2o0, cnt0 = O.rulebook_conv(cur_idx, batch, cur_shape, st["ksize"], st["stride"], st["padding"])
+            assert e["out_shape"] == sho0
+            assert np.array_equal(e["out_indices"].cpu().numpy(), io0)
+            assert np.array_equal(e["rb"].nbr_fwd.cpu().numpy(), o2i0)
+            assert np.array_equal(e["rb"].nbr_bwd.cpu().numpy(), i2o0)
+            assert np.array_equal(e["rb"].pair_cnt.cpu().numpy(), cnt0)
+            cur_idx, cur_shape = io0, sho0
+
+
+@pytest.mark.parametrize("c,relu,train", [(16, True, True), (64, True, True), (128, False, True), (32, True, False)])
+def test_fused_bn_rows_matches_torch_batchnorm1d(c, relu, train):
+    """toda_rows_moments + toda_bn_finalize + toda_rows_affine_act / toda_rows_bn_bwd against
+    nn.BatchNorm1d(eps=1e-3, momentum=0.01) (+ReLU) in fp64 on the CPU: outputs, input / affine
+    gradients and the running statistics."""
+    from toda_amd import ops
+
+    rng = np.random.default_rng(c)
+    x = (rng.standard_normal((20011, c)) * 1.7 + 0.3).astype(np.float32)
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).double()
+    with torch.no_grad():
+        ref.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, c)))
+        ref.bias.copy_(torch.from_numpy(rng.uniform(-0.5, 0.5, c)))
+        ref.running_mean.copy_(torch.from_numpy(rng.uniform(-0.2, 0.2, c)))
+        ref.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 2.0, c)))
+    mine = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+    mine.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+    mine = mine.cuda()
+    ref.train(train)
+    mine.train(train)
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    yr.backward(torch.from_numpy(g).double())
+    xm = dev(x).requires_grad_(True)
+    assert ops.bn_rows_supported(xm, mine)
+    ym = ops.bn_rows(xm, mine, relu)
+    ym.backward(dev(g))
+    np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xm.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(mine.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(mine.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(mine.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mine.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)

@@ -131,6 +131,100 @@ rows_affine_act_kernel(const f32x4* __restrict__ x, const float* __restrict__ sc
     y[t] = v;
 }
 
+// BatchNorm1d(+ReLU) backward over sparse rows, pass 1: per-channel sums of dz and dz*xhat where
+// dz = dy * (y > 0) when the block ends in a ReLU, xhat = (x - mean) * invstd.  Same thread layout
+// and fp32-in-thread / fp64-across-threads accumulation as rows_moments_kernel.
+__global__ void __launch_bounds__(DN_BLOCK)
+rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+                          const float* __restrict__ mean, const float* __restrict__ invstd, int n, int c, int relu,
+                          double* __restrict__ sums) {
+    __shared__ double sh[2 * DN_BLOCK];
+    const int rows_par = DN_BLOCK / c;
+    const int ch = threadIdx.x % c, rsub = threadIdx.x / c;
+    const int row_begin = blockIdx.x * MOM_ROWS;
+    const int row_end = min(n, row_begin + MOM_ROWS);
+    const float mu = mean[ch], is = invstd[ch];
+    float s = 0.f, s2 = 0.f;
+    for (int r = row_begin + rsub; r < row_end; r += rows_par) {
+        const size_t e = (size_t)r * c + ch;
+        float dz = dy[e];
+        if (relu && !(y[e] > 0.f)) dz = 0.f;
+        s += dz;
+        s2 += dz * ((x[e] - mu) * is);
+    }
+    sh[threadIdx.x] = s;
+    sh[DN_BLOCK + threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < c) {
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < rows_par; ++j) {
+            a += sh[j * c + threadIdx.x];
+            b += sh[DN_BLOCK + j * c + threadIdx.x];
+        }
+        atomicAdd(&sums[threadIdx.x], a);
+        atomicAdd(&sums[c + threadIdx.x], b);
+    }
+}
+
+// pass 2: dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+__global__ void __launch_bounds__(DN_BLOCK)
+rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ y, const f32x4* __restrict__ x,
+                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                         const float* __restrict__ gamma, const double* __restrict__ sums, long long n4, int c, int n,
+                         int relu, f32x4* __restrict__ dx) {
+    const long long t = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
+    if (t >= n4) return;
+    const int ch = (int)((t * 4) % c);
+    const f32x4 g = dy[t], xv = x[t];
+    f32x4 yv = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (relu) yv = y[t];
+    f32x4 out;
+    const float inv_n = 1.0f / (float)n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float is = invstd[ch + j];
+        const float xh = (xv[j] - mean[ch + j]) * is;
+        const float dz = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
+        const float m1 = (float)sums[ch + j] * inv_n, m2 = (float)sums[c + ch + j] * inv_n;
+        out[j] = gamma[ch + j] * is * (dz - m1 - xh * m2);
+    }
+    dx[t] = out;
+}
+
+// one block: batch statistics -> (mean, invstd, scale, shift) + running-stat update, exactly
+// nn.BatchNorm1d's training-mode bookkeeping (biased variance for normalisation, unbiased for
+// running_var, running = (1-m)*running + m*batch).  training == 0: use the running statistics.
+__global__ void __launch_bounds__(DN_BLOCK)
+bn_finalize_kernel(const double* __restrict__ sums, int n, int c, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                   float momentum, float eps, int training, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    const int ch = threadIdx.x;
+    if (ch >= c) return;
+    float mean, var;
+    if (training) {
+        const double m = sums[ch] / (double)n;
+        double v = sums[c + ch] / (double)n - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m;
+        var = (float)v;
+        if (running_mean) {
+            const double unbiased = n > 1 ? v * (double)n / (double)(n - 1) : v;
+            running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * mean;
+            running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)unbiased;
+        }
+    } else {
+        mean = running_mean[ch];
+        var = running_var[ch];
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[ch] : 1.0f, b = beta ? beta[ch] : 0.0f;
+    mean_out[ch] = mean;
+    invstd_out[ch] = invstd;
+    scale_out[ch] = g * invstd;
+    shift_out[ch] = b - mean * g * invstd;
+}
+
 static int scatter_common(bool fwd, float* feat, const int32_t* idx, int n, int c, int batch, DenseGeom g,
                           float* dense, hipStream_t s) {
     TODA_CHECK_ARG(n >= 0 && c >= 1 && batch >= 1, "sparse<->dense: bad sizes n=%d c=%d batch=%d", n, c, batch);
@@ -190,6 +284,32 @@ extern "C" int toda_rows_affine_act(const float* x, const float* scale, const fl
     const long long n4 = (long long)n * c / 4;
     hipLaunchKernelGGL(rows_affine_act_kernel, dim3(cdiv(n4, DN_BLOCK)), dim3(DN_BLOCK), 0, (hipStream_t)stream,
                        (const f32x4*)x, scale, shift, (const f32x4*)residual, n4, c, relu, (f32x4*)y);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_rows_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                const float* gamma, int n, int c, int relu, double* sums, float* dx, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TODA_CHECK_ARG(c >= 4 && c <= DN_BLOCK && DN_BLOCK % c == 0, "rows_bn_bwd: channels must divide 256 and be >= 4 (got %d)", c);
+    TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
+    if (n <= 0) return TODA_OK;
+    hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(cdiv(n, MOM_ROWS)), dim3(DN_BLOCK), 0, s, dy, y, x, mean, invstd, n, c,
+                       relu, sums);
+    const long long n4 = (long long)n * c / 4;
+    hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3(cdiv(n4, DN_BLOCK)), dim3(DN_BLOCK), 0, s, (const f32x4*)dy,
+                       (const f32x4*)y, (const f32x4*)x, mean, invstd, gamma, sums, n4, c, n, relu, (f32x4*)dx);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_bn_finalize(const double* sums, int n, int c, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, int training,
+                                float* mean, float* invstd, float* scale, float* shift, void* stream) {
+    TODA_CHECK_ARG(c >= 1 && c <= DN_BLOCK, "bn_finalize: channels must be <= 256 (got %d)", c);
+    TODA_CHECK_ARG(training || (running_mean && running_var), "bn_finalize: eval mode needs running statistics");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(DN_BLOCK), 0, (hipStream_t)stream, sums, n, c, gamma, beta,
+                       running_mean, running_var, momentum, eps, training, mean, invstd, scale, shift);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

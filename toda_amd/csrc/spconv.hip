@@ -211,16 +211,21 @@ gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict
 }
 
 // wgrad: dW[co][k][ci] = sum_o in[nbr[k][o]][ci] * dout[o][co].  Grid (row chunk, offset, channel
-// sub-block); the contraction runs over rows (4 per MFMA step, one per lane group).  The same
-// channel interleave as above turns the operand loads into MTB/NTB-wide vector loads.  Partial
-// sums go to a slab per chunk (plain stores) and a second kernel adds the slabs in fixed order:
-// deterministic, no float atomics.
+// sub-block).  The contraction runs over PAIRS, not rows: every wave reads 64 neighbour ids at a
+// time (one coalesced 256-byte load), compacts the valid (in,out) pairs into a small LDS queue
+// (ballot + prefix popcount) and feeds the MFMAs 16 pairs per round (4 per MFMA step, one per lane
+// group), so no matrix work is spent on rows without a neighbour and each round has 4 steps of
+// loads in flight.  The channel interleave of the forward kernel makes the operand loads
+// MTB/NTB-wide vector loads.  Partial sums go to a slab per chunk (plain stores) and a second
+// kernel adds the slabs in fixed order: deterministic, no float atomics.
 template <int MTB, int NTB>
 __global__ void __launch_bounds__(SC_BLOCK)
 wgrad_kernel(const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
              const int* __restrict__ nbr, int n_out, int K, int rows_per_chunk, int MT, int NT, int nsub_n,
              float* __restrict__ slab) {
+    constexpr int QCAP = 64 + 16;
     __shared__ float red[MTB * NTB * 4 * 64];
+    __shared__ int q_in[SC_BLOCK / 64][QCAP], q_out[SC_BLOCK / 64][QCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ii = lane & 15, g = lane >> 4;
     const int chunk = blockIdx.x, k = blockIdx.y;
@@ -228,6 +233,8 @@ wgrad_kernel(const float* __restrict__ in, int cin, const float* __restrict__ do
     const int row_begin = chunk * rows_per_chunk;
     const int row_end = min(n_out, row_begin + rows_per_chunk);
     const bool exact_a = cin == 16 * MT, exact_b = cout == 16 * NT;
+    int* qi = q_in[wv];
+    int* qo = q_out[wv];
 
     f32x4 acc[MTB][NTB];
 #pragma unroll
@@ -235,55 +242,100 @@ wgrad_kernel(const float* __restrict__ in, int cin, const float* __restrict__ do
 #pragma unroll
         for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int base = row_begin; base < row_end; base += 16) {
-        const int o = base + wv * 4 + g;
-        const int i = o < row_end ? nbr[(size_t)k * n_out + o] : -1;
-        if (!__any(i >= 0)) continue;
-        float a[MTB], b[NTB];
+    // one round: 4 MFMA steps over queue entries [d, d+16); entries >= limit contribute zeros
+    auto round16 = [&](int d, int limit) {
+        float a[4][MTB], b[4][NTB];
 #pragma unroll
-        for (int m = 0; m < MTB; ++m) a[m] = 0.f;
+        for (int t = 0; t < 4; ++t) {
+            const int p = d + 4 * t + g;
+            const bool ok = p < limit;
+            const int ip = ok ? qi[p] : 0, op = ok ? qo[p] : 0;
+            const float* pa = in + (size_t)ip * cin + MT * ii + m0;
+            const float* pb = dout + (size_t)op * cout + NT * ii + n0;
 #pragma unroll
-        for (int n = 0; n < NTB; ++n) b[n] = 0.f;
-        if (i >= 0) {
-            const float* pa = in + (size_t)i * cin + MT * ii + m0;
-            const float* pb = dout + (size_t)o * cout + NT * ii + n0;
-            if (exact_a) {
-                if constexpr (MTB == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(pa);
-                    a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
-                } else if constexpr (MTB == 2) {
-                    const float2 v = *reinterpret_cast<const float2*>(pa);
-                    a[0] = v.x; a[1] = v.y;
+            for (int m = 0; m < MTB; ++m) a[t][m] = 0.f;
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) b[t][n] = 0.f;
+            if (ok) {
+                if (exact_a) {
+                    if constexpr (MTB == 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(pa);
+                        a[t][0] = v[0]; a[t][1] = v[1]; a[t][2] = v[2]; a[t][3] = v[3];
+                    } else if constexpr (MTB == 2) {
+                        const float2 v = *reinterpret_cast<const float2*>(pa);
+                        a[t][0] = v.x; a[t][1] = v.y;
+                    } else {
+                        a[t][0] = pa[0];
+                    }
                 } else {
-                    a[0] = pa[0];
-                }
-            } else {
 #pragma unroll
-                for (int m = 0; m < MTB; ++m)
-                    if (MT * ii + m0 + m < cin) a[m] = pa[m];
-            }
-            if (exact_b) {
-                if constexpr (NTB == 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(pb);
-                    b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
-                } else if constexpr (NTB == 2) {
-                    const float2 v = *reinterpret_cast<const float2*>(pb);
-                    b[0] = v.x; b[1] = v.y;
+                    for (int m = 0; m < MTB; ++m)
+                        if (MT * ii + m0 + m < cin) a[t][m] = pa[m];
+                }
+                if (exact_b) {
+                    if constexpr (NTB == 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(pb);
+                        b[t][0] = v[0]; b[t][1] = v[1]; b[t][2] = v[2]; b[t][3] = v[3];
+                    } else if constexpr (NTB == 2) {
+                        const float2 v = *reinterpret_cast<const float2*>(pb);
+                        b[t][0] = v.x; b[t][1] = v.y;
+                    } else {
+                        b[t][0] = pb[0];
+                    }
                 } else {
-                    b[0] = pb[0];
-                }
-            } else {
 #pragma unroll
-                for (int n = 0; n < NTB; ++n)
-                    if (NT * ii + n0 + n < cout) b[n] = pb[n];
+                    for (int n = 0; n < NTB; ++n)
+                        if (NT * ii + n0 + n < cout) b[t][n] = pb[n];
+                }
             }
         }
 #pragma unroll
-        for (int m = 0; m < MTB; ++m)
+        for (int t = 0; t < 4; ++t) {
+            if (d + 4 * t < limit) {  // wave-uniform
 #pragma unroll
-            for (int n = 0; n < NTB; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][m], b[t][n], acc[m][n], 0, 0, 0);
+            }
+        }
+    };
+
+    int qn = 0;  // wave-uniform queue length (< 16 between batches)
+    for (int base = row_begin + wv * 64; base < row_end; base += SC_BLOCK) {
+        const int o = base + lane;
+        const int i = o < row_end ? nbr[(size_t)k * n_out + o] : -1;
+        const unsigned long long vote = __ballot(i >= 0);
+        if (vote == 0) continue;
+        if (i >= 0) {
+            const int pos = qn + __popcll(vote & ((1ull << lane) - 1));
+            qi[pos] = i;
+            qo[pos] = o;
+        }
+        qn += __popcll(vote);
+        __builtin_amdgcn_wave_barrier();
+        int done = 0;
+        while (qn - done >= 16) {
+            round16(done, qn);
+            done += 16;
+        }
+        const int left = qn - done;
+        if (done > 0 && left > 0) {  // move the tail (< 16 entries) to the front of the queue
+            int ti = 0, to = 0;
+            if (lane < left) {
+                ti = qi[done + lane];
+                to = qo[done + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < left) {
+                qi[lane] = ti;
+                qo[lane] = to;
+            }
+        }
+        qn = left;
+        __builtin_amdgcn_wave_barrier();
     }
+    if (qn > 0) round16(0, qn);
 
     // fold the 4 waves of the block in fixed order 0+1+2+3
     for (int src = 1; src < SC_BLOCK / 64; ++src) {

@@ -195,6 +195,81 @@ def build_conv_rulebook(indices, batch, shape, ksize, stride, padding):
     return idx_out, out_shape, rb, gi_out
 
 
+def build_index_plan(indices, batch, shape, steps):
+    """All rulebooks of a sequential sparse backbone with ONE host sync.
+
+    steps (forward order): {'kind': 'subm', 'key', 'ksize', 'dilation'} or
+    {'kind': 'conv', 'key', 'ksize', 'stride', 'padding'}.  The output index sets of the strided
+    convolutions are built back-to-back on the device (each level reads its input row count from
+    device memory, buffers are sized by an upper bound), then the counts are read once and the
+    neighbour tables are filled at their exact sizes.  Returns {key: indice_dict entry}."""
+    lib = L.load()
+    dev = indices.device
+    indices = indices.contiguous()
+    level = {"idx": indices, "n_upper": indices.shape[0], "n_dev": None, "shape": [int(v) for v in shape], "gi": None,
+             "n_out_dev": None}
+    levels = [level]
+    conv_steps = []
+    for st in steps:
+        if st["kind"] != "conv":
+            continue
+        cur = levels[-1]
+        ks, sd, pd = _triple(st["ksize"]), _triple(st["stride"]), _triple(st["padding"])
+        out_shape = conv_out_shape(cur["shape"], ks, sd, pd)
+        per_in = 1
+        for k, s_ in zip(ks, sd):
+            per_in *= -(-k // s_)
+        cap = int(min(cur["n_upper"] * per_in, batch * out_shape[0] * out_shape[1] * out_shape[2]))
+        gi_out = GridIndex(batch, out_shape, dev)
+        idx_out = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
+        n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        hs = [L.host_i32(v) for v in (cur["shape"], ks, sd, pd, out_shape)]
+        rc = lib.toda_gridindex_from_conv(L.ptr(cur["idx"]), cur["n_upper"], L.ptr(cur["n_dev"]), int(batch), L.hptr(hs[0]),
+                                          L.hptr(hs[1]), L.hptr(hs[2]), L.hptr(hs[3]), L.hptr(hs[4]), L.ptr(gi_out.buf),
+                                          L.ptr(idx_out), L.ptr(n_out_dev), cap, L.stream())
+        L.check(rc, "toda_gridindex_from_conv")
+        nxt = {"idx": idx_out, "n_upper": cap, "n_dev": n_out_dev, "shape": out_shape, "gi": gi_out, "cap": cap}
+        conv_steps.append((st, cur, nxt, hs))
+        levels.append(nxt)
+    if conv_steps:
+        counts = torch.cat([c[2]["n_dev"] for c in conv_steps]).tolist()  # the one sync
+        for (st, cur, nxt, hs), n_out in zip(conv_steps, counts):
+            if n_out > nxt["cap"]:
+                raise RuntimeError(f"strided rulebook {st['key']}: {n_out} outputs exceed the bound {nxt['cap']}")
+            nxt["idx"] = nxt["idx"][:n_out]
+            nxt["n"] = n_out
+    levels[0]["n"] = indices.shape[0]
+    out = {}
+    li = 0
+    for st in steps:
+        cur = levels[li]
+        if st["kind"] == "subm":
+            if st["key"] in out:
+                continue
+            rb, gi = build_subm_rulebook(cur["idx"], batch, cur["shape"], st["ksize"], st.get("dilation", 1),
+                                         grid_index=cur["gi"])
+            cur["gi"] = gi
+            out[st["key"]] = {"kind": "subm", "rb": rb, "n_in": cur["n"]}
+        else:
+            nxt = levels[li + 1]
+            ks, sd, pd = _triple(st["ksize"]), _triple(st["stride"]), _triple(st["padding"])
+            K = ks[0] * ks[1] * ks[2]
+            n_in, n_out = cur["n"], nxt["n"]
+            o2i = torch.empty((K, n_out), dtype=torch.int32, device=dev)
+            i2o = torch.empty((K, n_in), dtype=torch.int32, device=dev)
+            cnt = torch.empty((K,), dtype=torch.int32, device=dev)
+            hs = [L.host_i32(v) for v in (cur["shape"], ks, sd, pd, nxt["shape"])]
+            rc = lib.toda_rulebook_conv(L.ptr(cur["idx"]), n_in, int(batch), L.hptr(hs[0]), L.hptr(hs[1]), L.hptr(hs[2]),
+                                        L.hptr(hs[3]), L.hptr(hs[4]), L.ptr(nxt["gi"].buf), n_out, L.ptr(o2i), L.ptr(i2o),
+                                        L.ptr(cnt), L.stream())
+            L.check(rc, "toda_rulebook_conv")
+            rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=sd, padding=pd)
+            out[st["key"]] = {"kind": "conv", "rb": rb, "n_in": n_in, "out_indices": nxt["idx"],
+                              "out_shape": nxt["shape"], "gi": nxt["gi"]}
+            li += 1
+    return out
+
+
 # --------------------------------------------------------------------------- sparse conv
 def pack_weight(weight, transpose, flip_k):
     """weight [Cout, kz, ky, kx, Cin] -> MFMA fragment order (see csrc/spconv.hip)."""
@@ -343,6 +418,68 @@ def rows_affine_act(x, scale, shift, residual=None, relu=True):
                                        L.ptr(residual), n, c, int(bool(relu)), L.ptr(y), L.stream())
     L.check(rc, "toda_rows_affine_act")
     return y
+
+
+class _BNRows(torch.autograd.Function):
+    """nn.BatchNorm1d(+ReLU) over the rows of a sparse level in 3 passes forward / 5 backward
+    (torch: 5 / 7): toda_rows_moments -> toda_bn_finalize -> toda_rows_affine_act, toda_rows_bn_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        lib = L.load()
+        x = x.contiguous()
+        n, c = x.shape
+        dev = x.device
+        stats = torch.empty((4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        sums = torch.empty((2 * c,), dtype=torch.float64, device=dev)
+        if training:
+            L.check(lib.toda_rows_moments(L.ptr(x), n, c, L.ptr(sums), L.stream()), "toda_rows_moments")
+        rc = lib.toda_bn_finalize(L.ptr(sums), n, c, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                  float(momentum), float(eps), int(bool(training)), L.ptr(stats[0]), L.ptr(stats[1]),
+                                  L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
+        L.check(rc, "toda_bn_finalize")
+        y = torch.empty_like(x)
+        rc = lib.toda_rows_affine_act(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), None, n, c, int(bool(relu)), L.ptr(y),
+                                      L.stream())
+        L.check(rc, "toda_rows_affine_act")
+        ctx.save_for_backward(x, y if relu else None, stats, weight)
+        ctx.meta = (n, c, bool(relu), bool(training))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, stats, weight = ctx.saved_tensors
+        n, c, relu, training = ctx.meta
+        gy = gy.contiguous()
+        if not training:  # eval: plain affine map
+            dz = gy * (y > 0) if relu else gy
+            gx = dz * stats[2]
+            xhat = (x - stats[0]) * stats[1]
+            return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None
+        sums = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
+        gx = torch.empty_like(x)
+        gamma = weight if weight is not None else torch.ones(c, device=x.device)
+        rc = L.load().toda_rows_bn_bwd(L.ptr(gy), L.ptr(y), L.ptr(x), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(gamma), n, c,
+                                       int(relu), L.ptr(sums), L.ptr(gx), L.stream())
+        L.check(rc, "toda_rows_bn_bwd")
+        gs = sums.to(torch.float32)
+        return gx, gs[c:], gs[:c], None, None, None, None, None, None
+
+
+def bn_rows(x, bn, relu):
+    """Apply an nn.BatchNorm1d module (its parameters, buffers and train/eval state) to rows [N, C],
+    optionally fused with the ReLU that follows it."""
+    training = bn.training or not bn.track_running_stats
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    return _BNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu)
+
+
+def bn_rows_supported(x, bn):
+    c = x.shape[1]
+    return (x.is_cuda and x.dtype == torch.float32 and c >= 4 and 256 % c == 0 and bn.affine and bn.momentum is not None
+            and x.shape[0] > 1)
 
 
 # --------------------------------------------------------------- CenterHead target assign

@@ -69,7 +69,11 @@ class _Backbone8xBase(nn.Module):
         )
 
     def forward(self, batch_dict):
-        x = self.conv_input(self._input_tensor(batch_dict))
+        x = self._input_tensor(batch_dict)
+        if hasattr(spconv, "plan_indices"):
+            # all 8/9 rulebooks with one host sync instead of one per strided conv
+            spconv.plan_indices(x, self)
+        x = self.conv_input(x)
         stages = []
         for stage in (self.conv1, self.conv2, self.conv3, self.conv4):
             x = stage(x)

@@ -68,7 +68,8 @@ class SparseConvolution(SparseModule):
         """Find or build the rulebook; returns (rulebook, out_indices, out_shape, out_grid_index)."""
         cached = x.find_indice_pair(self.indice_key)
         if self.subm:
-            if cached is not None and cached["n_in"] == x.indices.shape[0] and cached["kind"] == "subm":
+            if cached is not None and cached["n_in"] == x.indices.shape[0] and cached["kind"] == "subm" \
+                    and cached["rb"].ksize == self.kernel_size:
                 return cached["rb"], x.indices, x.spatial_shape, x.grid_index
             rb, gi = ops.build_subm_rulebook(x.indices, x.batch_size, x.spatial_shape, self.kernel_size,
                                              self.dilation, grid_index=x.grid_index)

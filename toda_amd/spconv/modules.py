@@ -4,6 +4,7 @@ from collections import OrderedDict
 
 import torch.nn as nn
 
+from .. import ops
 from .core import SparseConvTensor
 
 
@@ -41,12 +42,22 @@ class SparseSequential(SparseModule):
         self.add_module(name if name is not None else str(len(self._modules)), module)
 
     def forward(self, x):
-        for module in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
                 x = module(x)
             elif isinstance(x, SparseConvTensor):
                 if x.features.shape[0] != 0:
+                    # BatchNorm1d (+ ReLU) over sparse rows: one fused HIP path instead of 2 modules
+                    if isinstance(module, nn.BatchNorm1d) and ops.bn_rows_supported(x.features, module):
+                        relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                        x = x.replace_feature(ops.bn_rows(x.features, module, relu))
+                        i += 2 if relu else 1
+                        continue
                     x = x.replace_feature(module(x.features))
             else:
                 x = module(x)
+            i += 1
         return x

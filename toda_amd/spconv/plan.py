@@ -1,0 +1,42 @@
+"""Index planning for sequential sparse backbones: build every rulebook of the network up front
+with one host round trip (toda_amd.ops.build_index_plan) instead of one per strided convolution.
+The convolution modules then find their tables in SparseConvTensor.indice_dict exactly as they
+would after a lazy build (spconv's indice_key cache)."""
+from .. import ops
+from .conv import SparseConvolution
+
+
+def conv_steps(module):
+    """Sparse convolutions of `module` in registration (= forward) order as plan steps, or None when
+    a module cannot be planned (no indice_key, dilated strided conv)."""
+    steps = []
+    for m in module.modules():
+        if not isinstance(m, SparseConvolution):
+            continue
+        if m.indice_key is None:
+            return None
+        if m.subm:
+            steps.append({"kind": "subm", "key": m.indice_key, "ksize": m.kernel_size, "dilation": m.dilation})
+        else:
+            if any(d != 1 for d in m.dilation):
+                return None
+            steps.append({"kind": "conv", "key": m.indice_key, "ksize": m.kernel_size, "stride": m.stride,
+                          "padding": m.padding})
+    return steps
+
+
+def plan_indices(x, module):
+    """Populate x.indice_dict for every sparse convolution under `module` (sequential topology)."""
+    steps = conv_steps(module)
+    if not steps or not x.indices.is_cuda:
+        return x
+    seen, ordered = set(), []
+    for st in steps:
+        if st["kind"] == "conv" and st["key"] in seen:
+            return x  # a strided rulebook reused by two layers: leave it to the lazy path
+        if st["kind"] == "conv" or st["key"] not in seen:
+            ordered.append(st)
+        seen.add(st["key"])
+    plan = ops.build_index_plan(x.indices, x.batch_size, x.spatial_shape, ordered)
+    x.indice_dict.update(plan)
+    return x

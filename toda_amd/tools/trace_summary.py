@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace CSV of bench.py over its TIMED steps only (the warm-up
+holds MIOpen find-mode kernels).  Usage: trace_summary.py <kernel_trace.csv> <timed_steps> [out.csv]"""
+import collections
+import csv
+import sys
+
+
+def main():
+    path, steps = sys.argv[1], int(sys.argv[2])
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [int(r["Start_Timestamp"]) for r in rows if "vox_insert" in r["Kernel_Name"]]
+    per_step = 2  # bs 2 -> two voxelise calls per step
+    t0 = marks[-steps * per_step]
+    t_end = int(rows[-1]["End_Timestamp"])
+    sel = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
+    agg = collections.defaultdict(lambda: [0, 0])
+    for r in sel:
+        agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        agg[r["Kernel_Name"]][1] += 1
+    busy = sum(v[0] for v in agg.values()) / 1e6
+    span = (t_end - t0) / 1e6
+    lines = [f"# timed steps={steps} span_ms={span:.2f} busy_ms={busy:.2f} kernels_per_step={len(sel) / steps:.0f}",
+             "kernel,calls_per_step,avg_us,ms_per_step"]
+    groups = collections.defaultdict(float)
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        lines.append(f'"{k}",{v[1] / steps:.1f},{v[0] / v[1] / 1e3:.2f},{v[0] / 1e6 / steps:.4f}')
+        name = k
+        if "toda::" in name:
+            key = "toda: " + name.split("toda::")[1].split("(")[0].split("<")[0]
+        elif any(t in name for t in ("miopenSp3", "igemm", "Cijk", "conv", "Conv", "Im2d", "Col2Im", "transpose", "SubTensor", "gemm")):
+            key = "miopen/blas conv"
+        elif "atch" in name and "orm" in name:
+            key = "batchnorm (torch/miopen)"
+        else:
+            key = "torch elementwise/reduce/other"
+        groups[key] += v[0] / 1e6 / steps
+    print(lines[0])
+    for k, v in sorted(groups.items(), key=lambda kv: -kv[1]):
+        print(f"{v:8.3f} ms/step  {k}")
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()

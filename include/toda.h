@@ -170,12 +170,12 @@ int toda_bn_finalize(const double* sums /*[2c] from toda_rows_moments*/, int n, 
                      const float* gamma, const float* beta, float* running_mean /*nullable*/,
                      float* running_var /*nullable*/, float momentum, float eps, int training,
                      float* mean, float* invstd, float* scale, float* shift, void* stream);
-/* Backward of the same pair: dz = dy * (y > 0) (relu != 0) or dy; sums[0:c] = sum dz,
- * sums[c:2c] = sum dz * xhat (zeroed and filled by the call; they are d(beta) and d(gamma));
+/* Backward of the same pair.  stats = [mean | invstd | scale | shift] (4*c floats, as written by
+ * toda_bn_finalize into one buffer).  dz = dy * (x*scale+shift > 0) (relu != 0) or dy;
+ * sums[0:c] = sum dz = d(beta), sums[c:2c] = sum dz*xhat = d(gamma) (zeroed and filled by the call);
  * dx = gamma * invstd * (dz - sums[0:c]/n - xhat * sums[c:2c]/n), xhat = (x - mean) * invstd. */
-int toda_rows_bn_bwd(const float* dy, const float* y /*unused when relu == 0*/, const float* x,
-                     const float* mean, const float* invstd, const float* gamma, int n, int c,
-                     int relu, double* sums /*[2c]*/, float* dx, void* stream);
+int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
+                     int n, int c, int relu, double* sums /*[2c]*/, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------
  * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,

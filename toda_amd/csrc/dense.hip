@@ -79,35 +79,61 @@ dense_tile_kernel(float* __restrict__ feat, const int4* __restrict__ idx, int n,
     }
 }
 
-// per-channel sum and sum of squares over n rows.  Thread t owns channel t % c for a stripe of
-// rows; fp32 inside the thread (<= rows_per_block/(256/c) terms), fp64 across threads and blocks.
-constexpr int MOM_ROWS = 1024;
-__global__ void __launch_bounds__(DN_BLOCK)
-rows_moments_kernel(const float* __restrict__ x, int n, int c, double* __restrict__ sums) {
-    __shared__ double sh[2 * DN_BLOCK];
-    const int lanes_per_row = c;  // c <= 256 and 256 % c == 0 is required by the caller
-    const int rows_par = DN_BLOCK / lanes_per_row;
-    const int ch = threadIdx.x % lanes_per_row, rsub = threadIdx.x / lanes_per_row;
+// Per-channel reductions over the rows of [n, c] (c a multiple of 4 that divides 256).  Thread t
+// owns 4 consecutive channels (one 16-byte load per row) for a stripe of rows; two independent
+// partial sums per quantity give the loads ILP; fp32 inside a thread (<= MOM_ROWS/rows_par terms),
+// fp64 across threads and blocks (LDS fold, then one double atomic per channel and block).
+constexpr int MOM_ROWS = 512;
+
+template <class Load>
+__device__ __forceinline__ void rows_reduce2(int n, int c, Load load, double* __restrict__ sums) {
+    __shared__ float sh[2][DN_BLOCK][4];
+    const int lanes = c >> 2;                 // threads per row
+    const int rows_par = DN_BLOCK / lanes;    // rows per block iteration
+    const int cl = threadIdx.x % lanes, rsub = threadIdx.x / lanes;
     const int row_begin = blockIdx.x * MOM_ROWS;
     const int row_end = min(n, row_begin + MOM_ROWS);
-    float s = 0.f, s2 = 0.f;
-    for (int r = row_begin + rsub; r < row_end; r += rows_par) {
-        const float v = x[(size_t)r * c + ch];
-        s += v;
-        s2 += v * v;
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, t0 = s0, s1 = s0, t1 = s0;
+    int r = row_begin + rsub;
+    for (; r + rows_par < row_end; r += 2 * rows_par) {
+        f32x4 a, b, a2, b2;
+        load(r, cl, a, b);
+        load(r + rows_par, cl, a2, b2);
+        s0 += a;
+        t0 += b;
+        s1 += a2;
+        t1 += b2;
     }
-    sh[threadIdx.x] = s;
-    sh[DN_BLOCK + threadIdx.x] = s2;
+    if (r < row_end) {
+        f32x4 a, b;
+        load(r, cl, a, b);
+        s0 += a;
+        t0 += b;
+    }
+    s0 += s1;
+    t0 += t1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sh[0][threadIdx.x][j] = s0[j];
+        sh[1][threadIdx.x][j] = t0[j];
+    }
     __syncthreads();
-    if (threadIdx.x < c) {
-        double a = 0.0, b = 0.0;
-        for (int j = 0; j < rows_par; ++j) {
-            a += sh[j * lanes_per_row + threadIdx.x];
-            b += sh[DN_BLOCK + j * lanes_per_row + threadIdx.x];
-        }
-        atomicAdd(&sums[threadIdx.x], a);
-        atomicAdd(&sums[c + threadIdx.x], b);
+    if (threadIdx.x < 2 * c) {  // thread -> (quantity, channel)
+        const int q = threadIdx.x / c, ch = threadIdx.x % c;
+        double acc = 0.0;
+        for (int j = 0; j < rows_par; ++j) acc += sh[q][j * lanes + (ch >> 2)][ch & 3];
+        atomicAdd(&sums[q * c + ch], acc);
     }
+}
+
+__global__ void __launch_bounds__(DN_BLOCK)
+rows_moments_kernel(const float* __restrict__ x, int n, int c, double* __restrict__ sums) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const int lanes = c >> 2;
+    rows_reduce2(n, c, [&](int r, int cl, f32x4& a, f32x4& b) {
+        a = x4[(size_t)r * lanes + cl];
+        b = a * a;
+    }, sums);
 }
 
 __global__ void __launch_bounds__(DN_BLOCK)
@@ -132,59 +158,46 @@ rows_affine_act_kernel(const f32x4* __restrict__ x, const float* __restrict__ sc
 }
 
 // BatchNorm1d(+ReLU) backward over sparse rows, pass 1: per-channel sums of dz and dz*xhat where
-// dz = dy * (y > 0) when the block ends in a ReLU, xhat = (x - mean) * invstd.  Same thread layout
-// and fp32-in-thread / fp64-across-threads accumulation as rows_moments_kernel.
+// dz = dy * (x*scale+shift > 0) when the block ends in a ReLU (the mask is recomputed from x, the
+// forward output is not read), xhat = (x - mean) * invstd.
 __global__ void __launch_bounds__(DN_BLOCK)
-rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
-                          const float* __restrict__ mean, const float* __restrict__ invstd, int n, int c, int relu,
-                          double* __restrict__ sums) {
-    __shared__ double sh[2 * DN_BLOCK];
-    const int rows_par = DN_BLOCK / c;
-    const int ch = threadIdx.x % c, rsub = threadIdx.x / c;
-    const int row_begin = blockIdx.x * MOM_ROWS;
-    const int row_end = min(n, row_begin + MOM_ROWS);
-    const float mu = mean[ch], is = invstd[ch];
-    float s = 0.f, s2 = 0.f;
-    for (int r = row_begin + rsub; r < row_end; r += rows_par) {
-        const size_t e = (size_t)r * c + ch;
-        float dz = dy[e];
-        if (relu && !(y[e] > 0.f)) dz = 0.f;
-        s += dz;
-        s2 += dz * ((x[e] - mu) * is);
-    }
-    sh[threadIdx.x] = s;
-    sh[DN_BLOCK + threadIdx.x] = s2;
-    __syncthreads();
-    if (threadIdx.x < c) {
-        double a = 0.0, b = 0.0;
-        for (int j = 0; j < rows_par; ++j) {
-            a += sh[j * c + threadIdx.x];
-            b += sh[DN_BLOCK + j * c + threadIdx.x];
+rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
+                          int n, int c, int relu, double* __restrict__ sums) {
+    const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const int lanes = c >> 2;
+    const int cl0 = threadIdx.x % lanes;
+    const f32x4 mu = reinterpret_cast<const f32x4*>(stats)[cl0];
+    const f32x4 is = reinterpret_cast<const f32x4*>(stats + c)[cl0];
+    const f32x4 sc = reinterpret_cast<const f32x4*>(stats + 2 * c)[cl0];
+    const f32x4 sf = reinterpret_cast<const f32x4*>(stats + 3 * c)[cl0];
+    rows_reduce2(n, c, [&](int r, int cl, f32x4& a, f32x4& b) {
+        const f32x4 g = dy4[(size_t)r * lanes + cl], xv = x4[(size_t)r * lanes + cl];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dz = (relu && !(xv[j] * sc[j] + sf[j] > 0.f)) ? 0.f : g[j];
+            a[j] = dz;
+            b[j] = dz * ((xv[j] - mu[j]) * is[j]);
         }
-        atomicAdd(&sums[threadIdx.x], a);
-        atomicAdd(&sums[c + threadIdx.x], b);
-    }
+    }, sums);
 }
 
 // pass 2: dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))
 __global__ void __launch_bounds__(DN_BLOCK)
-rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ y, const f32x4* __restrict__ x,
-                         const float* __restrict__ mean, const float* __restrict__ invstd,
+rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x, const float* __restrict__ stats,
                          const float* __restrict__ gamma, const double* __restrict__ sums, long long n4, int c, int n,
                          int relu, f32x4* __restrict__ dx) {
     const long long t = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
     if (t >= n4) return;
     const int ch = (int)((t * 4) % c);
     const f32x4 g = dy[t], xv = x[t];
-    f32x4 yv = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (relu) yv = y[t];
     f32x4 out;
     const float inv_n = 1.0f / (float)n;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float is = invstd[ch + j];
-        const float xh = (xv[j] - mean[ch + j]) * is;
-        const float dz = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
+        const float mu = stats[ch + j], is = stats[c + ch + j];
+        const float xh = (xv[j] - mu) * is;
+        const float dz = (relu && !(xv[j] * stats[2 * c + ch + j] + stats[3 * c + ch + j] > 0.f)) ? 0.f : g[j];
         const float m1 = (float)sums[ch + j] * inv_n, m2 = (float)sums[c + ch + j] * inv_n;
         out[j] = gamma[ch + j] * is * (dz - m1 - xh * m2);
     }
@@ -269,7 +282,8 @@ extern "C" int toda_pillar_scatter_bwd(const float* grad_canvas, const int32_t* 
 
 extern "C" int toda_rows_moments(const float* x, int n, int c, double* sums, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    TODA_CHECK_ARG(c >= 1 && c <= DN_BLOCK && DN_BLOCK % c == 0, "rows_moments: channels must divide 256 (got %d)", c);
+    TODA_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= DN_BLOCK / 2 && DN_BLOCK % c == 0,
+                   "rows_moments: channels must be a multiple of 4 dividing 256, <= 128 (got %d)", c);
     TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
     if (n <= 0) return TODA_OK;
     hipLaunchKernelGGL(rows_moments_kernel, dim3(cdiv(n, MOM_ROWS)), dim3(DN_BLOCK), 0, s, x, n, c, sums);
@@ -288,17 +302,18 @@ extern "C" int toda_rows_affine_act(const float* x, const float* scale, const fl
     return TODA_OK;
 }
 
-extern "C" int toda_rows_bn_bwd(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                                const float* gamma, int n, int c, int relu, double* sums, float* dx, void* stream) {
+extern "C" int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int n, int c,
+                                int relu, double* sums, float* dx, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    TODA_CHECK_ARG(c >= 4 && c <= DN_BLOCK && DN_BLOCK % c == 0, "rows_bn_bwd: channels must divide 256 and be >= 4 (got %d)", c);
+    TODA_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= DN_BLOCK / 2 && DN_BLOCK % c == 0,
+                   "rows_bn_bwd: channels must be a multiple of 4 dividing 256, <= 128 (got %d)", c);
     TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
     if (n <= 0) return TODA_OK;
-    hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(cdiv(n, MOM_ROWS)), dim3(DN_BLOCK), 0, s, dy, y, x, mean, invstd, n, c,
-                       relu, sums);
+    hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(cdiv(n, MOM_ROWS)), dim3(DN_BLOCK), 0, s, dy, x, stats, n, c, relu,
+                       sums);
     const long long n4 = (long long)n * c / 4;
     hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3(cdiv(n4, DN_BLOCK)), dim3(DN_BLOCK), 0, s, (const f32x4*)dy,
-                       (const f32x4*)y, (const f32x4*)x, mean, invstd, gamma, sums, n4, c, n, relu, (f32x4*)dx);
+                       (const f32x4*)x, stats, gamma, sums, n4, c, n, relu, (f32x4*)dx);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

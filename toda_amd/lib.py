@@ -39,7 +39,7 @@ SIGNATURES = {
     "toda_rows_moments": (_i, [_vp, _i, _i, _vp, _vp]),
     "toda_rows_affine_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "toda_bn_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp, _vp, _vp]),
-    "toda_rows_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "toda_rows_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_center_assign": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _dbl, _i, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -442,25 +442,25 @@ class _BNRows(torch.autograd.Function):
         rc = lib.toda_rows_affine_act(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), None, n, c, int(bool(relu)), L.ptr(y),
                                       L.stream())
         L.check(rc, "toda_rows_affine_act")
-        ctx.save_for_backward(x, y if relu else None, stats, weight)
+        ctx.save_for_backward(x, stats, weight)
         ctx.meta = (n, c, bool(relu), bool(training))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, stats, weight = ctx.saved_tensors
+        x, stats, weight = ctx.saved_tensors
         n, c, relu, training = ctx.meta
         gy = gy.contiguous()
         if not training:  # eval: plain affine map
-            dz = gy * (y > 0) if relu else gy
+            dz = gy * (x * stats[2] + stats[3] > 0) if relu else gy
             gx = dz * stats[2]
             xhat = (x - stats[0]) * stats[1]
             return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None
         sums = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
         gx = torch.empty_like(x)
         gamma = weight if weight is not None else torch.ones(c, device=x.device)
-        rc = L.load().toda_rows_bn_bwd(L.ptr(gy), L.ptr(y), L.ptr(x), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(gamma), n, c,
-                                       int(relu), L.ptr(sums), L.ptr(gx), L.stream())
+        rc = L.load().toda_rows_bn_bwd(L.ptr(gy), L.ptr(x), L.ptr(stats), L.ptr(gamma), n, c, int(relu), L.ptr(sums),
+                                       L.ptr(gx), L.stream())
         L.check(rc, "toda_rows_bn_bwd")
         gs = sums.to(torch.float32)
         return gx, gs[c:], gs[:c], None, None, None, None, None, None
@@ -478,7 +478,7 @@ def bn_rows(x, bn, relu):
 
 def bn_rows_supported(x, bn):
     c = x.shape[1]
-    return (x.is_cuda and x.dtype == torch.float32 and c >= 4 and 256 % c == 0 and bn.affine and bn.momentum is not None
+    return (x.is_cuda and x.dtype == torch.float32 and 4 <= c <= 128 and 256 % c == 0 and bn.affine and bn.momentum is not None
             and x.shape[0] > 1)
 
 

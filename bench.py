@@ -40,6 +40,8 @@ WORKLOADS = {
            "CenterPoint-Voxel fwd+bwd+optimizer, synthetic 180k-pt Waymo-shape clouds, bs 2 per GPU"),
     "c5": ("toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml", 2,
            "TODA stage-1 CenterPoint (VoxelResBackBone8x), mixed 180k/35k-pt clouds, bs 2 per GPU"),
+    "c5cl": ("toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml", 2,
+             "TODA stage-2 consistency step (2 fwd + 1 bwd, VoxelResBackBone8x), mixed 180k/35k-pt clouds, bs 2 per GPU"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA peak (dense)
@@ -63,6 +65,22 @@ def make_device_batches(dataset, per_gpu, n_batches, rank, device):
         out["gt_boxes"] = torch.from_numpy(col["gt_boxes"]).float().to(device)
         batches.append(out)
     return batches
+
+
+def make_device_pair_batches(dataset, per_gpu, n_batches, rank, device):
+    """(adv, org) batches of the stage-2 consistency step, tensors resident on the device."""
+    out = []
+    for b in range(n_batches):
+        base = (rank * n_batches + b) * per_gpu
+        pair = dataset.collate_batch([dataset[(base + i) % len(dataset)] for i in range(per_gpu)])
+        dev = []
+        for col in pair:
+            d = {k: v for k, v in col.items() if k in ("batch_size", "points_per_sample", "augmentation_list", "augmentation_params")}
+            d["points"] = torch.from_numpy(col["points"]).float().to(device)
+            d["gt_boxes"] = torch.from_numpy(col["gt_boxes"]).float().to(device)
+            dev.append(d)
+        out.append(tuple(dev))
+    return out
 
 
 class KernelTimer:
@@ -102,7 +120,13 @@ class KernelTimer:
 def run_gpu(args, rank, world, device):
     yaml_path, per_gpu, desc = WORKLOADS[args.workload]
     cfg = load_cfg(yaml_path)
-    dataset = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    pair = args.workload.endswith("cl")
+    if pair:
+        from toda_amd.pcdet.datasets import SyntheticPairDataset
+        from toda_amd.pcdet.models import DistModel, model_fn_decorator_cl
+        dataset = SyntheticPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    else:
+        dataset = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
     torch.manual_seed(1234)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), dataset).to(device)
     model.train()
@@ -110,9 +134,15 @@ def run_gpu(args, rank, world, device):
     total_steps = max(args.steps + args.warmup, 10)
     scheduler, _ = build_scheduler(optimizer, total_steps, 1, -1, cfg.OPTIMIZATION)
     net = model
+    if pair:
+        model = DistModel(model)
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
-    batches = make_device_batches(dataset, per_gpu, args.batches, rank, device)
+    if pair:
+        batches = make_device_pair_batches(dataset, per_gpu, args.batches, rank, device)
+        cl_fn = model_fn_decorator_cl()
+    else:
+        batches = make_device_batches(dataset, per_gpu, args.batches, rank, device)
     params = [p for p in net.parameters() if p.requires_grad]
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
     timer = KernelTimer()
@@ -120,14 +150,19 @@ def run_gpu(args, rank, world, device):
     def step(it):
         scheduler.step(it)
         optimizer.zero_grad()
-        batch = dict(batches[it % len(batches)])
-        voxelize_on_gpu(batch, dataset.voxel_cfg)
-        ret, tb, _ = model(batch)
-        loss = ret["loss"].mean()
+        if pair:
+            adv, org = batches[it % len(batches)]
+            loss = cl_fn(model, dict(adv), dict(org), world > 1).loss
+        else:
+            batch = dict(batches[it % len(batches)])
+            voxelize_on_gpu(batch, dataset.voxel_cfg)
+            ret, tb, _ = model(batch)
+            loss = ret["loss"].mean()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, clip)
         optimizer.step()
-        net.update_global_step()
+        if not pair:
+            net.update_global_step()
         return loss
 
     for it in range(args.warmup):
@@ -266,7 +301,8 @@ def main():
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": res["desc"], "global_batch": per_gpu * world, "points_per_cloud": 180000,
+            "config": {"workload": res["desc"], "global_batch": per_gpu * world,
+                       "points_per_cloud": 180000 if args.workload == "c3" else "180000/35000 alternating",
                        "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4)},
             "roofline": roof,
         }

@@ -1,0 +1,151 @@
+"""Host-side logic that needs neither the GPU nor the reference: config system, dataset contract,
+collate, processors, checkpoint layout conversion, stage-2 consistency helpers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from toda_amd.pcdet.config import AttrDict, cfg_from_list, cfg_from_yaml_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "toda_amd/tools/cfgs/models")
+
+
+def load(name):
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(CFG, name + ".yaml"), cfg)
+    return cfg
+
+
+@pytest.mark.parametrize("name,grid,p,cap,c", [
+    ("pointpillar_kitti", [432, 496, 1], 32, 16000, 4),
+    ("second_backbone_nuscenes", [1024, 1024, 40], 10, 60000, 5),
+    ("centerpoint_voxel_waymo", [1504, 1504, 40], 5, 150000, 5),
+    ("toda_stage1_centerpoint_res", [1440, 1440, 49], 10, 120000, 4),
+])
+def test_baseline_configs_resolve_to_the_survey_geometry(name, grid, p, cap, c):
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+
+    cfg = load(name)
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    assert list(ds.grid_size) == grid
+    assert ds.voxel_cfg["max_points_per_voxel"] == p and ds.voxel_cfg["max_num_voxels"] == cap
+    assert ds.point_feature_encoder.num_point_features == c
+
+
+def test_config_set_overrides_and_base_include():
+    cfg = load("centerpoint_voxel_waymo")
+    assert cfg.DATA_CONFIG.DATASET == "SyntheticLidarDataset"  # came through _BASE_CONFIG_
+    cfg_from_list(["OPTIMIZATION.LR", "0.01", "MODEL.BACKBONE_2D.LAYER_NUMS", "[3,3]", "OPTIMIZATION.LR_WARMUP", "True"], cfg)
+    assert cfg.OPTIMIZATION.LR == 0.01 and cfg.MODEL.BACKBONE_2D.LAYER_NUMS == [3, 3] and cfg.OPTIMIZATION.LR_WARMUP is True
+    with pytest.raises(AssertionError):
+        cfg_from_list(["MODEL.NOPE", "1"], cfg)
+    assert cfg.MODEL.get("ROI_HEAD", None) is None
+
+
+def test_parameter_counts_match_survey_a4():
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import build_network
+
+    for name, expect in (("centerpoint_voxel_waymo", 5775803), ("toda_stage1_centerpoint_res", 7757225)):
+        cfg = load(name)
+        ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+        model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+        assert sum(p.numel() for p in model.parameters()) == expect
+        keys = set(model.state_dict())
+        assert {"backbone_3d.conv_input.0.weight", "backbone_3d.conv_out.0.weight", "backbone_2d.blocks.0.1.weight",
+                "dense_head.shared_conv.0.weight", "dense_head.heads_list.0.hm.1.bias", "global_step"} <= keys
+
+
+def test_dataset_sample_is_deterministic_and_masks_range():
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+
+    cfg = load("second_backbone_nuscenes")
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = 5000
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    a, b = ds[3], ds[3]
+    assert np.array_equal(a["points"], b["points"]) and np.array_equal(a["gt_boxes"], b["gt_boxes"])
+    r = cfg.DATA_CONFIG.POINT_CLOUD_RANGE
+    p = a["points"]
+    assert (p[:, 0] >= r[0]).all() and (p[:, 0] <= r[3]).all() and (p[:, 1] >= r[1]).all() and (p[:, 1] <= r[4]).all()
+    assert a["gt_boxes"].shape[1] == 8 and set(np.unique(a["gt_boxes"][:, 7])) <= {1.0, 2.0, 3.0}
+
+
+def test_collate_batch_contract():
+    from toda_amd.pcdet.datasets import DatasetTemplate
+
+    s0 = {"points": np.ones((5, 4), np.float32), "voxels": np.zeros((3, 2, 4), np.float32), "voxel_coords": np.zeros((3, 3), np.int32),
+          "voxel_num_points": np.ones(3, np.int32), "gt_boxes": np.ones((2, 8), np.float32), "frame_id": "a"}
+    s1 = {"points": np.ones((7, 4), np.float32), "voxels": np.zeros((4, 2, 4), np.float32), "voxel_coords": np.zeros((4, 3), np.int32),
+          "voxel_num_points": np.ones(4, np.int32), "gt_boxes": np.ones((5, 8), np.float32), "frame_id": "b"}
+    out = DatasetTemplate.collate_batch([s0, s1])
+    assert out["batch_size"] == 2 and out["points"].shape == (12, 5) and out["voxel_coords"].shape == (7, 4)
+    assert out["points"][:5, 0].tolist() == [0] * 5 and out["points"][5:, 0].tolist() == [1] * 7
+    assert out["voxel_coords"][3:, 0].tolist() == [1] * 4
+    assert out["gt_boxes"].shape == (2, 5, 8) and (out["gt_boxes"][0, 2:] == 0).all()
+    assert out["voxels"].shape == (7, 2, 4) and out["points_per_sample"] == [5, 7]
+
+
+def test_spconv_v1_checkpoint_layout_is_converted_on_load(tmp_path):
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import build_network
+
+    cfg = load("centerpoint_voxel_waymo")
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    model = build_network(cfg.MODEL, 3, ds)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    key = "backbone_3d.conv2.0.0.weight"            # [Cout,kz,ky,kx,Cin] here; spconv 1.x stores [kz,ky,kx,Cin,Cout]
+    v1 = sd[key].permute(1, 2, 3, 4, 0).contiguous()
+    sd[key] = v1
+    path = tmp_path / "ckpt.pth"
+    torch.save({"model_state": sd, "epoch": 3, "it": 7, "optimizer_state": None}, path)
+    fresh = build_network(cfg.MODEL, 3, ds)
+    fresh.load_params_from_file(str(path), to_cpu=True)
+    assert torch.equal(fresh.state_dict()[key], model.state_dict()[key])
+    it, epoch = fresh.load_params_with_optimizer(str(path), to_cpu=True)
+    assert (it, epoch) == (7, 3)
+
+
+def test_consistency_helpers_round_trip():
+    from toda_amd.pcdet.models import get_consistency_loss, random_world_flip, random_world_rotation, random_world_scaling
+
+    rng = np.random.default_rng(0)
+    boxes = torch.from_numpy(rng.uniform(-5, 5, (6, 7)).astype(np.float32))
+    b = boxes.clone()
+    b = random_world_flip(b, ["x"])
+    b = random_world_rotation(b, 0.3)
+    b = random_world_scaling(b, 1.04)
+    b = random_world_scaling(b, 1.04, reverse=True)
+    b = random_world_rotation(b, 0.3, reverse=True)
+    b = random_world_flip(b, ["x"], reverse=True)
+    assert torch.allclose(b, boxes, atol=1e-5)
+    c, s = get_consistency_loss([{"pred_boxes": boxes.clone()}], [{"pred_boxes": boxes.clone()}])
+    assert float(c) == 0.0 and float(s) == 0.0
+    shifted = boxes.clone()
+    shifted[:, 0] += 0.5
+    c, s = get_consistency_loss([{"pred_boxes": boxes.clone()}], [{"pred_boxes": shifted}])
+    assert abs(float(c) - 0.5) < 1e-5 and float(s) == 0.0
+
+
+def test_stage2_two_forward_one_backward_step_on_cpu():
+    from oracle.cpu_backend import oracle_backend
+    from toda_amd.pcdet.datasets import SyntheticPairDataset
+    from toda_amd.pcdet.models import DistModel, build_network, model_fn_decorator_cl
+
+    cfg = load("toda_stage1_centerpoint_res")
+    cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [-7.2, -7.2, -5.0, 7.2, 7.2, 4.8]
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = 4000
+    cfg.MODEL.BACKBONE_2D.LAYER_NUMS = [1, 1]
+    cfg.MODEL.DENSE_HEAD.POST_PROCESSING.POST_CENTER_LIMIT_RANGE = [-7.2, -7.2, -10, 7.2, 7.2, 10]
+    ds = SyntheticPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    torch.manual_seed(0)
+    model = build_network(cfg.MODEL, 1, ds).train()
+    adv, org = ds.collate_batch([ds[0], ds[1]])
+    assert org["augmentation_list"][0][-1] == "random_world_scaling"
+    with oracle_backend():
+        ret = model_fn_decorator_cl()(DistModel(model), adv, org)
+        ret.loss.backward()
+    assert torch.isfinite(ret.loss) and {"loss_org", "cl_center", "cl_size"} <= set(ret.tb_dict)
+    assert int(model.global_step) == 1
+    assert all(p.grad is not None for n, p in model.named_parameters() if "backbone_3d.conv_input.0" in n)

@@ -9,11 +9,12 @@ from torch.utils.data import DistributedSampler as _DistributedSampler
 
 from ..utils import common_utils
 from .dataset import DatasetTemplate
-from .synthetic import SyntheticLidarDataset
+from .synthetic import SyntheticLidarDataset, SyntheticPairDataset
 
 __all__ = {
     "DatasetTemplate": DatasetTemplate,
     "SyntheticLidarDataset": SyntheticLidarDataset,
+    "SyntheticPairDataset": SyntheticPairDataset,
 }
 
 

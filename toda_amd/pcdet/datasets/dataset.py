@@ -76,6 +76,8 @@ class DatasetTemplate(torch_data.Dataset):
                     [np.pad(v, ((0, 0), (1, 0)), mode="constant", constant_values=i) for i, v in enumerate(vals)], axis=0)
                 if key == "points":
                     ret["points_per_sample"] = [int(v.shape[0]) for v in vals]
+            elif key in ("augmentation_list", "augmentation_params"):
+                ret[key] = list(vals)  # per-sample python objects (stage-2 consistency step)
             elif key == "gt_boxes":
                 width = vals[0].shape[-1]
                 out = np.zeros((len(vals), max(len(v) for v in vals), width), dtype=np.float32)

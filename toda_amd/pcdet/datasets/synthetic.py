@@ -90,3 +90,56 @@ class SyntheticLidarDataset(DatasetTemplate):
         data = {"points": points, "gt_boxes": boxes, "gt_names": names, "frame_id": f"syn_{index:06d}",
                 "_rng": np.random.default_rng(10_000_019 * (self.seed + 1) + index)}
         return self.prepare_data(data)
+
+
+def _rotate_z(xyz, angle):
+    c, s_ = np.cos(angle), np.sin(angle)
+    rot = np.array([[c, s_, 0], [-s_, c, 0], [0, 0, 1]], dtype=np.float32)
+    return xyz @ rot
+
+
+class SyntheticPairDataset(SyntheticLidarDataset):
+    """Stage-2 shaped items (reference nuscenes_mixup_adv_dataset.py:286-588 returns a pair): the
+    same frame twice - `adv`: points nudged by eps * sign-noise (eps = 1e-3, the role of the stored
+    voxel perturbation), `org`: the clean frame under a recorded global flip / rotation / scaling,
+    which model_fn_decorator_cl undoes on the decoded boxes (reverse_transform)."""
+
+    EPS = 1e-3
+
+    def __getitem__(self, index):
+        points, boxes, names = self.raw_sample(index)
+        rng = np.random.default_rng(7_000_003 * (self.seed + 1) + index)
+        adv_pts = points.copy()
+        adv_pts[:, :3] -= self.EPS * np.sign(rng.standard_normal((len(points), 3))).astype(np.float32)
+        adv = {"points": adv_pts, "gt_boxes": boxes.copy(), "gt_names": names.copy(), "frame_id": f"syn_{index:06d}_adv",
+               "augmentation_list": [], "augmentation_params": {},
+               "_rng": np.random.default_rng(10_000_019 * (self.seed + 1) + index)}
+        org_pts, org_boxes = points.copy(), boxes.copy()
+        aug_list, aug_params = [], {}
+        if rng.random() < 0.5:  # flip along x: y -> -y
+            org_pts[:, 1] = -org_pts[:, 1]
+            org_boxes[:, 1] = -org_boxes[:, 1]
+            org_boxes[:, 6] = -org_boxes[:, 6]
+            aug_list.append("random_world_flip")
+            aug_params["random_world_flip"] = ["x"]
+        angle = float(rng.uniform(-0.3925, 0.3925))
+        org_pts[:, :3] = _rotate_z(org_pts[:, :3], angle)
+        org_boxes[:, :3] = _rotate_z(org_boxes[:, :3], angle)
+        org_boxes[:, 6] += angle
+        aug_list.append("random_world_rotation")
+        aug_params["random_world_rotation"] = angle
+        scale = float(rng.uniform(0.95, 1.05))
+        org_pts[:, :3] *= scale
+        org_boxes[:, :6] *= scale
+        aug_list.append("random_world_scaling")
+        aug_params["random_world_scaling"] = scale
+        org = {"points": org_pts, "gt_boxes": org_boxes, "gt_names": names.copy(), "frame_id": f"syn_{index:06d}_org",
+               "augmentation_list": aug_list, "augmentation_params": aug_params,
+               "_rng": np.random.default_rng(10_000_019 * (self.seed + 1) + index)}
+        return self.prepare_data(adv), self.prepare_data(org)
+
+    @staticmethod
+    def collate_batch(batch_list, _unused=False):
+        adv = DatasetTemplate.collate_batch([b[0] for b in batch_list])
+        org = DatasetTemplate.collate_batch([b[1] for b in batch_list])
+        return adv, org

@@ -62,3 +62,153 @@ def model_fn_decorator():
         return ModelReturn(loss, tb_dict, disp_dict)
 
     return model_func
+
+
+# --------------------------------------------------------------------------------------------
+# TODA stage 2: "2 forward + 1 backward" consistency step (reference :88-260).
+# ---------------------------------------------------------------------------------------------
+def random_world_flip(box_preds, params, reverse=False):
+    order = ("y", "x") if reverse else ("x", "y")
+    for axis in order:
+        if axis not in params:
+            continue
+        if axis == "x":
+            box_preds[:, 1] = -box_preds[:, 1]
+            box_preds[:, 6] = -box_preds[:, 6]
+        else:
+            box_preds[:, 0] = -box_preds[:, 0]
+            box_preds[:, 6] = -(box_preds[:, 6] + np.pi)
+    return box_preds
+
+
+def random_world_rotation(box_preds, params, reverse=False):
+    angle = torch.tensor([-params if reverse else params], dtype=torch.float32, device=box_preds.device)
+    c, s_, z, o = torch.cos(angle), torch.sin(angle), angle.new_zeros(1), angle.new_ones(1)
+    rot = torch.stack((c, s_, z, -s_, c, z, z, z, o), dim=1).reshape(3, 3)
+    box_preds[:, :3] = box_preds[:, :3] @ rot
+    box_preds[:, 6] += float(angle)
+    return box_preds
+
+
+def random_world_scaling(box_preds, params, reverse=False):
+    box_preds[:, :6] *= (1.0 / params) if reverse else params
+    return box_preds
+
+
+_AUGS = {"random_world_flip": random_world_flip, "random_world_rotation": random_world_rotation,
+         "random_world_scaling": random_world_scaling}
+
+
+@torch.no_grad()
+def reverse_transform(boxes, batch_dict):
+    """Undo the recorded world augmentations (last applied first) on the decoded boxes of each sample."""
+    lists, params = batch_dict.get("augmentation_list"), batch_dict.get("augmentation_params")
+    if lists is None:
+        return boxes
+    for b, box in enumerate(boxes):
+        preds = box["pred_boxes"]
+        for key in list(lists[b])[::-1]:
+            if key == "gt_sampling":
+                continue
+            preds = _AUGS[key](preds, params[b][key], reverse=True)
+        box["pred_boxes"] = preds
+    return boxes
+
+
+def filter_boxes_centerpoint(batch_dict, model):
+    """Decoded (top-K, score-thresholded, un-NMSed) boxes of a CenterHead forward (reference :310-360)."""
+    net = model.module if hasattr(model, "module") and not hasattr(model, "dense_head") else model
+    net = getattr(net, "onepass", net)
+    head = net.dense_head
+    from .model_utils import centernet_utils
+
+    post = head.model_cfg.POST_PROCESSING
+    ref = batch_dict["pred_dicts"][0]["hm"]
+    limit = torch.tensor(post.POST_CENTER_LIMIT_RANGE, dtype=torch.float32, device=ref.device)
+    out = [{"pred_boxes": [], "pred_scores": []} for _ in range(batch_dict["batch_size"])]
+    for pred in batch_dict["pred_dicts"]:
+        hm = pred["hm"]
+        hm = hm if (hm.min() >= 0 and hm.max() <= 1) else hm.sigmoid()  # get_loss already applied the sigmoid
+        decoded = centernet_utils.decode_bbox_from_heatmap(
+            heatmap=hm, rot_cos=pred["rot"][:, 0:1], rot_sin=pred["rot"][:, 1:2], center=pred["center"],
+            center_z=pred["center_z"], dim=pred["dim"].exp(), vel=None, point_cloud_range=head.point_cloud_range,
+            voxel_size=head.voxel_size, feature_map_stride=head.feature_map_stride, K=post.MAX_OBJ_PER_SAMPLE,
+            circle_nms=False, score_thresh=post.SCORE_THRESH, post_center_limit_range=limit)
+        for k, d in enumerate(decoded):
+            out[k]["pred_boxes"].append(d["pred_boxes"])
+            out[k]["pred_scores"].append(d["pred_scores"])
+    for d in out:
+        d["pred_boxes"] = torch.cat(d["pred_boxes"], dim=0)
+        d["pred_scores"] = torch.cat(d["pred_scores"], dim=0)
+    return out
+
+
+def get_consistency_loss(adv_boxes, org_boxes):
+    """Nearest-centre matching (< 1 m^2) between the two passes; L1 on centres, MSE on sizes.  The
+    reference detaches both box sets (:229-230), so this term carries no gradient; kept as is."""
+    import torch.nn.functional as F
+
+    centre_terms, size_terms, norm = [], [], 0
+    for adv, org in zip(adv_boxes, org_boxes):
+        a, o = adv["pred_boxes"].detach(), org["pred_boxes"].detach()
+        norm += 1
+        if a.shape[0] == 0 or o.shape[0] == 0:
+            continue
+        d2 = ((a[:, None, :3] - o[None, :, :3]) ** 2).sum(-1)
+        d_a, idx_o_of_a = d2.min(1)
+        d_o, idx_a_of_o = d2.min(0)
+        m_o = (d_a < 1).float().unsqueeze(-1)   # adv boxes that found an org partner
+        m_a = (d_o < 1).float().unsqueeze(-1)
+        n = a.shape[0] + o.shape[0]
+        centre_terms.append((((a[:, :3] - o[idx_o_of_a, :3]) * m_o).abs().sum()
+                             + ((o[:, :3] - a[idx_a_of_o, :3]) * m_a).abs().sum()) / n)
+        size_terms.append(((F.mse_loss(o[idx_o_of_a, 3:6], a[:, 3:6], reduction="none") * m_o).sum()
+                           + (F.mse_loss(a[idx_a_of_o, 3:6], o[:, 3:6], reduction="none") * m_a).sum()) / n)
+    zero = 0.0
+    return (sum(centre_terms) if centre_terms else zero) / max(norm, 1), (sum(size_terms) if size_terms else zero) / max(norm, 1)
+
+
+class DistModel(torch.nn.Module):
+    """Both passes inside ONE module forward so that DDP sees a single backward and issues a single
+    gradient all-reduce (reference tools/stage2_mixup_train_cl.py:61-74)."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.onepass = model
+
+    def forward(self, batch_adv, batch_org):
+        return self.onepass(batch_adv), self.onepass(batch_org)
+
+    def update_global_step(self):
+        self.onepass.update_global_step()
+
+
+def model_fn_decorator_cl():
+    """loss = loss_adv + loss_org + 0.1 * (centre consistency + size consistency)."""
+
+    def model_func(model, adv_batch_dict, org_batch_dict, dist=False):
+        net = model.module if hasattr(model, "module") and not hasattr(model, "dataset") else model
+        net = getattr(net, "onepass", net)
+        for b in (adv_batch_dict, org_batch_dict):
+            load_data_to_gpu(b)
+            if "voxels" not in b and "points" in b:
+                voxelize_on_gpu(b, net.dataset.voxel_cfg)
+        net.return_batch_dict = True
+        try:
+            if isinstance(model, DistModel) or isinstance(getattr(model, "module", None), DistModel):
+                (adv_b, adv_ret, adv_tb, adv_disp), (org_b, org_ret, org_tb, org_disp) = model(adv_batch_dict, org_batch_dict)
+            else:
+                adv_b, adv_ret, adv_tb, adv_disp = model(adv_batch_dict)
+                org_b, org_ret, org_tb, org_disp = model(org_batch_dict)
+        finally:
+            net.return_batch_dict = False
+        loss_adv, loss_org = adv_ret["loss"].mean(), org_ret["loss"].mean()
+        adv_boxes = filter_boxes_centerpoint(adv_b, net)
+        org_boxes = reverse_transform(filter_boxes_centerpoint(org_b, net), org_b)
+        centre_loss, size_loss = get_consistency_loss(adv_boxes, org_boxes)
+        loss = loss_adv + loss_org + 0.1 * (centre_loss + size_loss)
+        net.update_global_step()
+        adv_tb = dict(adv_tb, loss_org=loss_org.detach(), cl_center=centre_loss, cl_size=size_loss)
+        return ModelReturn(loss, adv_tb, adv_disp)
+
+    return model_func

@@ -12,6 +12,10 @@ class CenterPoint(Detector3DTemplate):
             batch_dict = module(batch_dict)
         if self.training:
             loss, tb_dict, disp_dict = self.get_training_loss()
+            if getattr(self, "return_batch_dict", False):
+                # the stage-2 consistency step also needs the raw head outputs (reference models/__init__.py:96-102)
+                batch_dict["pred_dicts"] = self.dense_head.forward_ret_dict["pred_dicts"]
+                return batch_dict, {"loss": loss}, tb_dict, disp_dict
             return {"loss": loss}, tb_dict, disp_dict
         return self.post_processing(batch_dict)
 

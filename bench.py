@@ -191,6 +191,19 @@ def run_gpu(args, rank, world, device):
             "dataset": dataset, "model": net}
 
 
+def pmc_traffic(d):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (separate FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_pmc_*.json); None
+    when no profiled launch shape matches (PMC counters cannot be read from inside bench.py)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_gather_gemm_64x64.json")
+    if not os.path.exists(path) or (d["c_gather"], d["c_produce"], d["K"]) != (64, 64, 27):
+        return None
+    for shape in json.load(open(path))["launch_shapes"]:
+        if 0 <= shape["rows_upper"] - d["n_out"] < 1024:
+            return shape["hbm_bytes"]
+    return None
+
+
 def roofline_from_timer(timer):
     """Dominant gather-GEMM launch shape (largest total time inside the timed region)."""
     groups = timer.summary()
@@ -214,7 +227,7 @@ def roofline_from_timer(timer):
     else:
         achieved, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
     roof = {"bound": d["bound"], "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": None,
+            "frac": round(achieved / peak, 4), "traffic": pmc_traffic(d),
             "kernel": f"gather_gemm_kernel rows={d['n_out']} K={d['K']} {d['c_gather']}->{d['c_produce']} pairs={d['pairs']}",
             "avg_launch_ms": round(d["ms"], 4)}
     return roof, rows

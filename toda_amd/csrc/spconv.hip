@@ -93,14 +93,15 @@ __device__ __forceinline__ void gather_rows(const float* __restrict__ in, int cg
 template <int Q, int NT, int RT, bool PF>
 __global__ void __launch_bounds__(SC_BLOCK)
 gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
-                   int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out) {
+                   int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out, int xcd_order) {
     const int lane = threadIdx.x & 63;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give
     // each XCD one contiguous range of row tiles - canonical rows are spatial neighbours and gather
     // overlapping input rows, which then hit in that XCD's L2 instead of being fetched 8 times.
     // (speed only; any placement is correct)
     const int nwg = gridDim.x, xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int tile_block = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int tile_block = xcd_order ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3)
+                                     : (int)blockIdx.x;
     const int wave = tile_block * (SC_BLOCK / 64) + (threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int row0 = wave * (16 * RT);
@@ -432,13 +433,14 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int c_gather, const floa
     // tuning knobs for experiments: TODA_GG_RT in {1,2,4} (0 = built-in choice), TODA_GG_PF in {0,1}
     static const int env_rt = getenv("TODA_GG_RT") ? atoi(getenv("TODA_GG_RT")) : 0;
     static const int env_pf = getenv("TODA_GG_PF") ? atoi(getenv("TODA_GG_PF")) : 0;
+    static const int env_xcd = getenv("TODA_GG_XCD") ? atoi(getenv("TODA_GG_XCD")) : 0;  // measured 6-8 % slower: z-slabs differ in density, round-robin balances better
     int rt_sel = env_rt ? env_rt : (NT >= 8 ? 1 : 2);
     if (NT >= 8 && rt_sel > 2) rt_sel = 2;
     if (Q >= 8 && rt_sel > 2) rt_sel = 2;
 #define GG(QQ, NN, RR, PP)                                                                                            \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP>),                                           \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, c_gather, wp, nbr, \
-                       n_out, k_vol, c_produce, bias, out)
+                       n_out, k_vol, c_produce, bias, out, env_xcd)
 #define GG_PF(QQ, NN, RR)        \
     if (env_pf) {                \
         GG(QQ, NN, RR, true);    \

@@ -125,13 +125,15 @@ int toda_rulebook_conv(const int32_t* idx_in, int n_in, int batch,
 size_t toda_spconv_packed_weight_floats(int k_vol, int c_gather, int c_produce);
 int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int cin,
                             int transpose, int flip_k, float* wp, void* stream);
-/* out[o, :] = bias + sum_k Wp[k] . in[nbr[k*n_out + o], :]   (rows with nbr<0 skipped) */
-int toda_spconv_gather_gemm(const float* in, int c_gather, const float* wp,
+/* out[o, :] = bias + sum_k Wp[k] . in[nbr[k*n_out + o], :]   (rows with nbr<0 skipped).
+ * `in` has n_in rows of c_gather floats (the table is read through a bounds-checked buffer
+ * descriptor, so n_in * c_gather * 4 must be < 4 GiB). */
+int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp,
                             const int32_t* nbr, int n_out, int k_vol, int c_produce,
                             const float* bias /*nullable*/, float* out, void* stream);
 /* dw[co][k][ci] = sum_o in[nbr[k*n_out+o], ci] * dout[o, co] */
 size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout);
-int toda_spconv_wgrad(const float* in, const float* dout, const int32_t* nbr,
+int toda_spconv_wgrad(const float* in, int n_in, const float* dout, const int32_t* nbr,
                       int n_out, int k_vol, int cin, int cout, float* dw,
                       void* ws, size_t ws_bytes, void* stream);
 

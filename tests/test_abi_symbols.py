@@ -37,7 +37,7 @@ def test_host_side_size_queries_need_no_gpu():
 
 def test_bad_arguments_fail_loudly_without_touching_the_device():
     lib = L.load()
-    rc = lib.toda_spconv_gather_gemm(None, 200, None, None, 0, 27, 16, None, None, None)
+    rc = lib.toda_spconv_gather_gemm(None, 0, 200, None, None, 0, 27, 16, None, None, None)
     assert rc == -1 and b"channels" in lib.toda_last_error()
 
 

@@ -19,6 +19,8 @@
 //     NT accumulators for one row are NT consecutive channels -> one 16/32-byte store.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace toda {
@@ -60,27 +62,39 @@ pack_weight_kernel(const float* __restrict__ w, int cout, int K, int cin, int tr
     wp[e] = v;
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer resource over a whole fp32 table.  Reads through it are bounds-checked by the hardware:
+// an offset >= bytes returns 0 and touches no memory, which is how "no neighbour" (-1) rows are
+// gathered as zeros WITHOUT a branch (branches around loads make hipcc serialise them behind
+// s_waitcnt vmcnt(0), cdna_hip_programming.md §5 trap (c)).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
 // Gather one wave's A fragments for one offset: lane (r, g) of row tile rt reads the 4 channels
-// 16q+4g..+3 of input row src[rt] (zeros when there is no neighbour).
-template <int Q, int RT>
-__device__ __forceinline__ void gather_rows(const float* __restrict__ in, int cg, bool vec, int g, const int (&src)[RT],
+// 16q+4g..+3 of input row src[rt] (zeros when src < 0).  Channels >= cg (only when cg is not a
+// multiple of 16) meet zero weights in the packed operand and are zeroed here as well.
+template <int Q, int RT, bool VEC>
+__device__ __forceinline__ void gather_rows(__amdgpu_buffer_rsrc_t rsrc, int cg, int g, const int (&src)[RT],
                                             f32x4 (&a)[RT][Q]) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
+        const unsigned row_off = (unsigned)src[rt] * (unsigned)cg * 4u;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int col = 16 * q + 4 * g;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (src[rt] >= 0) {
-                const float* p = in + (size_t)src[rt] * cg + col;
-                if (vec) {
-                    if (col < cg) v = *reinterpret_cast<const f32x4*>(p);
-                } else {
-                    if (col + 0 < cg) v[0] = p[0];
-                    if (col + 1 < cg) v[1] = p[1];
-                    if (col + 2 < cg) v[2] = p[2];
-                    if (col + 3 < cg) v[3] = p[3];
-                }
+            const bool ok = src[rt] >= 0 && col < cg;
+            const unsigned off = row_off + (unsigned)col * 4u;
+            f32x4 v;
+            if constexpr (VEC) {
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off : OOB, 0, 0));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                         rsrc, (ok && col + j < cg) ? off + 4u * j : OOB, 0, 0));
             }
             a[rt][q] = v;
         }
@@ -90,10 +104,11 @@ __device__ __forceinline__ void gather_rows(const float* __restrict__ in, int cg
 // PF = software pipeline depth: with PF the neighbour ids of offset k+2 and the gathered rows of
 // offset k+1 are requested before the MFMAs of offset k issue, so a wave's HBM/L2 round trips run
 // under its own matrix work instead of relying on other waves to cover them.
-template <int Q, int NT, int RT, bool PF>
+template <int Q, int NT, int RT, bool PF, bool VEC>
 __global__ void __launch_bounds__(SC_BLOCK)
-gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
-                   int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out, int xcd_order) {
+gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
+                   const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
+                   float* __restrict__ out, int xcd_order) {
     const int lane = threadIdx.x & 63;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give
     // each XCD one contiguous range of row tiles - canonical rows are spatial neighbours and gather
@@ -116,16 +131,28 @@ gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict
         for (int rt = 0; rt < RT; ++rt) acc[rt][n] = f32x4{b, b, b, b};
     }
     const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
-    const bool vec = (cg & 3) == 0;
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cg * 4u);
     int rows[RT];
+    bool live[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) rows[rt] = row0 + rt * 16 + r;
+    for (int rt = 0; rt < RT; ++rt) {
+        live[rt] = row0 + rt * 16 + r < n_out;
+        rows[rt] = live[rt] ? row0 + rt * 16 + r : n_out - 1;  // clamped: loads stay unconditional
+    }
 
     auto load_ids = [&](int k, int (&dst)[RT]) {
+        const int kk = k < K ? k : K - 1;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) dst[rt] = (k < K && rows[rt] < n_out) ? nbr[(size_t)k * n_out + rows[rt]] : -1;
+        for (int rt = 0; rt < RT; ++rt) {
+            const int v = nbr[(size_t)kk * n_out + rows[rt]];
+            dst[rt] = (k < K && live[rt]) ? v : -1;
+        }
     };
-    auto mma = [&](int k, const f32x4 (&a)[RT][Q], const bool (&hit)[RT]) {
+    // MASK = compile-time set of row tiles that take part: the wave-uniform "does this tile have a
+    // neighbour at offset k" test is made ONCE per offset (3 specialised bodies for RT = 2), not
+    // around every MFMA, so the matrix instructions issue back to back.
+    auto mma_masked = [&](auto mask_tag, int k, const f32x4 (&a)[RT][Q]) {
+        constexpr unsigned MASK = decltype(mask_tag)::value;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             f32x4 b[NT];
@@ -138,11 +165,22 @@ gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict
                 for (int n = 0; n < NT; ++n) {
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) {
-                        if (hit[rt])
+                        if ((MASK >> rt) & 1u)  // folds after unrolling
                             acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[n][j], acc[rt][n], 0, 0, 0);
                     }
                 }
             }
+        }
+    };
+    auto mma = [&](int k, const f32x4 (&a)[RT][Q], const bool (&hit)[RT]) {
+        if constexpr (RT == 1) {
+            mma_masked(std::integral_constant<unsigned, 1u>{}, k, a);
+        } else if constexpr (RT == 2) {
+            if (hit[0] && hit[1]) mma_masked(std::integral_constant<unsigned, 3u>{}, k, a);
+            else if (hit[0]) mma_masked(std::integral_constant<unsigned, 1u>{}, k, a);
+            else mma_masked(std::integral_constant<unsigned, 2u>{}, k, a);
+        } else {
+            mma_masked(std::integral_constant<unsigned, (1u << RT) - 1u>{}, k, a);  // RT = 4: no per-tile skip
         }
     };
 
@@ -151,10 +189,10 @@ gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict
         f32x4 a0[RT][Q], a1[RT][Q];
         load_ids(0, s0);
         load_ids(1, s1);
-        gather_rows<Q, RT>(in, cg, vec, g, s0, a0);
+        gather_rows<Q, RT, VEC>(in_rsrc, cg, g, s0, a0);
         for (int k = 0; k < K; ++k) {
             load_ids(k + 2, s2);
-            gather_rows<Q, RT>(in, cg, vec, g, s1, a1);  // rows of offset k+1, in flight during the MFMAs below
+            gather_rows<Q, RT, VEC>(in_rsrc, cg, g, s1, a1);  // rows of offset k+1, in flight during the MFMAs below
             bool hit[RT];
             bool any = false;
 #pragma unroll
@@ -184,10 +222,135 @@ gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict
             }
             if (!any) continue;  // wave-uniform skip of an empty offset
             f32x4 a[RT][Q];
-            gather_rows<Q, RT>(in, cg, vec, g, src, a);
+            gather_rows<Q, RT, VEC>(in_rsrc, cg, g, src, a);
             mma(k, a, hit);
         }
     }
+
+    const bool full = cp == 16 * NT;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + rt * 16 + 4 * g + reg;
+            if (row >= n_out) continue;
+            float* dst = out + (size_t)row * cp + NT * r;
+            if (full) {
+                if constexpr (NT == 1) {
+                    dst[0] = acc[rt][0][reg];
+                } else if constexpr (NT == 2) {
+                    *reinterpret_cast<float2*>(dst) = make_float2(acc[rt][0][reg], acc[rt][1][reg]);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NT; n += 4)
+                        *reinterpret_cast<f32x4*>(dst + n) =
+                            f32x4{acc[rt][n][reg], acc[rt][n + 1][reg], acc[rt][n + 2][reg], acc[rt][n + 3][reg]};
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    if (NT * r + n < cp) dst[n] = acc[rt][n][reg];
+            }
+        }
+    }
+}
+
+// LDS-staged variant: the offset's weight slice (Q*NT KiB) is loaded ONCE per workgroup and offset
+// into a double-buffered LDS image and read by the 4 waves with ds_read_b128, instead of every wave
+// streaming it through L1 (4x less vector-memory traffic: with per-wave weight loads the CU's
+// 64 B/clk L1 path, not the MFMA pipe, sets the pace - measured 59 % matrix-pipe utilisation).
+// One barrier per offset; waves still skip the MFMAs of offsets without a neighbour in their rows.
+template <int Q, int NT, int RT, bool VEC>
+__global__ void __launch_bounds__(SC_BLOCK)
+gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
+                       const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
+                       float* __restrict__ out) {
+    constexpr int SLICE = Q * NT * 64;                    // float4 per offset
+    constexpr int PER_THREAD = (SLICE + SC_BLOCK - 1) / SC_BLOCK;
+    __shared__ f32x4 wl[2][SLICE];
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (SC_BLOCK / 64) + (threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = wave * (16 * RT);
+    const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        float b = 0.0f;
+        if (bias && NT * r + n < cp) b = bias[NT * r + n];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][n] = f32x4{b, b, b, b};
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cg * 4u);
+    int rows[RT];
+    bool live[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        live[rt] = row0 + rt * 16 + r < n_out;
+        rows[rt] = live[rt] ? row0 + rt * 16 + r : n_out - 1;
+    }
+
+    // stage offset 0
+#pragma unroll
+    for (int t = 0; t < PER_THREAD; ++t) {
+        const int e = t * SC_BLOCK + threadIdx.x;
+        if (e < SLICE) wl[0][e] = wp4[e];
+    }
+    __syncthreads();
+
+    for (int k = 0; k < K; ++k) {
+        const int cur = k & 1;
+        // next offset's weights: global -> registers now, registers -> LDS after this offset's math
+        f32x4 stage[PER_THREAD];
+        if (k + 1 < K) {
+#pragma unroll
+            for (int t = 0; t < PER_THREAD; ++t) {
+                const int e = t * SC_BLOCK + threadIdx.x;
+                if (e < SLICE) stage[t] = wp4[(size_t)(k + 1) * SLICE + e];
+            }
+        }
+        int src[RT];
+        bool hit[RT];
+        bool any = false;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int v = nbr[(size_t)k * n_out + rows[rt]];
+            src[rt] = live[rt] ? v : -1;
+            hit[rt] = __any(src[rt] >= 0);
+            any = any || hit[rt];
+        }
+        if (any) {
+            f32x4 a[RT][Q];
+            gather_rows<Q, RT, VEC>(in_rsrc, cg, g, src, a);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                f32x4 b[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[n] = wl[cur][(q * NT + n) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) {
+                            if (hit[rt])
+                                acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[n][j], acc[rt][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (k + 1 < K) {
+#pragma unroll
+            for (int t = 0; t < PER_THREAD; ++t) {
+                const int e = t * SC_BLOCK + threadIdx.x;
+                if (e < SLICE) wl[cur ^ 1][e] = stage[t];
+            }
+        }
+        __syncthreads();
+    }
+    if (row0 >= n_out) return;
 
     const bool full = cp == 16 * NT;
 #pragma unroll
@@ -227,7 +390,7 @@ gather_gemm_kernel(const float* __restrict__ in, int cg, const float* __restrict
 // kernel adds the slabs in fixed order: deterministic, no float atomics.
 template <int MTB, int NTB>
 __global__ void __launch_bounds__(SC_BLOCK)
-wgrad_kernel(const float* __restrict__ in, int cin, const float* __restrict__ dout, int cout,
+wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __restrict__ dout, int cout,
              const int* __restrict__ nbr, int n_out, int K, int rows_per_chunk, int MT, int NT, int nsub_n,
              float* __restrict__ slab) {
     constexpr int QCAP = 64 + 16;
@@ -249,51 +412,39 @@ wgrad_kernel(const float* __restrict__ in, int cin, const float* __restrict__ do
 #pragma unroll
         for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // one round: 4 MFMA steps over queue entries [d, d+16); entries >= limit contribute zeros
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cin * 4u);
+    const __amdgpu_buffer_rsrc_t dout_rsrc = table_rsrc(dout, (unsigned)n_out * (unsigned)cout * 4u);
+    // one round: 4 MFMA steps over queue entries [d, d+16); entries >= limit contribute zeros.
+    // Operands come through bounds-checked buffer loads (out-of-range offset -> 0), so there is no
+    // branch around any load and all 8 loads of a round are in flight together.
     auto round16 = [&](int d, int limit) {
         float a[4][MTB], b[4][NTB];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int p = d + 4 * t + g;
             const bool ok = p < limit;
-            const int ip = ok ? qi[p] : 0, op = ok ? qo[p] : 0;
-            const float* pa = in + (size_t)ip * cin + MT * ii + m0;
-            const float* pb = dout + (size_t)op * cout + NT * ii + n0;
+            const int pc = ok ? p : d;  // any valid queue slot
+            const unsigned ia = ((unsigned)qi[pc] * (unsigned)cin + (unsigned)(MT * ii + m0)) * 4u;
+            const unsigned ib = ((unsigned)qo[pc] * (unsigned)cout + (unsigned)(NT * ii + n0)) * 4u;
+            if (exact_a && MTB == 4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? ia : OOB, 0, 0));
 #pragma unroll
-            for (int m = 0; m < MTB; ++m) a[t][m] = 0.f;
+                for (int m = 0; m < MTB; ++m) a[t][m] = v[m];
+            } else {
 #pragma unroll
-            for (int n = 0; n < NTB; ++n) b[t][n] = 0.f;
-            if (ok) {
-                if (exact_a) {
-                    if constexpr (MTB == 4) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(pa);
-                        a[t][0] = v[0]; a[t][1] = v[1]; a[t][2] = v[2]; a[t][3] = v[3];
-                    } else if constexpr (MTB == 2) {
-                        const float2 v = *reinterpret_cast<const float2*>(pa);
-                        a[t][0] = v.x; a[t][1] = v.y;
-                    } else {
-                        a[t][0] = pa[0];
-                    }
-                } else {
+                for (int m = 0; m < MTB; ++m)
+                    a[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                  in_rsrc, (ok && MT * ii + m0 + m < cin) ? ia + 4u * m : OOB, 0, 0));
+            }
+            if (exact_b && NTB == 4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? ib : OOB, 0, 0));
 #pragma unroll
-                    for (int m = 0; m < MTB; ++m)
-                        if (MT * ii + m0 + m < cin) a[t][m] = pa[m];
-                }
-                if (exact_b) {
-                    if constexpr (NTB == 4) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(pb);
-                        b[t][0] = v[0]; b[t][1] = v[1]; b[t][2] = v[2]; b[t][3] = v[3];
-                    } else if constexpr (NTB == 2) {
-                        const float2 v = *reinterpret_cast<const float2*>(pb);
-                        b[t][0] = v.x; b[t][1] = v.y;
-                    } else {
-                        b[t][0] = pb[0];
-                    }
-                } else {
+                for (int n = 0; n < NTB; ++n) b[t][n] = v[n];
+            } else {
 #pragma unroll
-                    for (int n = 0; n < NTB; ++n)
-                        if (NT * ii + n0 + n < cout) b[t][n] = pb[n];
-                }
+                for (int n = 0; n < NTB; ++n)
+                    b[t][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                  dout_rsrc, (ok && NT * ii + n0 + n < cout) ? ib + 4u * n : OOB, 0, 0));
             }
         }
 #pragma unroll
@@ -311,7 +462,8 @@ wgrad_kernel(const float* __restrict__ in, int cin, const float* __restrict__ do
     int qn = 0;  // wave-uniform queue length (< 16 between batches)
     for (int base = row_begin + wv * 64; base < row_end; base += SC_BLOCK) {
         const int o = base + lane;
-        const int i = o < row_end ? nbr[(size_t)k * n_out + o] : -1;
+        const int iv = nbr[(size_t)k * n_out + min(o, n_out - 1)];  // clamped, unconditional
+        const int i = o < row_end ? iv : -1;
         const unsigned long long vote = __ballot(i >= 0);
         if (vote == 0) continue;
         if (i >= 0) {
@@ -422,24 +574,60 @@ extern "C" int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int 
     return TODA_OK;
 }
 
-extern "C" int toda_spconv_gather_gemm(const float* in, int c_gather, const float* wp, const int32_t* nbr, int n_out,
-                                       int k_vol, int c_produce, const float* bias, float* out, void* stream) {
+extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
+                                       int n_out, int k_vol, int c_produce, const float* bias, float* out,
+                                       void* stream) {
     TODA_CHECK_ARG(c_gather >= 1 && c_gather <= 128 && c_produce >= 1 && c_produce <= 128,
                    "gather_gemm: channels must be in [1,128] (gather %d, produce %d)", c_gather, c_produce);
-    TODA_CHECK_ARG(n_out >= 0 && k_vol >= 1, "gather_gemm: bad sizes");
+    TODA_CHECK_ARG(n_out >= 0 && n_in >= 0 && k_vol >= 1, "gather_gemm: bad sizes");
+    TODA_CHECK_ARG((unsigned long long)n_in * c_gather * 4ull < 0xFFFFFFF0ull, "gather_gemm: gathered table must be < 4 GiB");
     if (n_out == 0) return TODA_OK;
+    if (n_in == 0) {  // nothing to gather: bias only
+        TODA_CHECK_ARG(bias == nullptr, "gather_gemm: empty input with bias is unsupported");
+        TODA_HIP(hipMemsetAsync(out, 0, (size_t)n_out * c_produce * sizeof(float), (hipStream_t)stream));
+        return TODA_OK;
+    }
     const int Q = tiles_pow2(c_gather), NT = tiles_pow2(c_produce);
     hipStream_t s = (hipStream_t)stream;
     // tuning knobs for experiments: TODA_GG_RT in {1,2,4} (0 = built-in choice), TODA_GG_PF in {0,1}
     static const int env_rt = getenv("TODA_GG_RT") ? atoi(getenv("TODA_GG_RT")) : 0;
     static const int env_pf = getenv("TODA_GG_PF") ? atoi(getenv("TODA_GG_PF")) : 0;
     static const int env_xcd = getenv("TODA_GG_XCD") ? atoi(getenv("TODA_GG_XCD")) : 0;  // measured 6-8 % slower: z-slabs differ in density, round-robin balances better
+    // weight staging: 1 = auto (LDS-shared slice when it measured faster: Q >= 2 and NT >= Q), 0 = never, 2 = always
+    static const int env_lds_raw = getenv("TODA_GG_LDS") ? atoi(getenv("TODA_GG_LDS")) : 1;
+    const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);
+    const bool vec_ok = (c_gather & 3) == 0;
+    if (env_lds && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
+#define GL(QQ, NN, RR)                                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
+                       dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
+                       k_vol, c_produce, bias, out)
+#define GL_ROW(QQ)                 \
+    switch (NT) {                  \
+        case 1: GL(QQ, 1, 2); break; \
+        case 2: GL(QQ, 2, 2); break; \
+        case 4: GL(QQ, 4, 2); break; \
+        default: GL(QQ, 8, 1); break; \
+    }
+        switch (Q) {
+            case 1: GL_ROW(1); break;
+            case 2: GL_ROW(2); break;
+            case 4: GL_ROW(4); break;
+            default: GL_ROW(8); break;
+        }
+#undef GL_ROW
+#undef GL
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
     int rt_sel = env_rt ? env_rt : (NT >= 8 ? 1 : 2);
     if (NT >= 8 && rt_sel > 2) rt_sel = 2;
     if (Q >= 8 && rt_sel > 2) rt_sel = 2;
 #define GG(QQ, NN, RR, PP)                                                                                            \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP>),                                           \
-                       dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, c_gather, wp, nbr, \
+    GGV(QQ, NN, RR, PP, true)
+#define GGV(QQ, NN, RR, PP, VV)                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP, VV>),                                       \
+                       dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, \
                        n_out, k_vol, c_produce, bias, out, env_xcd)
 #define GG_PF(QQ, NN, RR)        \
     if (env_pf) {                \
@@ -462,6 +650,17 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int c_gather, const floa
         case 4: GG_RT(QQ, 4); break; \
         default: GG_RT(QQ, 8); break; \
     }
+    if (!vec_ok) {  // rows not 16-byte aligned (e.g. 5 point features): dword gathers, plain variant
+        TODA_CHECK_ARG(Q == 1, "gather_gemm: gathered channel counts above 16 must be multiples of 4 (got %d)", c_gather);
+        switch (NT) {
+            case 1: GGV(1, 1, 2, false, false); break;
+            case 2: GGV(1, 2, 2, false, false); break;
+            case 4: GGV(1, 4, 2, false, false); break;
+            default: GGV(1, 8, 1, false, false); break;
+        }
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
     switch (Q) {
         case 1: GG_ROW(1); break;
         case 2: GG_ROW(2); break;
@@ -471,6 +670,7 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int c_gather, const floa
 #undef GG_ROW
 #undef GG_RT
 #undef GG_PF
+#undef GGV
 #undef GG
     TODA_LAUNCH_CHECK();
     return TODA_OK;
@@ -482,13 +682,15 @@ extern "C" size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int ci
     return align_up((size_t)chunks * k_vol * cin * cout * sizeof(float), 256);
 }
 
-extern "C" int toda_spconv_wgrad(const float* in, const float* dout, const int32_t* nbr, int n_out, int k_vol, int cin,
-                                 int cout, float* dw, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, const int32_t* nbr, int n_out, int k_vol,
+                                 int cin, int cout, float* dw, void* ws, size_t ws_bytes, void* stream) {
     TODA_CHECK_ARG(cin >= 1 && cin <= 128 && cout >= 1 && cout <= 128, "wgrad: channels must be in [1,128]");
-    TODA_CHECK_ARG(n_out >= 0 && k_vol >= 1, "wgrad: bad sizes");
+    TODA_CHECK_ARG(n_out >= 0 && n_in >= 0 && k_vol >= 1, "wgrad: bad sizes");
+    TODA_CHECK_ARG((unsigned long long)n_in * cin * 4ull < 0xFFFFFFF0ull && (unsigned long long)n_out * cout * 4ull < 0xFFFFFFF0ull,
+                   "wgrad: feature tables must be < 4 GiB");
     hipStream_t s = (hipStream_t)stream;
     const long long elems = (long long)cout * k_vol * cin;
-    if (n_out == 0) {
+    if (n_out == 0 || n_in == 0) {
         TODA_HIP(hipMemsetAsync(dw, 0, elems * sizeof(float), s));
         return TODA_OK;
     }
@@ -505,7 +707,7 @@ extern "C" int toda_spconv_wgrad(const float* in, const float* dout, const int32
     float* slab = (float*)ws;
     const dim3 grid(chunks, k_vol, nsub_m * nsub_n);
 #define WG(MM, NN)                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN>), grid, dim3(SC_BLOCK), 0, s, in, cin, dout, cout, nbr,   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \
                        n_out, k_vol, rpc, MT, NT, nsub_n, slab)
 #define WG_ROW(MM)             \
     switch (ntb) {             \

@@ -289,8 +289,8 @@ def gather_gemm(feat, wp, nbr, c_produce, bias=None):
     lib = L.load()
     K, n_out = nbr.shape
     out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
-    rc = lib.toda_spconv_gather_gemm(L.ptr(feat), feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce,
-                                     L.ptr(bias), L.ptr(out), L.stream())
+    rc = lib.toda_spconv_gather_gemm(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K,
+                                     c_produce, L.ptr(bias), L.ptr(out), L.stream())
     L.check(rc, "toda_spconv_gather_gemm")
     return out
 
@@ -302,8 +302,8 @@ def wgrad(feat, dout, nbr, wshape):
     dw = torch.empty(wshape, dtype=torch.float32, device=feat.device)
     ws_bytes = lib.toda_spconv_wgrad_workspace_bytes(n_out, K, cin, cout)
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=feat.device)
-    rc = lib.toda_spconv_wgrad(L.ptr(feat), L.ptr(dout), L.ptr(nbr), n_out, K, cin, cout, L.ptr(dw), L.ptr(ws),
-                               ws_bytes, L.stream())
+    rc = lib.toda_spconv_wgrad(L.ptr(feat), feat.shape[0], L.ptr(dout), L.ptr(nbr), n_out, K, cin, cout, L.ptr(dw),
+                               L.ptr(ws), ws_bytes, L.stream())
     L.check(rc, "toda_spconv_wgrad")
     return dw
 

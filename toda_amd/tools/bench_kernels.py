@@ -51,9 +51,9 @@ class Recorder:
     @staticmethod
     def label(name, a):
         if name == "toda_spconv_gather_gemm":
-            return (a[4], a[5], a[1], a[6])          # rows, K, c_gather, c_produce
+            return (a[5], a[6], a[2], a[7])          # rows, K, c_gather, c_produce
         if name == "toda_spconv_wgrad":
-            return (a[3], a[4], a[5], a[6])          # rows, K, cin, cout
+            return (a[4], a[5], a[6], a[7])          # rows, K, cin, cout
         if name in ("toda_rulebook_subm", "toda_rulebook_conv", "toda_gridindex_from_coords", "toda_gridindex_from_conv"):
             return (a[1],)
         if name == "toda_voxelize_hard":

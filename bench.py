@@ -136,7 +136,7 @@ def run_gpu(args, rank, world, device):
     net = model
     if pair:
         model = DistModel(model)
-    if world > 1:
+    if world > 1 or os.environ.get("TODA_FORCE_DDP") == "1":  # the env knob rehearses the DDP path on one GPU
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
     if pair:
         batches = make_device_pair_batches(dataset, per_gpu, args.batches, rank, device)
@@ -296,9 +296,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("TODA_FORCE_DDP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     res = run_gpu(args, rank, world, device)
@@ -322,7 +323,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(res["cfg"])
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -194,6 +194,19 @@ int toda_center_assign(const float* gt_boxes, int batch, int n_gt, int code_size
                        int64_t* inds /*[B, max_objs]*/, int64_t* mask /*[B, max_objs]*/,
                        void* stream);
 
+/* ------------------------------------------------------------------------
+ * Rotated BEV IoU and greedy NMS (pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:236-326 and the host
+ * sweep of iou3d_nms.cpp:100-135, reached through model_nms_utils.class_agnostic_nms from
+ * CenterHead.generate_predicted_boxes, center_head.py:291-300).  Boxes are rows of 7 floats
+ * (x, y, z, dx, dy, dz, heading).  toda_nms_rotated expects the boxes sorted by descending score
+ * and leaves the kept indices (ascending = score order) and their count on the device.
+ * ---------------------------------------------------------------------- */
+int toda_boxes_iou_bev(const float* boxes_a, int na, const float* boxes_b, int nb,
+                       float* iou /*[na, nb]*/, void* stream);
+size_t toda_nms_workspace_bytes(int n);
+int toda_nms_rotated(const float* boxes_sorted, int n, float thresh, int64_t* keep /*[n]*/,
+                     int32_t* n_keep_dev, void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,3 +222,19 @@ def center_assign(gt_boxes, num_classes, fm_w, fm_h, pc_range, voxel_size, fm_st
                                _p(_f32(pc_range)), _p(_f32(voxel_size)), int(fm_stride), int(max_objs),
                                float(overlap), int(min_radius), _p(hm), _p(rb), _p(inds), _p(mask))
     return hm, rb, inds, mask
+
+
+def boxes_iou_bev(boxes_a, boxes_b):
+    a, b = _f32(boxes_a)[:, :7].copy(), _f32(boxes_b)[:, :7].copy()
+    iou = np.empty((len(a), len(b)), np.float32)
+    lib().oracle_boxes_iou_bev(_p(a), len(a), _p(b), len(b), _p(iou))
+    return iou
+
+
+def nms_rotated(boxes_sorted, thresh):
+    """Greedy NMS over boxes already sorted by descending score -> kept indices (int64)."""
+    b = _f32(boxes_sorted)[:, :7].copy()
+    keep = np.empty((len(b),), np.int64)
+    lib().oracle_nms_rotated.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    n = lib().oracle_nms_rotated(_p(b), len(b), float(thresh), _p(keep))
+    return keep[:n].copy()

@@ -535,6 +535,115 @@ void oracle_center_assign(const float* gt, int batch, int n_gt, int code, int nu
     }
 }
 
+
+/* ------------------------------------------------------------- rotated BEV IoU + greedy NMS */
+/* Restates pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:35-250 (box_overlap / iou_bev) and the host
+ * sweep of iou3d_nms.cpp:100-135.  Boxes are (x, y, z, dx, dy, dz, heading); only x, y, dx, dy and
+ * heading matter.  The overlap polygon is assembled from edge-edge intersection points plus the
+ * corners of each box that lie inside the other (with the reference's 1e-2 margin), ordered by
+ * angle around their centroid, and its area is taken as a triangle fan. */
+typedef struct { float x, y; } pt2;
+static inline float cross3(pt2 p1, pt2 p2, pt2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+
+static int seg_intersection(pt2 p1, pt2 p0, pt2 q1, pt2 q0, pt2* ans) {
+    /* bounding-box rejection (kernel.cu:42-48) */
+    if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+          fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+        return 0;
+    float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0; /* proper crossing only (kernel.cu:72) */
+    float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > 1e-8f) {
+        ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        float D = a0 * b1 - a1 * b0;
+        ans->x = (b0 * c1 - b1 * c0) / D;
+        ans->y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+static int in_box2d(const float* box, pt2 p) { /* kernel.cu:50-61, MARGIN 1e-2 */
+    float c = cosf(-box[6]), s_ = sinf(-box[6]);
+    float rx = (p.x - box[0]) * c + (p.y - box[1]) * (-s_);
+    float ry = (p.x - box[0]) * s_ + (p.y - box[1]) * c;
+    return fabsf(rx) < box[3] / 2 + 1e-2f && fabsf(ry) < box[4] / 2 + 1e-2f;
+}
+
+static void box_corners(const float* b, pt2* c) {
+    float hx = b[3] / 2, hy = b[4] / 2, cs = cosf(b[6]), sn = sinf(b[6]);
+    const float lx[4] = {-hx, hx, hx, -hx}, ly[4] = {-hy, -hy, hy, hy};
+    for (int k = 0; k < 4; ++k) {
+        /* rotate_around_center (kernel.cu:94-98) applied to (centre + local) */
+        float px = b[0] + lx[k], py = b[1] + ly[k];
+        c[k].x = (px - b[0]) * cs + (py - b[1]) * (-sn) + b[0];
+        c[k].y = (px - b[0]) * sn + (py - b[1]) * cs + b[1];
+    }
+    c[4] = c[0];
+}
+
+float oracle_box_overlap(const float* a, const float* b) {
+    pt2 ca[5], cb[5], pts[16], centre = {0, 0};
+    int cnt = 0;
+    box_corners(a, ca);
+    box_corners(b, cb);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (seg_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], &pts[cnt])) {
+                centre.x += pts[cnt].x;
+                centre.y += pts[cnt].y;
+                cnt++;
+            }
+    for (int k = 0; k < 4; ++k) {
+        if (in_box2d(a, cb[k])) { centre.x += cb[k].x; centre.y += cb[k].y; pts[cnt++] = cb[k]; }
+        if (in_box2d(b, ca[k])) { centre.x += ca[k].x; centre.y += ca[k].y; pts[cnt++] = ca[k]; }
+    }
+    if (cnt == 0) return 0.0f;
+    centre.x /= cnt;
+    centre.y /= cnt;
+    for (int j = 0; j < cnt - 1; ++j) /* bubble sort by polar angle (kernel.cu:198-207) */
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (atan2f(pts[i].y - centre.y, pts[i].x - centre.x) > atan2f(pts[i + 1].y - centre.y, pts[i + 1].x - centre.x)) {
+                pt2 t = pts[i];
+                pts[i] = pts[i + 1];
+                pts[i + 1] = t;
+            }
+    float area = 0;
+    for (int k = 0; k < cnt - 1; ++k) {
+        pt2 u = {pts[k].x - pts[0].x, pts[k].y - pts[0].y}, v = {pts[k + 1].x - pts[0].x, pts[k + 1].y - pts[0].y};
+        area += u.x * v.y - u.y * v.x;
+    }
+    return fabsf(area) / 2.0f;
+}
+
+float oracle_iou_bev(const float* a, const float* b) {
+    float sa = a[3] * a[4], sb = b[3] * b[4], so = oracle_box_overlap(a, b);
+    return so / fmaxf(sa + sb - so, 1e-8f);
+}
+
+void oracle_boxes_iou_bev(const float* a, int na, const float* b, int nb, float* iou) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) iou[(size_t)i * nb + j] = oracle_iou_bev(a + 7 * i, b + 7 * j);
+}
+
+/* boxes already sorted by descending score; keep[] receives the kept indices; returns their count */
+int oracle_nms_rotated(const float* boxes, int n, float thresh, int64_t* keep) {
+    unsigned char* dead = (unsigned char*)calloc((size_t)n + 1, 1);
+    int kept = 0;
+    for (int i = 0; i < n; ++i) {
+        if (dead[i]) continue;
+        keep[kept++] = i;
+        for (int j = i + 1; j < n; ++j)
+            if (!dead[j] && oracle_iou_bev(boxes + 7 * i, boxes + 7 * j) > thresh) dead[j] = 1;
+    }
+    free(dead);
+    return kept;
+}
+
 int oracle_abi_version(void) { return 1; }
 
 /* number of OpenMP threads the oracle uses (the cpu_baseline leg states it as `cores`) */

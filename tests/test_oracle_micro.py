@@ -92,3 +92,28 @@ def test_sparse_to_dense_channel_fold():
     assert d.sum() == 12
     g = O.sparse_to_dense_bwd(d, idx, [2, 1, 3])
     assert g.tolist() == [[5.0, 7.0]]
+
+
+def test_rotated_iou_hand_cases():
+    a = np.array([[0, 0, 0, 4, 2, 1, 0], [0, 0, 0, 2, 2, 1, 0]], np.float32)
+    b = np.array([[0, 0, 0, 4, 2, 1, 0],            # identical to a0 -> 1
+                  [2, 0, 0, 4, 2, 1, 0],            # shifted by half its length: 4 / (8 + 8 - 4)
+                  [0, 0, 0, 2, 2, 1, np.pi / 4],    # square vs itself turned 45 deg: octagon 8(sqrt2-1)
+                  [0, 0, 0, 2, 4, 1, np.pi / 2],    # 2x4 turned 90 deg == 4x2
+                  [9, 9, 0, 1, 1, 1, 0.3]], np.float32)
+    iou = O.boxes_iou_bev(a, b)
+    oct_area = 8 * (np.sqrt(2) - 1)
+    assert np.allclose(iou[0], [1.0, 1 / 3, iou[0, 2], 1.0, 0.0], atol=1e-5)
+    assert np.allclose(iou[1, 2], oct_area / (8 - oct_area), atol=1e-4)
+    assert np.allclose(iou[1, 0], 0.5, atol=1e-5) and iou[1, 4] == 0.0
+
+
+def test_nms_greedy_order():
+    boxes = np.array([[0, 0, 0, 4, 2, 1, 0],        # kept
+                      [0.2, 0, 0, 4, 2, 1, 0.05],   # suppressed by 0
+                      [10, 0, 0, 4, 2, 1, 0],       # kept
+                      [10, 0.1, 0, 4, 2, 1, 0],     # suppressed by 2
+                      [0, 5, 0, 4, 2, 1, 1.0]], np.float32)
+    assert O.nms_rotated(boxes, 0.5).tolist() == [0, 2, 4]
+    assert O.nms_rotated(boxes, 0.99).tolist() == [0, 1, 2, 3, 4]
+    assert O.nms_rotated(boxes[:0], 0.5).tolist() == []

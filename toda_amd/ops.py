@@ -501,3 +501,27 @@ def center_assign(gt_boxes, num_classes, fm_w, fm_h, pc_range, voxel_size, fm_st
                                 L.ptr(rb), L.ptr(inds), L.ptr(mask), L.stream())
     L.check(rc, "toda_center_assign")
     return hm, rb, inds, mask
+
+
+# ------------------------------------------------------------------ rotated IoU / NMS (eval path)
+def boxes_iou_bev(boxes_a, boxes_b):
+    a, b = boxes_a[:, :7].contiguous().float(), boxes_b[:, :7].contiguous().float()
+    iou = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    L.check(L.load().toda_boxes_iou_bev(L.ptr(a), a.shape[0], L.ptr(b), b.shape[0], L.ptr(iou), L.stream()),
+            "toda_boxes_iou_bev")
+    return iou
+
+
+def nms_rotated(boxes_sorted, thresh):
+    """Greedy rotated NMS over boxes sorted by descending score.  Returns (keep [n] int64 padded,
+    n_keep [1] int32), both on the device - no host sync."""
+    lib = L.load()
+    b = boxes_sorted[:, :7].contiguous().float()
+    n = b.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=b.device)
+    n_keep = torch.zeros((1,), dtype=torch.int32, device=b.device)
+    ws_bytes = lib.toda_nms_workspace_bytes(n)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=b.device)
+    rc = lib.toda_nms_rotated(L.ptr(b), n, float(thresh), L.ptr(keep), L.ptr(n_keep), L.ptr(ws), ws_bytes, L.stream())
+    L.check(rc, "toda_nms_rotated")
+    return keep, n_keep

@@ -38,6 +38,8 @@ WORKLOADS = {
     # name: (yaml, samples per GPU, description)
     "c3": ("toda_amd/tools/cfgs/models/centerpoint_voxel_waymo.yaml", 2,
            "CenterPoint-Voxel fwd+bwd+optimizer, synthetic 180k-pt Waymo-shape clouds, bs 2 per GPU"),
+    "c2": ("toda_amd/tools/cfgs/models/second_backbone_nuscenes.yaml", 4,
+           "SECOND-style VoxelBackBone8x forward only (voxelize+MeanVFE+backbone+dense BEV), 60k-pt nuScenes-shape clouds, bs 4"),
     "c5": ("toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml", 2,
            "TODA stage-1 CenterPoint (VoxelResBackBone8x), mixed 180k/35k-pt clouds, bs 2 per GPU"),
     "c5cl": ("toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml", 2,
@@ -147,7 +149,16 @@ def run_gpu(args, rank, world, device):
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
     timer = KernelTimer()
 
+    fwd_only = args.workload == "c2"
+
     def step(it):
+        if fwd_only:  # BASELINE config 2: inference through the sparse backbone only
+            with torch.no_grad():
+                batch = dict(batches[it % len(batches)])
+                voxelize_on_gpu(batch, dataset.voxel_cfg)
+                for m in (net.vfe, net.backbone_3d, net.map_to_bev_module):
+                    batch = m(batch)
+            return batch["spatial_features"].sum()
         scheduler.step(it)
         optimizer.zero_grad()
         if pair:
@@ -311,12 +322,12 @@ def main():
             for r in rows:
                 print(json.dumps(r), file=sys.stderr)
         line = {
-            "metric": "LiDAR training samples/sec", "value": round(total_samples / res["elapsed"], 3),
+            "metric": "LiDAR training samples/sec" if args.workload != "c2" else "LiDAR backbone forward samples/sec", "value": round(total_samples / res["elapsed"], 3),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(res["elapsed"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": res["desc"], "global_batch": per_gpu * world,
-                       "points_per_cloud": 180000 if args.workload == "c3" else "180000/35000 alternating",
+                       "points_per_cloud": {"c3": 180000, "c2": 60000}.get(args.workload, "180000/35000 alternating"),
                        "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4)},
             "roofline": roof,
         }

@@ -602,11 +602,19 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
                        k_vol, c_produce, bias, out)
+#define GL_RT(QQ, NN)                          \
+    if (env_rt == 4 && QQ <= 4 && NN <= 4) {   \
+        GL(QQ, NN, 4);                         \
+    } else if (env_rt == 1) {                  \
+        GL(QQ, NN, 1);                         \
+    } else {                                   \
+        GL(QQ, NN, 2);                         \
+    }
 #define GL_ROW(QQ)                 \
     switch (NT) {                  \
-        case 1: GL(QQ, 1, 2); break; \
-        case 2: GL(QQ, 2, 2); break; \
-        case 4: GL(QQ, 4, 2); break; \
+        case 1: GL_RT(QQ, 1); break; \
+        case 2: GL_RT(QQ, 2); break; \
+        case 4: GL_RT(QQ, 4); break; \
         default: GL(QQ, 8, 1); break; \
     }
         switch (Q) {
@@ -616,6 +624,7 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
             default: GL_ROW(8); break;
         }
 #undef GL_ROW
+#undef GL_RT
 #undef GL
         TODA_LAUNCH_CHECK();
         return TODA_OK;

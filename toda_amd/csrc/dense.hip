@@ -136,25 +136,27 @@ rows_moments_kernel(const float* __restrict__ x, int n, int c, double* __restric
     }, sums);
 }
 
+// Elementwise passes over [n, c] rows: the grid stride (gridDim * 256 float4) is a multiple of c/4,
+// so a thread meets the same 4 channels in every iteration and keeps their coefficients in
+// registers instead of re-loading per-channel vectors for every element.
+constexpr int EW_BLOCKS = 2048;
+
 __global__ void __launch_bounds__(DN_BLOCK)
 rows_affine_act_kernel(const f32x4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                        const f32x4* __restrict__ res, long long n4, int c, int relu, f32x4* __restrict__ y) {
-    const long long t = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
-    if (t >= n4) return;
-    const int ch = (int)((t * 4) % c);
-    f32x4 v = x[t];
+    const long long t0 = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
+    const long long stride = (long long)gridDim.x * DN_BLOCK;
+    const int ch = (int)((t0 * 4) % c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ch), sf = *reinterpret_cast<const f32x4*>(shift + ch);
+    for (long long t = t0; t < n4; t += stride) {
+        f32x4 v = x[t] * sc + sf;
+        if (res) v += res[t];
+        if (relu) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = v[j] * scale[ch + j] + shift[ch + j];
-    if (res) {
-        const f32x4 rr = res[t];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        y[t] = v;
     }
-    if (relu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-    }
-    y[t] = v;
 }
 
 // BatchNorm1d(+ReLU) backward over sparse rows, pass 1: per-channel sums of dz and dz*xhat where
@@ -182,26 +184,37 @@ rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict_
     }, sums);
 }
 
-// pass 2: dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))
+// pass 2: dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) = k1 * (dz - m1 - (x - mu) * k2)
 __global__ void __launch_bounds__(DN_BLOCK)
 rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x, const float* __restrict__ stats,
                          const float* __restrict__ gamma, const double* __restrict__ sums, long long n4, int c, int n,
                          int relu, f32x4* __restrict__ dx) {
-    const long long t = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
-    if (t >= n4) return;
-    const int ch = (int)((t * 4) % c);
-    const f32x4 g = dy[t], xv = x[t];
-    f32x4 out;
+    const long long t0 = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
+    const long long stride = (long long)gridDim.x * DN_BLOCK;
+    const int ch = (int)((t0 * 4) % c);
     const float inv_n = 1.0f / (float)n;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(stats + ch);
+    const f32x4 is = *reinterpret_cast<const f32x4*>(stats + c + ch);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(stats + 2 * c + ch);
+    const f32x4 sf = *reinterpret_cast<const f32x4*>(stats + 3 * c + ch);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + ch);
+    f32x4 m1, m2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float mu = stats[ch + j], is = stats[c + ch + j];
-        const float xh = (xv[j] - mu) * is;
-        const float dz = (relu && !(xv[j] * stats[2 * c + ch + j] + stats[3 * c + ch + j] > 0.f)) ? 0.f : g[j];
-        const float m1 = (float)sums[ch + j] * inv_n, m2 = (float)sums[c + ch + j] * inv_n;
-        out[j] = gamma[ch + j] * is * (dz - m1 - xh * m2);
+        m1[j] = (float)(sums[ch + j] * (double)inv_n);
+        m2[j] = (float)(sums[c + ch + j] * (double)inv_n);
     }
-    dx[t] = out;
+    const f32x4 k1 = ga * is, k2 = is * m2;  // xhat * m2 = (x - mu) * (is * m2)
+    for (long long t = t0; t < n4; t += stride) {
+        const f32x4 g = dy[t], xv = x[t];
+        f32x4 out;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dz = (relu && !(xv[j] * sc[j] + sf[j] > 0.f)) ? 0.f : g[j];
+            out[j] = k1[j] * (dz - m1[j] - (xv[j] - mu[j]) * k2[j]);
+        }
+        dx[t] = out;
+    }
 }
 
 // one block: batch statistics -> (mean, invstd, scale, shift) + running-stat update, exactly
@@ -236,6 +249,15 @@ bn_finalize_kernel(const double* __restrict__ sums, int n, int c, const float* _
     invstd_out[ch] = invstd;
     scale_out[ch] = g * invstd;
     shift_out[ch] = b - mean * g * invstd;
+}
+
+// grid for the grid-stride elementwise kernels: <= EW_BLOCKS blocks and (blocks * 256 * 4) % c == 0
+static int ew_grid(long long n4, int c) {
+    long long blocks = (n4 + DN_BLOCK - 1) / DN_BLOCK;
+    if (blocks > EW_BLOCKS) blocks = EW_BLOCKS;
+    // 256 * 4 = 1024 floats per block; c divides 1024 for c in {4,...,256 powers of two}; otherwise round up
+    while ((blocks * DN_BLOCK * 4) % c != 0) ++blocks;
+    return (int)blocks;
 }
 
 static int scatter_common(bool fwd, float* feat, const int32_t* idx, int n, int c, int batch, DenseGeom g,
@@ -293,10 +315,10 @@ extern "C" int toda_rows_moments(const float* x, int n, int c, double* sums, voi
 
 extern "C" int toda_rows_affine_act(const float* x, const float* scale, const float* shift, const float* residual,
                                     int n, int c, int relu, float* y, void* stream) {
-    TODA_CHECK_ARG(c >= 4 && c % 4 == 0, "rows_affine_act: channels must be a multiple of 4 (got %d)", c);
+    TODA_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= 1024, "rows_affine_act: channels must be a multiple of 4, <= 1024 (got %d)", c);
     if (n <= 0) return TODA_OK;
     const long long n4 = (long long)n * c / 4;
-    hipLaunchKernelGGL(rows_affine_act_kernel, dim3(cdiv(n4, DN_BLOCK)), dim3(DN_BLOCK), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(rows_affine_act_kernel, dim3(ew_grid(n4, c)), dim3(DN_BLOCK), 0, (hipStream_t)stream,
                        (const f32x4*)x, scale, shift, (const f32x4*)residual, n4, c, relu, (f32x4*)y);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
@@ -312,7 +334,7 @@ extern "C" int toda_rows_bn_bwd(const float* dy, const float* x, const float* st
     hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(cdiv(n, MOM_ROWS)), dim3(DN_BLOCK), 0, s, dy, x, stats, n, c, relu,
                        sums);
     const long long n4 = (long long)n * c / 4;
-    hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3(cdiv(n4, DN_BLOCK)), dim3(DN_BLOCK), 0, s, (const f32x4*)dy,
+    hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3(ew_grid(n4, c)), dim3(DN_BLOCK), 0, s, (const f32x4*)dy,
                        (const f32x4*)x, stats, gamma, sums, n4, c, n, relu, (f32x4*)dx);
     TODA_LAUNCH_CHECK();
     return TODA_OK;

@@ -308,6 +308,19 @@ def wgrad(feat, dout, nbr, wshape):
     return dw
 
 
+import os as _os
+
+WGRAD_ON_SIDE_STREAM = _os.environ.get("TODA_WGRAD_STREAM", "0") == "1"  # measured: no gain (each kernel already fills the chip)
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _SparseConv(torch.autograd.Function):
     """out = conv(features; weight, bias, rulebook).  Backward = dgrad (same gather-GEMM kernel on
     the transposed table and transposed packed weights) + wgrad, as autograd does through spconv
@@ -330,13 +343,28 @@ class _SparseConv(torch.autograd.Function):
         rb = ctx.rb
         gout = gout.contiguous()
         gfeat = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        need_d, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        side = _side_stream(gout.device) if (need_d and need_w and WGRAD_ON_SIDE_STREAM) else None
+        if side is not None:
+            # dgrad and wgrad only share their inputs: run wgrad on a second HIP stream so that the two
+            # MFMA-bound kernels (each ~60 % matrix-pipe utilisation on its own) fill each other's gaps
+            main = torch.cuda.current_stream(gout.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gw = wgrad(features, gout, rb.nbr_fwd, tuple(weight.shape))
+            for t in (features, gout, rb.nbr_fwd):
+                t.record_stream(side)
+            need_w = False
+        if need_d:
             wp_t = pack_weight(weight, True, rb.flip_bwd)
             gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None)
-        if ctx.needs_input_grad[1]:
+        if need_w:
             gw = wgrad(features, gout, rb.nbr_fwd, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gout.sum(0)
+        if side is not None:
+            torch.cuda.current_stream(gout.device).wait_stream(side)
+            gw.record_stream(torch.cuda.current_stream(gout.device))
         return gfeat, gw, gb, None, None
 
 

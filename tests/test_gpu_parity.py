@@ -424,3 +424,98 @@ def test_centerpoint_eval_forward_decodes_and_suppresses():
             iou.fill_diagonal_(0)
             assert float(iou.max()) <= thr + 1e-4
         assert set(p["pred_labels"].unique().tolist()) <= {1, 2, 3}
+
+
+def test_full_size_waymo_cloud_properties():
+    """BASELINE config 3 at FULL size (180k points, cap 150k voxels, grid 1504x1504x40, bs 2): properties
+    that hold independently of an oracle run - voxel invariants, rulebook symmetry and counts, strided
+    output sets in canonical order, dense round trip, conv linearity / bias / identity-stencil checks."""
+    import os
+    from toda_amd import ops
+    from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(root, "toda_amd/tools/cfgs/models/centerpoint_voxel_waymo.yaml"), cfg)
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    vc = ds.voxel_cfg
+    clouds = [torch.from_numpy(ds[i]["points"]).cuda() for i in range(2)]
+    vox, coords, num = ops.voxelize_batch(clouds, vc["point_cloud_range"], vc["voxel_size"], vc["max_points_per_voxel"],
+                                          vc["max_num_voxels"])
+    P, cap = vc["max_points_per_voxel"], vc["max_num_voxels"]
+    per = torch.bincount(coords[:, 0].long(), minlength=2)
+    assert int(per.max()) <= cap and int(per.min()) > 100000
+    assert int(num.min()) >= 1 and int(num.max()) <= P
+    # unique cells, all inside the grid
+    gx, gy, gz = (int(v) for v in ds.grid_size)
+    lin = ((coords[:, 0].long() * gz + coords[:, 1]) * gy + coords[:, 2]) * gx + coords[:, 3]
+    assert lin.unique().numel() == lin.numel()
+    assert bool(((coords[:, 1] >= 0) & (coords[:, 1] < gz) & (coords[:, 2] < gy) & (coords[:, 3] < gx)).all())
+    # slots beyond num_points are zero, filled slots are real points of that cell
+    slot = torch.arange(P, device="cuda")[None, :]
+    pad = slot >= num[:, None]
+    assert float(vox[pad].abs().max()) == 0.0
+    r0 = torch.tensor(vc["point_cloud_range"][:3], device="cuda")
+    vs = torch.tensor(vc["voxel_size"], device="cuda")
+    cell = torch.floor((vox[..., :3] - r0) / vs).int()              # (x, y, z) cell of every stored point
+    want = coords[:, [3, 2, 1]][:, None, :].expand(-1, P, -1)
+    assert bool((cell == want)[~pad].all())
+    # first-appearance order: the first stored point of voxel v precedes that of voxel v+1 in the cloud
+    b0 = coords[:, 0] == 0
+    first_pts = vox[b0][:, 0, :]
+    cloud0 = clouds[0]
+    key = (cloud0[:, 0].double() * 1e6 + cloud0[:, 1].double()) * 1e6 + cloud0[:, 2].double()
+    order = {float(k): i for i, k in reversed(list(enumerate(key[:20000].tolist())))}
+    fk = ((first_pts[:, 0].double() * 1e6 + first_pts[:, 1].double()) * 1e6 + first_pts[:, 2].double())[:2000].tolist()
+    pos = [order[k] for k in fk if k in order]
+    assert len(pos) > 1500 and pos == sorted(pos)
+
+    feats = ops.mean_vfe(vox, num)
+    shape = [gz + 1, gy, gx]
+    steps = [{"kind": "subm", "key": "subm1", "ksize": [3, 3, 3], "dilation": [1, 1, 1]},
+             {"kind": "conv", "key": "spconv2", "ksize": [3, 3, 3], "stride": [2, 2, 2], "padding": [1, 1, 1]},
+             {"kind": "subm", "key": "subm2", "ksize": [3, 3, 3], "dilation": [1, 1, 1]}]
+    plan = ops.build_index_plan(coords, 2, shape, steps)
+    rb1, rb2, rbs = plan["subm1"]["rb"], plan["subm2"]["rb"], plan["spconv2"]
+    n0 = coords.shape[0]
+    # SubM: centre tap is the identity, table is point symmetric, counts agree
+    assert torch.equal(rb1.nbr_fwd[13], torch.arange(n0, device="cuda", dtype=torch.int32))
+    for k in (0, 4, 9, 12):
+        v = rb1.nbr_fwd[k] >= 0
+        assert torch.equal(rb1.nbr_fwd[26 - k][rb1.nbr_fwd[k][v].long()], torch.arange(n0, device="cuda", dtype=torch.int32)[v])
+    assert torch.equal(rb1.pair_cnt, (rb1.nbr_fwd >= 0).sum(1).int())
+    assert torch.equal(rb1.pair_cnt, rb1.pair_cnt.flip(0))
+    # strided set: canonical ascending order, every input reaches >= 1 output, o2i / i2o are inverse
+    oi, osh = rbs["out_indices"], rbs["out_shape"]
+    olin = ((oi[:, 0].long() * osh[0] + oi[:, 1]) * osh[1] + oi[:, 2]) * osh[2] + oi[:, 3]
+    assert bool((olin[1:] > olin[:-1]).all())
+    assert bool((rbs["rb"].nbr_bwd >= 0).any(0).all())
+    k = 13
+    v = rbs["rb"].nbr_fwd[k] >= 0
+    assert torch.equal(rbs["rb"].nbr_bwd[k][rbs["rb"].nbr_fwd[k][v].long()],
+                       torch.arange(oi.shape[0], device="cuda", dtype=torch.int32)[v])
+    assert int(rbs["rb"].pair_cnt.sum()) == int((rbs["rb"].nbr_bwd >= 0).sum())
+
+    # conv arithmetic at full size
+    rng = torch.Generator(device="cuda").manual_seed(0)
+    w = torch.randn((16, 3, 3, 3, 5), device="cuda", generator=rng) * 0.1
+    y = ops.sparse_conv(feats, w, None, rb1)
+    y2 = ops.sparse_conv(2.5 * feats, w, None, rb1)
+    assert torch.allclose(y2, 2.5 * y, rtol=1e-4, atol=1e-3)  # features are raw metres (|x| <= 75): fp32 rounding of the partial sums
+    bias = torch.randn(16, device="cuda", generator=rng)
+    assert torch.allclose(ops.sparse_conv(feats, w, bias, rb1), y + bias, rtol=1e-4, atol=1e-3)
+    w_id = torch.zeros_like(w)
+    w_id[:5, 1, 1, 1, :] = torch.eye(5, device="cuda")          # centre tap = identity on 5 channels
+    y_id = ops.sparse_conv(feats, w_id, None, rb1)
+    assert torch.equal(y_id[:, :5], feats) and float(y_id[:, 5:].abs().max()) == 0.0
+    w_ones = torch.ones((16, 3, 3, 3, 1), device="cuda")
+    cnt = ops.sparse_conv(torch.ones((n0, 1), device="cuda"), w_ones, None, rb1)   # counts active neighbours
+    assert torch.equal(cnt[:, 0].int(), (rb1.nbr_fwd >= 0).sum(0).int())
+    # dense round trip on the stride-2 level
+    f2 = torch.randn((oi.shape[0], 32), device="cuda", generator=rng)
+    dense = ops.sparse_to_dense(f2, oi, 2, osh)
+    assert float(dense.abs().sum()) > 0 and int((dense != 0).sum()) == int((f2 != 0).sum())
+    back = dense[oi[:, 0].long(), :, oi[:, 1].long(), oi[:, 2].long(), oi[:, 3].long()]
+    assert torch.equal(back, f2)
+    assert rb2.n_out == oi.shape[0]

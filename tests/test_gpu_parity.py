@@ -137,7 +137,7 @@ def test_rulebook_conv_bit_exact(ks, st, pd):
     assert np.array_equal(rb2.pair_cnt.cpu().numpy(), cnt1)
 
 
-CHANNELS = [(5, 16), (4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (24, 48)]
+CHANNELS = [(5, 16), (4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 64), (24, 48)]
 
 
 @pytest.mark.parametrize("cin,cout", CHANNELS)

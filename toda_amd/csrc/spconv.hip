@@ -260,14 +260,14 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
 // streaming it through L1 (4x less vector-memory traffic: with per-wave weight loads the CU's
 // 64 B/clk L1 path, not the MFMA pipe, sets the pace - measured 59 % matrix-pipe utilisation).
 // One barrier per offset; waves still skip the MFMAs of offsets without a neighbour in their rows.
-template <int Q, int NT, int RT, bool VEC>
+template <int Q, int NT, int RT, bool VEC, bool DB = true>
 __global__ void __launch_bounds__(SC_BLOCK)
 gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                        const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
                        float* __restrict__ out) {
     constexpr int SLICE = Q * NT * 64;                    // float4 per offset
     constexpr int PER_THREAD = (SLICE + SC_BLOCK - 1) / SC_BLOCK;
-    __shared__ f32x4 wl[2][SLICE];
+    __shared__ f32x4 wl[DB ? 2 : 1][SLICE];  // DB = false: one 64 KiB buffer (128-channel layers), two barriers per offset
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (SC_BLOCK / 64) + (threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -300,7 +300,7 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
     __syncthreads();
 
     for (int k = 0; k < K; ++k) {
-        const int cur = k & 1;
+        const int cur = DB ? (k & 1) : 0;
         // next offset's weights: global -> registers now, registers -> LDS after this offset's math
         f32x4 stage[PER_THREAD];
         if (k + 1 < K) {
@@ -341,11 +341,12 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
                 }
             }
         }
+        if (!DB) __syncthreads();  // everyone is done reading the single buffer
         if (k + 1 < K) {
 #pragma unroll
             for (int t = 0; t < PER_THREAD; ++t) {
                 const int e = t * SC_BLOCK + threadIdx.x;
-                if (e < SLICE) wl[cur ^ 1][e] = stage[t];
+                if (e < SLICE) wl[DB ? (cur ^ 1) : 0][e] = stage[t];
             }
         }
         __syncthreads();
@@ -426,20 +427,26 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
             const int pc = ok ? p : d;  // any valid queue slot
             const unsigned ia = ((unsigned)qi[pc] * (unsigned)cin + (unsigned)(MT * ii + m0)) * 4u;
             const unsigned ib = ((unsigned)qo[pc] * (unsigned)cout + (unsigned)(NT * ii + n0)) * 4u;
-            if (exact_a && MTB == 4) {
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? ia : OOB, 0, 0));
+            if (exact_a && MTB % 4 == 0) {
 #pragma unroll
-                for (int m = 0; m < MTB; ++m) a[t][m] = v[m];
+                for (int m4 = 0; m4 < MTB; m4 += 4) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? ia + 4u * m4 : OOB, 0, 0));
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[t][m4 + m] = v[m];
+                }
             } else {
 #pragma unroll
                 for (int m = 0; m < MTB; ++m)
                     a[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                   in_rsrc, (ok && MT * ii + m0 + m < cin) ? ia + 4u * m : OOB, 0, 0));
             }
-            if (exact_b && NTB == 4) {
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? ib : OOB, 0, 0));
+            if (exact_b && NTB % 4 == 0) {
 #pragma unroll
-                for (int n = 0; n < NTB; ++n) b[t][n] = v[n];
+                for (int n4 = 0; n4 < NTB; n4 += 4) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? ib + 4u * n4 : OOB, 0, 0));
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) b[t][n4 + n] = v[n];
+                }
             } else {
 #pragma unroll
                 for (int n = 0; n < NTB; ++n)
@@ -597,6 +604,17 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
     static const int env_lds_raw = getenv("TODA_GG_LDS") ? atoi(getenv("TODA_GG_LDS")) : 1;
     const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);
     const bool vec_ok = (c_gather & 3) == 0;
+    static const int env_lds88 = getenv("TODA_GG_LDS88") ? atoi(getenv("TODA_GG_LDS88")) : 1;  // 1: RT=1 single-buffer LDS (0.67 ms), 2: RT=2 (0.76), 0: registers-only RT=2 (0.70) on 97.5k x 27 x 128 x 128
+    if (env_lds88 && vec_ok && Q == 8 && NT == 8) {
+        if (env_lds88 == 2)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)),
+                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
+                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
     if (env_lds && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
 #define GL(QQ, NN, RR)                                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
@@ -629,7 +647,7 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
-    int rt_sel = env_rt ? env_rt : (NT >= 8 ? 1 : 2);
+    int rt_sel = env_rt ? env_rt : ((NT >= 8 && Q < 8) ? 1 : 2);  // 128->128: RT = 2 measured 16 % faster than 1
     if (NT >= 8 && rt_sel > 2) rt_sel = 2;
     if (Q >= 8 && rt_sel > 2) rt_sel = 2;
 #define GG(QQ, NN, RR, PP)                                                                                            \
@@ -711,7 +729,10 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
         return TODA_EWORKSPACE;
     }
     const int MT = tiles_pow2(cin), NT = tiles_pow2(cout);
-    const int mtb = MT < 4 ? MT : 4, ntb = NT < 4 ? NT : 4;
+    static const int env_sub = getenv("TODA_WG_SUB") ? atoi(getenv("TODA_WG_SUB")) : 3;  // 128-channel sides take 8 tiles per block: 1.08 -> 0.76 ms on 97.5k x 27 x 128 x 128
+    int mtb = MT < 4 ? MT : 4, ntb = NT < 4 ? NT : 4;
+    if (MT == 8 && (env_sub & 1)) mtb = 8;
+    if (NT == 8 && (env_sub & 2)) ntb = 8;
     const int nsub_m = MT / mtb, nsub_n = NT / ntb;
     float* slab = (float*)ws;
     const dim3 grid(chunks, k_vol, nsub_m * nsub_n);
@@ -722,12 +743,14 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
     switch (ntb) {             \
         case 1: WG(MM, 1); break; \
         case 2: WG(MM, 2); break; \
-        default: WG(MM, 4); break; \
+        case 4: WG(MM, 4); break; \
+        default: WG(MM, 8); break; \
     }
     switch (mtb) {
         case 1: WG_ROW(1); break;
         case 2: WG_ROW(2); break;
-        default: WG_ROW(4); break;
+        case 4: WG_ROW(4); break;
+        default: WG_ROW(8); break;
     }
 #undef WG_ROW
 #undef WG

@@ -207,6 +207,48 @@ size_t toda_nms_workspace_bytes(int n);
 int toda_nms_rotated(const float* boxes_sorted, int n, float thresh, int64_t* keep /*[n]*/,
                      int32_t* n_keep_dev, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Point-table primitives of the TODA mixing processors and the data processor's range mask.
+ * They replace, on the device, the numpy / single-thread C++ work the reference does per scene in
+ * DataLoader workers:
+ *   - roiaware_pool3d_utils.points_in_boxes_cpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168),
+ *     box_utils.remove_points_in_boxes3d (pcdet/utils/box_utils.py:75-89), augmentor_utils.get_points_in_box
+ *     (pcdet/datasets/augmentor/augmentor_utils.py:474-491)                       -> toda_points_in_boxes
+ *   - the azimuth-sector test of PolarMix swap (inter_domain_point_polarmix.py:76-98) -> toda_points_sector
+ *   - the crop test of CutMix (inter_domain_point_cutmix.py:44-54) and mask_points_by_range
+ *     (pcdet/utils/common_utils.py:60-63)                                         -> toda_points_rect
+ *   - the cylinder cells of LaserMix (inter_domain_point_lasermix.py:89-165)       -> toda_points_polar_cell
+ *   - boolean-mask indexing / np.delete / np.concatenate of point arrays           -> toda_rows_select_append
+ *   - rotate_copy's point rotation (inter_domain_point_polarmix.py:160-188)        -> toda_points_rotate_z
+ * points: [n, c] fp32 rows (x, y, z, ...).  n_dev (nullable): device int32, rows = min(n, *n_dev), so
+ * chains run without host syncs.  flags / cells are int32 per row.
+ * ---------------------------------------------------------------------- */
+/* flags[j] = 1 iff some box (rows of box_stride >= 7 floats: x y z dx dy dz heading) contains point j.
+ * mode 0: roiaware test (margin 1e-2, strict), mode 1: get_points_in_box test (margin 1e-1, inclusive). */
+int toda_points_in_boxes(const float* points, int n, const int32_t* n_dev, int c, const float* boxes,
+                         int k, int box_stride, int mode, int32_t* flags, void* stream);
+/* flags[j] = lo < -atan2(y, x) < hi   (yaw as an fp32 value, compared in fp64) */
+int toda_points_sector(const float* points, int n, const int32_t* n_dev, int c, double lo, double hi,
+                       int32_t* flags, void* stream);
+/* closed == 0: lo < (x, y) < hi;  closed == 1: lo <= (x, y) <= hi */
+int toda_points_rect(const float* points, int n, const int32_t* n_dev, int c, const double* lo_xy_host,
+                     const double* hi_xy_host, int closed, int32_t* flags, void* stream);
+/* cell[j] = i * n_dis + j' for yaw' in (yaw_edges[i], yaw_edges[i+1]] and range in (dis_edges[j'], dis_edges[j'+1]],
+ * yaw' = wrap(-atan2(y, x) + phase), range = clip(sqrt(x^2 + y^2), dis_lo, dis_hi); -1 when outside every cell */
+int toda_points_polar_cell(const float* points, int n, const int32_t* n_dev, int c, float phase,
+                           const double* yaw_edges_host, int n_yaw, const double* dis_edges_host, int n_dis,
+                           float dis_lo, float dis_hi, int32_t* cell, void* stream);
+/* Stable compaction: rows with (keys[j] == match) != invert (all rows when keys == NULL) are appended, in
+ * order, at dst[*cursor_dev ...]; *cursor_dev += count.  Rows beyond cap_rows are dropped (the cursor still
+ * counts them, so the caller sees the overflow). */
+size_t toda_rows_select_workspace_bytes(int n);
+int toda_rows_select_append(const float* src, int n, const int32_t* n_dev, int c, const int32_t* keys,
+                            int match, int invert, float* dst, int cap_rows, int32_t* cursor_dev,
+                            void* ws, size_t ws_bytes, void* stream);
+/* dst[:, 0:2] = fp32(rotation of (x, y) in fp64 by (cosv, sinv)), z and column 3 copied, columns >= 4 zeroed */
+int toda_points_rotate_z(const float* src, int n, const int32_t* n_dev, int c, double cosv, double sinv,
+                         float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

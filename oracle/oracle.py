@@ -238,3 +238,14 @@ def nms_rotated(boxes_sorted, thresh):
     lib().oracle_nms_rotated.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p]
     n = lib().oracle_nms_rotated(_p(b), len(b), float(thresh), _p(keep))
     return keep[:n].copy()
+
+
+def points_in_boxes(points, boxes, mode=0):
+    """[k, n] int32 membership matrix (mode 0: roiaware points_in_boxes_cpu, mode 1: get_points_in_box)."""
+    pts = _f32(points)
+    bx = _f32(boxes)
+    if bx.ndim != 2 or bx.shape[0] == 0:
+        return np.zeros((0, pts.shape[0]), np.int32)
+    out = np.empty((bx.shape[0], pts.shape[0]), np.int32)
+    lib().oracle_points_in_boxes(_p(pts), pts.shape[0], pts.shape[1], _p(bx), bx.shape[0], bx.shape[1], int(mode), _p(out))
+    return out

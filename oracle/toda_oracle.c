@@ -644,6 +644,43 @@ int oracle_nms_rotated(const float* boxes, int n, float thresh, int64_t* keep) {
     return kept;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Point-in-box tests of the mixing processors.
+ * mode 0: roiaware_pool3d_utils.points_in_boxes_cpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168):
+ *         reject when |z - cz| > dz / 2.0; rotate the xy offset by -heading in fp32 (cos / sin taken in
+ *         fp64 and rounded); inside when |local| < d / 2.0 + 1e-2f, compared in fp64.
+ * mode 1: augmentor_utils.get_points_in_box (pcdet/datasets/augmentor/augmentor_utils.py:474-491), used by
+ *         MixUp's collision removal: |z - cz| <= dz / 2 and |local| <= fp32(d / 2 + 0.1), all fp32.
+ * out [k][n] int32 (the reference's point_indices layout).  That extension cannot be built here
+ * (its .cpp pulls in CUDA launchers), so this restatement is pinned by hand-checkable cases
+ * (tests/test_oracle_mix.py) and through the mixers' golden vectors.
+ * ------------------------------------------------------------------------------------------- */
+void oracle_points_in_boxes(const float* pts, int n, int c, const float* boxes, int k, int stride,
+                            int mode, int32_t* out) {
+    for (int i = 0; i < k; ++i) {
+        const float* b = boxes + (size_t)i * stride;
+        const float cx = b[0], cy = b[1], cz = b[2], dx = b[3], dy = b[4], dz = b[5];
+        const double a = (double)(-b[6]);
+        const float cosa = (float)cos(a), sina = (float)sin(a);
+        for (int j = 0; j < n; ++j) {
+            const float x = pts[(size_t)j * c], y = pts[(size_t)j * c + 1], z = pts[(size_t)j * c + 2];
+            int in = 0;
+            const float sz = z - cz;
+            const float sx = x - cx, sy = y - cy;
+            const float t1 = sx * cosa, t2 = sy * (-sina), t3 = sx * sina, t4 = sy * cosa;
+            const float lx = t1 + t2, ly = t3 + t4;
+            if (mode == 0) {
+                if (!((double)fabsf(sz) > (double)dz / 2.0))
+                    in = (fabs((double)lx) < (double)dx / 2.0 + (double)1e-2f) && (fabs((double)ly) < (double)dy / 2.0 + (double)1e-2f);
+            } else {
+                const float mx = dx / 2.0f + 0.1f, my = dy / 2.0f + 0.1f;
+                in = (fabsf(sz) <= dz / 2.0f) && (fabsf(lx) <= mx) && (fabsf(ly) <= my);
+            }
+            out[(size_t)i * n + j] = in;
+        }
+    }
+}
+
 int oracle_abi_version(void) { return 1; }
 
 /* number of OpenMP threads the oracle uses (the cpu_baseline leg states it as `cores`) */

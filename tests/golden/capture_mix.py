@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Capture golden vectors from the REFERENCE's own mixing processors (build container only).
+
+    python tests/golden/capture_mix.py        # writes tests/golden/mix_*.npz
+
+The four processor files (inter_domain_point_{cutmix,polarmix,lasermix}.py, intra_domain_point_mixup.py)
+are loaded by path under a stub package named `pcdet` (they use absolute `pcdet.…` imports,
+SURVEY.md Appendix D step 4).  Their two compiled helpers cannot be built in this image
+(`roiaware_pool3d_cuda.points_in_boxes_cpu` links CUDA launchers, `iou3d_nms_cuda.boxes_iou_bev_cpu`
+includes <cuda.h>), so those two symbols are served by the oracle's C restatements
+(oracle_points_in_boxes / oracle_boxes_iou_bev).  What the fixtures pin is therefore the reference's
+Python logic: order of the random draws, masks, ordering of output rows, box bookkeeping.
+Only inputs, parameters, the numpy seed and outputs are stored — no reference source.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+import capture_reference as CR  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from toda_amd.pcdet.datasets.synthetic import synth_cloud  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+PC_RANGE = np.array([-54.0, -54.0, -5.0, 54.0, 54.0, 4.8], np.float32)
+
+
+def setup():
+    CR.ALIAS = "pcdet"
+    CR.setup()
+    cu = sys.modules["pcdet.ops.roiaware_pool3d.roiaware_pool3d_cuda"]
+    iu = sys.modules["pcdet.ops.iou3d_nms.iou3d_nms_cuda"]
+
+    def points_in_boxes_cpu(boxes, pts, out):
+        out.copy_(torch.from_numpy(O.points_in_boxes(pts.numpy(), boxes.numpy(), 0)))
+        return 1
+
+    def boxes_iou_bev_cpu(a, b, out):
+        out.copy_(torch.from_numpy(O.boxes_iou_bev(a.numpy(), b.numpy())))
+        return 1
+
+    cu.points_in_boxes_cpu = points_in_boxes_cpu
+    iu.boxes_iou_bev_cpu = boxes_iou_bev_cpu
+    CR._load("pcdet.datasets.augmentor.augmentor_utils", "pcdet/datasets/augmentor/augmentor_utils.py")
+    M = {}
+    for name in ("inter_domain_point_cutmix", "inter_domain_point_polarmix", "inter_domain_point_lasermix",
+                 "intra_domain_point_mixup"):
+        M[name] = CR._load(f"pcdet.datasets.processor.{name}", f"pcdet/datasets/processor/{name}.py")
+    return M
+
+
+def scene(kind, seed, n_points, n_boxes):
+    """points [N, 4] fp32, gt_boxes [K, 8] fp32 (7 + class id), clipped to the TODA range like the data pipeline."""
+    pts, boxes, _ = synth_cloud(kind, seed, n_points=n_points, n_boxes=n_boxes)
+    pts = pts[:, :4].copy()
+    keep = (np.abs(pts[:, 0]) < 54) & (np.abs(pts[:, 1]) < 54)
+    cls = (1 + np.arange(len(boxes)) % 3).astype(np.float32)[:, None]
+    return {"points": np.ascontiguousarray(pts[keep]), "gt_boxes": np.concatenate([boxes, cls], 1).astype(np.float32)}
+
+
+def save(name, src, tgt, out, **params):
+    np.savez_compressed(os.path.join(OUT, f"mix_{name}.npz"), src_points=src["points"], src_boxes=src["gt_boxes"],
+                        tgt_points=tgt["points"], tgt_boxes=tgt["gt_boxes"], out_points=np.asarray(out["points"], np.float32),
+                        out_boxes=np.asarray(out["gt_boxes"], np.float32), **params)
+    print(name, src["points"].shape, tgt["points"].shape, "->", np.asarray(out["points"]).shape, np.asarray(out["gt_boxes"]).shape)
+
+
+def copy(d):
+    return {k: v.copy() for k, v in d.items()}
+
+
+def main():
+    M = setup()
+    # CutMix needs > 10 000 target points inside the crop (inter_domain_point_cutmix.py:57)
+    src, tgt = scene("waymo_toda", 11, 14000, 12), scene("nuscenes_toda", 12, 26000, 10)
+    np.random.seed(101)
+    out = M["inter_domain_point_cutmix"].inter_domain_point_cutmix(copy(src), copy(tgt), PC_RANGE, "center")
+    save("cutmix", src, tgt, out, seed=101)
+
+    src, tgt = scene("waymo_toda", 21, 6000, 14), scene("nuscenes_toda", 22, 4000, 12)
+    cases = [("polarmix_center", 201, dict(rc=1, degree=1.570796, pct=0.3, methods=["FIX", "FIX", "FIX"], inc="center")),
+             ("polarmix_corner", 202, dict(rc=2, degree=[0.8, 1.9], pct=0.6, methods=["RAND", "ASC"], inc="corner")),
+             ("polarmix_corner_del", 203, dict(rc=3, degree=[1.0, 2.5], pct=0.5, methods=["ASC_SIG", "DESC", "RAND"], inc="corner_del"))]
+    for name, seed, p in cases:
+        np.random.seed(seed)
+        out = M["inter_domain_point_polarmix"].inter_domain_point_polarmix(
+            copy(src), copy(tgt), p["rc"], p["degree"], p["pct"], p["methods"], PC_RANGE, "FULL", p["inc"], False)
+        deg = np.atleast_1d(np.asarray(p["degree"], np.float64))
+        save(name, src, tgt, out, seed=seed, rc=p["rc"], degree=deg, degree_is_float=isinstance(p["degree"], float),
+             pct=p["pct"], methods=np.array(p["methods"]), inc=p["inc"])
+
+    src, tgt = scene("waymo_toda", 31, 6000, 14), scene("nuscenes_toda", 32, 5000, 12)
+    for name, seed, areas, angles, inc in [("lasermix_center", 301, 3, 2, "center"), ("lasermix_corner_del", 302, 2, 4, "corner_del")]:
+        np.random.seed(seed)
+        out = M["inter_domain_point_lasermix"].inter_domain_point_lasermix(copy(src), copy(tgt), None, areas, angles, PC_RANGE, inc)
+        save(name, src, tgt, out, seed=seed, num_areas=areas, num_angles=angles, inc=inc)
+
+    d1, d2 = scene("nuscenes_toda", 41, 5000, 12), scene("nuscenes_toda", 42, 4000, 40)
+    for name, seed, fn in [("mixup", 401, "intra_domain_point_mixup"), ("mixup_cd", 402, "intra_domain_point_mixup_cd")]:
+        np.random.seed(seed)
+        out = getattr(M["intra_domain_point_mixup"], fn)(copy(d1), copy(d2), alpha=2)
+        save(name, d1, d2, out, seed=seed, alpha=2)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+"""TODA mixing processors on the MI355X (csrc/points.hip through the C ABI) - bit-exact against
+  (i) the golden vectors captured from the reference's own Python processors (tests/golden/mix_*.npz),
+  (ii) the CPU oracle (oracle/mix.py, oracle_points_in_boxes) on seeded inputs up to the full C5 cloud sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mix as OM
+from oracle import oracle as O
+from tests.test_oracle_mix import CASES, PC_RANGE, run_case
+
+pytestmark = pytest.mark.gpu
+
+
+def cloud(seed, n, c=4, span=50.0):
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-span, span, (n, c)).astype(np.float32)
+    p[:, 2] = rng.uniform(-3, 3, n)
+    return p
+
+
+def boxes(seed, k, span=45.0):
+    rng = np.random.default_rng(seed)
+    b = np.concatenate([rng.uniform(-span, span, (k, 2)), rng.uniform(-1, 1, (k, 1)), rng.uniform(1.5, 6, (k, 2)),
+                        rng.uniform(1, 3, (k, 1)), rng.uniform(-np.pi, np.pi, (k, 1)), rng.integers(1, 4, (k, 1))], 1)
+    return b.astype(np.float32)
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("n,k", [(50000, 40), (1000, 1), (7, 300), (180000, 64)])
+def test_points_in_boxes_matches_oracle(mode, n, k):
+    from toda_amd import ops
+    p, b = cloud(1, n), boxes(2, k)
+    p[: min(n, 4 * k), :3] = np.repeat(b[:, :3], 4, 0)[: min(n, 4 * k)] + np.random.default_rng(3).normal(0, 1.0, (min(n, 4 * k), 3)).astype(np.float32)
+    want = O.points_in_boxes(p[:, :3].copy(), b[:, :7].copy(), mode).sum(0) != 0
+    got = ops.points_in_boxes(dev(p), dev(b), mode).cpu().numpy()
+    assert want.sum() > 0
+    np.testing.assert_array_equal(got != 0, want)
+
+
+def test_points_in_boxes_empty_inputs():
+    from toda_amd import ops
+    p = dev(cloud(1, 100))
+    assert int(ops.points_in_boxes(p, torch.zeros((0, 7), device="cuda")).sum()) == 0
+    assert ops.points_in_boxes(torch.zeros((0, 4), device="cuda"), dev(boxes(1, 3))).numel() == 0
+
+
+def test_sector_rect_and_cell_flags_match_numpy_restatement():
+    from toda_amd import ops
+    p = cloud(5, 200000)
+    p[:8, :2] = [[0, 0], [1, 0], [-1, 0], [0, 1], [0, -1], [-1, -0.0], [3, 3], [-3, 3]]      # axis / branch-cut cases
+    yaw = OM.yaw32(p[:, 0], p[:, 1])
+    d = dev(p)
+    for lo, hi in [(-0.5, 1.2), (2.0, np.pi), (-np.pi, -2.5), (0.3, 0.3)]:
+        want = (yaw > np.float32(lo)) & (yaw < np.float32(hi))
+        np.testing.assert_array_equal(ops.points_sector(d, np.float32(lo), np.float32(hi)).cpu().numpy() != 0, want)
+    lo, hi = np.array([-10.25, 3.5]), np.array([21.125, 30.0])
+    want = (p[:, 0] > lo[0]) & (p[:, 0] < hi[0]) & (p[:, 1] > lo[1]) & (p[:, 1] < hi[1])
+    np.testing.assert_array_equal(ops.points_rect(d, lo, hi, closed=False).cpu().numpy() != 0, want)
+    p[:3, 0], p[:3, 1] = lo[0], hi[1]                                                         # exactly on the boundary
+    d = dev(p)
+    want = (p[:, 0] >= lo[0]) & (p[:, 0] <= hi[0]) & (p[:, 1] >= lo[1]) & (p[:, 1] <= hi[1])
+    got = ops.points_rect(d, lo, hi, closed=True).cpu().numpy() != 0
+    np.testing.assert_array_equal(got, want)
+    assert got[:3].all() and not (ops.points_rect(d, lo, hi, closed=False).cpu().numpy()[:3] != 0).any()
+    # LaserMix cells
+    for phase, n_ang, n_dis in [(0.7, 2, 3), (-2.9, 4, 2), (3.1, 6, 5)]:
+        yaw_e, dis_e = np.linspace(-np.pi, np.pi, n_ang + 1), np.linspace(0, np.float32(54.0), n_dis + 1)
+        yw = OM._wrap(OM.yaw32(p[:, 0], p[:, 1]), phase)
+        ds = OM._clip_range(p[:, 0], p[:, 1], np.float32(54.0))
+        want = np.full(len(p), -1, np.int32)
+        for i in range(n_ang):
+            for j in range(n_dis):
+                m = (yw > yaw_e[i]) & (yw <= yaw_e[i + 1]) & (ds > dis_e[j]) & (ds <= dis_e[j + 1])
+                want[m] = i * n_dis + j
+        got = ops.points_polar_cell(d, np.float32(phase), yaw_e, dis_e, np.float32(1e-05), np.float32(54.0) - np.float32(1e-05))
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_select_append_is_a_stable_compaction_with_device_side_counts():
+    from toda_amd import ops
+    a, b = cloud(7, 70001, c=5), cloud(8, 33333, c=5)
+    ka = (np.random.default_rng(9).integers(0, 4, len(a))).astype(np.int32)
+    kb = (np.random.default_rng(10).integers(0, 2, len(b))).astype(np.int32)
+    buf = ops.RowBuffer(len(a) + len(b), 5, "cuda")
+    buf.append(dev(a), dev(ka), 2).append(dev(b), dev(kb), 1, invert=True).append(dev(a[:10]))
+    want = np.concatenate([a[ka == 2], b[kb != 1], a[:10]], 0)
+    got = buf.finish().cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # chained: the second stage reads its row count from the first stage's cursor (no host sync in between)
+    stage1 = ops.RowBuffer(len(a), 5, "cuda").append(dev(a), dev(ka), 0, invert=True)
+    sel = a[ka != 0]
+    flags = ops.points_sector(stage1.data, -1.0, 1.0, stage1.cursor)
+    stage2 = ops.RowBuffer(len(a), 5, "cuda").append(stage1.data, flags, 1, n_dev=stage1.cursor)
+    yaw = OM.yaw32(sel[:, 0], sel[:, 1])
+    np.testing.assert_array_equal(stage2.finish().cpu().numpy(), sel[(yaw > -1.0) & (yaw < 1.0)])
+    # nothing selected / everything selected / overflow is reported
+    assert ops.RowBuffer(10, 5, "cuda").append(dev(a), dev(ka), 99).finish().shape[0] == 0
+    with pytest.raises(RuntimeError, match="overflow"):
+        ops.RowBuffer(10, 5, "cuda").append(dev(a)).finish()
+
+
+def test_rotate_z_rounds_like_the_fp64_product():
+    from toda_amd import ops
+    p = cloud(11, 30000, c=5)
+    om = 1.2345
+    rot = np.array([[np.cos(om), np.sin(om), 0], [-np.sin(om), np.cos(om), 0], [0, 0, 1]])
+    want = np.zeros_like(p)
+    want[:, :3] = np.dot(p[:, :3], rot)
+    want[:, 3] = p[:, 3]
+    got = ops.points_rotate_z(dev(p), np.cos(om), np.sin(om)).cpu().numpy()
+    np.testing.assert_array_equal(got[:, 2:], want[:, 2:])
+    np.testing.assert_array_equal(got[:, :2], want[:, :2])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_device_mixers_reproduce_reference_outputs(name):
+    from toda_amd.pcdet.datasets.processor import point_mix
+    z, out = run_case(name, point_mix)
+    np.testing.assert_array_equal(out["gt_boxes"], z["out_boxes"])
+    assert out["points"].shape == z["out_points"].shape
+    np.testing.assert_array_equal(out["points"], z["out_points"])
+
+
+def full_scene(kind, seed, n_boxes):
+    from toda_amd.pcdet.datasets.synthetic import synth_cloud
+    pts, bx, _ = synth_cloud(kind, seed, n_boxes=n_boxes)
+    cls = (1 + np.arange(len(bx)) % 3).astype(np.float32)[:, None]
+    return {"points": np.ascontiguousarray(pts[:, :4]), "gt_boxes": np.concatenate([bx, cls], 1).astype(np.float32)}
+
+
+@pytest.mark.parametrize("which", ["cutmix", "polarmix", "lasermix", "mixup_cd"])
+def test_device_mixers_match_oracle_at_full_c5_size(which):
+    """180k-point Waymo-shape source x 35k-point nuScenes-shape target (config C5), same seed on both sides."""
+    from toda_amd.pcdet.datasets.processor import point_mix
+    src, tgt = full_scene("waymo_toda", 501, 40), full_scene("nuscenes_toda", 502, 30)
+    if which == "cutmix":
+        tgt = full_scene("waymo_toda", 503, 30)                                    # needs > 10 000 target points in the crop
+        args = lambda e, r: e.cutmix(src, tgt, PC_RANGE, rng=r)
+    elif which == "polarmix":
+        args = lambda e, r: e.polarmix(src, tgt, 2, [1.0, 2.0], 0.4, ["FIX", "RAND", "ASC_SIG"], "corner_del", rng=r)
+    elif which == "lasermix":
+        args = lambda e, r: e.lasermix_cyc(src, tgt, 3, 4, PC_RANGE, "corner_del", rng=r)
+    else:
+        args = lambda e, r: e.mixup(src, tgt, 2.0, collision=True, rng=r)
+    want = args(OM, np.random.RandomState(77))
+    got = args(point_mix, np.random.RandomState(77))
+    np.testing.assert_array_equal(got["gt_boxes"], want["gt_boxes"])
+    assert got["points"].shape == want["points"].shape and got["points"].shape[0] > 30000
+    np.testing.assert_array_equal(got["points"], want["points"])
+
+
+def test_mixers_keep_cuda_tensors_on_the_device_and_wrappers_are_drop_in():
+    from toda_amd.pcdet.datasets.processor.inter_domain_point_polarmix import inter_domain_point_polarmix
+    from toda_amd.pcdet.datasets.processor.intra_domain_point_mixup import intra_domain_point_mixup
+    src, tgt = full_scene("nuscenes_toda", 601, 10), full_scene("nuscenes_toda", 602, 10)
+    src_d = {"points": dev(src["points"]), "gt_boxes": src["gt_boxes"], "frame_id": "a"}
+    tgt_d = {"points": dev(tgt["points"]), "gt_boxes": tgt["gt_boxes"], "frame_id": "b"}
+    np.random.seed(3)
+    out = inter_domain_point_polarmix(src_d, tgt_d, 1, 1.570796, 0.0, ["FIX", "FIX", "FIX"], PC_RANGE, "FULL", "center", False)
+    assert out["points"].is_cuda and out["frame_id"] == "b" and out["gt_boxes"].shape[1] == 8
+    np.random.seed(3)
+    want = OM.polarmix(src, tgt, 1, 1.570796, 0.0, ["FIX", "FIX", "FIX"], "center")
+    np.testing.assert_array_equal(out["points"].cpu().numpy(), want["points"])
+    np.random.seed(4)
+    out = intra_domain_point_mixup(dict(src, frame_id="a"), dict(tgt), alpha=2)
+    assert isinstance(out["points"], np.ndarray) and out["frame_id"] == "a"
+    with pytest.raises(NotImplementedError):
+        inter_domain_point_polarmix(src_d, tgt_d, 1, 1.5, 0.0, ["FIX"], PC_RANGE, "RAND", "center", False)

@@ -43,6 +43,13 @@ SIGNATURES = {
     "toda_boxes_iou_bev": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "toda_nms_workspace_bytes": (_sz, [_i]),
     "toda_nms_rotated": (_i, [_vp, _i, C.c_float, _vp, _vp, _vp, _sz, _vp]),
+    "toda_points_in_boxes": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "toda_points_sector": (_i, [_vp, _i, _vp, _i, _dbl, _dbl, _vp, _vp]),
+    "toda_points_rect": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "toda_points_polar_cell": (_i, [_vp, _i, _vp, _i, C.c_float, _vp, _i, _vp, _i, C.c_float, C.c_float, _vp, _vp]),
+    "toda_rows_select_workspace_bytes": (_sz, [_i]),
+    "toda_rows_select_append": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "toda_points_rotate_z": (_i, [_vp, _i, _vp, _i, _dbl, _dbl, _vp, _vp]),
     "toda_center_assign": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _dbl, _i, _vp, _vp, _vp, _vp, _vp]),
 }
 
@@ -105,6 +112,11 @@ def host_i32(vals):
 
 def host_f32(vals):
     arr = (C.c_float * len(vals))(*[float(v) for v in vals])
+    return arr
+
+
+def host_f64(vals):
+    arr = (C.c_double * len(vals))(*[float(v) for v in vals])
     return arr
 
 

@@ -553,3 +553,93 @@ def nms_rotated(boxes_sorted, thresh):
     rc = lib.toda_nms_rotated(L.ptr(b), n, float(thresh), L.ptr(keep), L.ptr(n_keep), L.ptr(ws), ws_bytes, L.stream())
     L.check(rc, "toda_nms_rotated")
     return keep, n_keep
+
+
+# --------------------------------------------------------------------------- point tables (mix processors, range mask)
+def _rows(points, n_dev):
+    if points.dtype != torch.float32 or points.dim() != 2:
+        raise RuntimeError("point tables are [n, c] float32")
+    return points.shape[0], points.shape[1], (L.ptr(n_dev) if n_dev is not None else None)
+
+
+def points_in_boxes(points, boxes, mode=0, n_dev=None):
+    """flags[j] = 1 iff some box holds point j (mode 0: roiaware points_in_boxes_cpu test, mode 1: get_points_in_box)."""
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    flags = torch.zeros((n,), dtype=torch.int32, device=points.device)
+    k = int(boxes.shape[0]) if boxes is not None and boxes.dim() == 2 else 0
+    if n == 0 or k == 0:
+        return flags
+    boxes = boxes.contiguous().float()
+    rc = lib.toda_points_in_boxes(L.ptr(points), n, nd, c, L.ptr(boxes), k, boxes.shape[1], int(mode), L.ptr(flags), L.stream())
+    L.check(rc, "toda_points_in_boxes")
+    return flags
+
+
+def points_sector(points, lo, hi, n_dev=None):
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    flags = torch.zeros((n,), dtype=torch.int32, device=points.device)
+    rc = lib.toda_points_sector(L.ptr(points), n, nd, c, float(lo), float(hi), L.ptr(flags), L.stream())
+    L.check(rc, "toda_points_sector")
+    return flags
+
+
+def points_rect(points, lo_xy, hi_xy, closed=False, n_dev=None):
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    flags = torch.zeros((n,), dtype=torch.int32, device=points.device)
+    lo, hi = L.host_f64(lo_xy), L.host_f64(hi_xy)
+    rc = lib.toda_points_rect(L.ptr(points), n, nd, c, L.hptr(lo), L.hptr(hi), int(bool(closed)), L.ptr(flags), L.stream())
+    L.check(rc, "toda_points_rect")
+    return flags
+
+
+def points_polar_cell(points, phase, yaw_edges, dis_edges, dis_lo, dis_hi, n_dev=None):
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    cell = torch.full((n,), -1, dtype=torch.int32, device=points.device)
+    ye, de = L.host_f64(yaw_edges), L.host_f64(dis_edges)
+    rc = lib.toda_points_polar_cell(L.ptr(points), n, nd, c, float(phase), L.hptr(ye), len(yaw_edges) - 1, L.hptr(de),
+                                    len(dis_edges) - 1, float(dis_lo), float(dis_hi), L.ptr(cell), L.stream())
+    L.check(rc, "toda_points_polar_cell")
+    return cell
+
+
+def points_rotate_z(points, cosv, sinv, n_dev=None):
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    out = torch.empty_like(points)
+    rc = lib.toda_points_rotate_z(L.ptr(points), n, nd, c, float(cosv), float(sinv), L.ptr(out), L.stream())
+    L.check(rc, "toda_points_rotate_z")
+    return out
+
+
+class RowBuffer:
+    """A point table under construction on the device: rows are appended by stable selection at a device-side
+    cursor, so a whole mix runs without a host round trip; `finish()` reads the row count (one sync)."""
+
+    def __init__(self, cap_rows, c, device):
+        self.cap = int(cap_rows)
+        self.data = torch.empty((max(self.cap, 1), c), dtype=torch.float32, device=device)
+        self.cursor = torch.zeros((1,), dtype=torch.int32, device=device)
+
+    def append(self, src, keys=None, match=1, invert=False, n_dev=None):
+        lib = L.load()
+        n, c, nd = _rows(src, n_dev)
+        if c != self.data.shape[1]:
+            raise RuntimeError("RowBuffer.append: column count differs")
+        if n == 0:
+            return self
+        ws_bytes = lib.toda_rows_select_workspace_bytes(n)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=src.device)
+        rc = lib.toda_rows_select_append(L.ptr(src), n, nd, c, L.ptr(keys), int(match), int(bool(invert)), L.ptr(self.data),
+                                         self.cap, L.ptr(self.cursor), L.ptr(ws), ws_bytes, L.stream())
+        L.check(rc, "toda_rows_select_append")
+        return self
+
+    def finish(self):
+        n = int(self.cursor.item())
+        if n > self.cap:
+            raise RuntimeError(f"RowBuffer overflow: {n} rows for a capacity of {self.cap}")
+        return self.data[:n]

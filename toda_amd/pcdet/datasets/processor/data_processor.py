@@ -10,22 +10,11 @@ from functools import partial
 
 import numpy as np
 
-from ...utils import common_utils
+from ...utils import box_utils, common_utils
 
 
 def mask_boxes_outside_range(boxes, limit_range, min_num_corners=1):
-    """Keep boxes with >= min_num_corners BEV corners inside the x/y range (reference
-    box_utils.mask_boxes_outside_range_numpy)."""
-    if boxes.shape[0] == 0:
-        return np.zeros((0,), dtype=bool)
-    half = boxes[:, 3:5] / 2
-    signs = np.array([[1, 1], [1, -1], [-1, -1], [-1, 1]], dtype=boxes.dtype)
-    local = signs[None] * half[:, None, :]                        # [N, 4, 2]
-    c, s = np.cos(boxes[:, 6]), np.sin(boxes[:, 6])
-    rot = np.stack([np.stack([c, -s], -1), np.stack([s, c], -1)], -2)  # [N, 2, 2]
-    corners = np.einsum("nij,nkj->nki", rot, local) + boxes[:, None, 0:2]
-    inside = ((corners >= np.asarray(limit_range[0:2])) & (corners <= np.asarray(limit_range[3:5]))).all(-1)
-    return inside.sum(1) >= min_num_corners
+    return box_utils.mask_boxes_outside_range_numpy(boxes, limit_range, min_num_corners=min_num_corners)
 
 
 class DataProcessor:

@@ -26,3 +26,28 @@ def boxes3d_lidar_to_aligned_bev_boxes(boxes3d):
 
 def boxes3d_nearest_bev_iou(boxes_a, boxes_b):
     return boxes_iou_normal(boxes3d_lidar_to_aligned_bev_boxes(boxes_a), boxes3d_lidar_to_aligned_bev_boxes(boxes_b))
+
+
+_CORNER_SIGNS = ((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))
+
+
+def boxes_to_corners_3d(boxes3d):
+    """[N, >=7] (x y z dx dy dz heading) -> [N, 8, 3]; corners 0-3 bottom (+x+y, +x-y, -x-y, -x+y), 4-7 top, same
+    order as the reference (box_utils.py:28-54).  fp32 torch arithmetic, numpy in -> numpy out."""
+    boxes3d, is_numpy = common_utils.check_numpy_to_torch(boxes3d)
+    half = boxes3d.new_tensor(_CORNER_SIGNS) / 2
+    local = boxes3d[:, None, 3:6].repeat(1, 8, 1) * half[None, :, :]
+    corners = common_utils.rotate_points_along_z(local.view(-1, 8, 3), boxes3d[:, 6]).view(-1, 8, 3)
+    corners += boxes3d[:, None, 0:3]
+    return corners.numpy() if is_numpy else corners
+
+
+def mask_boxes_outside_range_numpy(boxes, limit_range, min_num_corners=1):
+    """True for boxes with at least `min_num_corners` of their 8 corners inside [min xyz, max xyz], ends inclusive
+    (reference box_utils.py:57-72; all three coordinates are tested)."""
+    if boxes.shape[0] == 0:
+        return np.zeros((0,), dtype=bool)
+    corners = boxes_to_corners_3d(boxes[:, 0:7])
+    lim = np.asarray(limit_range)
+    inside = ((corners >= lim[0:3]) & (corners <= lim[3:6])).all(axis=2)
+    return inside.sum(axis=1) >= min_num_corners

@@ -90,3 +90,16 @@ class AverageMeter:
         self.sum += val * n
         self.count += n
         self.avg = self.sum / self.count
+
+
+def rotate_points_along_z(points, angle):
+    """points [B, N, 3+C], angle [B] (radians, counter-clockwise seen from +z): fp32 batched product with the
+    row-vector rotation matrix [[c, s, 0], [-s, c, 0], [0, 0, 1]] (reference common_utils.py:34-57)."""
+    points, is_numpy = check_numpy_to_torch(points)
+    angle, _ = check_numpy_to_torch(angle)
+    c, s = torch.cos(angle), torch.sin(angle)
+    o, l = torch.zeros_like(angle), torch.ones_like(angle)
+    rot = torch.stack((c, s, o, -s, c, o, o, o, l), dim=1).view(-1, 3, 3).float()
+    xyz = torch.matmul(points[:, :, 0:3], rot)
+    out = torch.cat((xyz, points[:, :, 3:]), dim=-1)
+    return out.numpy() if is_numpy else out

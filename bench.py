@@ -42,6 +42,9 @@ WORKLOADS = {
            "SECOND-style VoxelBackBone8x forward only (voxelize+MeanVFE+backbone+dense BEV), 60k-pt nuScenes-shape clouds, bs 4"),
     "c5": ("toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml", 2,
            "TODA stage-1 CenterPoint (VoxelResBackBone8x), mixed 180k/35k-pt clouds, bs 2 per GPU"),
+    "c5mix": ("toda_amd/tools/cfgs/models/toda_stage1_polarmix.yaml", 2,
+              "TODA stage-1 step with the inter-domain PolarMix in the loop: mix (180k-pt source x 35k-pt target, on the device) "
+              "+ range mask + shuffle + voxelize + CenterPoint (VoxelResBackBone8x) fwd+bwd+optimizer, bs 2 per GPU"),
     "c5cl": ("toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml", 2,
              "TODA stage-2 consistency step (2 fwd + 1 bwd, VoxelResBackBone8x), mixed 180k/35k-pt clouds, bs 2 per GPU"),
 }
@@ -123,10 +126,17 @@ def run_gpu(args, rank, world, device):
     yaml_path, per_gpu, desc = WORKLOADS[args.workload]
     cfg = load_cfg(yaml_path)
     pair = args.workload.endswith("cl")
+    mixed = args.workload.endswith("mix")
     if pair:
         from toda_amd.pcdet.datasets import SyntheticPairDataset
         from toda_amd.pcdet.models import DistModel, model_fn_decorator_cl
         dataset = SyntheticPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    elif mixed:
+        from toda_amd.pcdet.datasets import SyntheticMixDataset
+        cfg.DATA_CONFIG.CACHE_FRAMES = True      # raw clouds of both domains stay resident in HBM
+        cfg.DATA_CONFIG.SYNTHETIC.NUM_SOURCE = cfg.DATA_CONFIG.SYNTHETIC.NUM_TARGET = 2 * per_gpu * world
+        dataset = SyntheticMixDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+        np.random.seed(4321 + rank)
     else:
         dataset = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
     torch.manual_seed(1234)
@@ -143,6 +153,11 @@ def run_gpu(args, rank, world, device):
     if pair:
         batches = make_device_pair_batches(dataset, per_gpu, args.batches, rank, device)
         cl_fn = model_fn_decorator_cl()
+    elif mixed:
+        batches = None
+        for i in range(len(dataset)):            # generate + upload every raw frame before the clock starts
+            dataset._frame(dataset.source_kind, i % dataset.num_source)
+            dataset._frame(dataset.target_kind, 100_000 + i % dataset.num_target)
     else:
         batches = make_device_batches(dataset, per_gpu, args.batches, rank, device)
     params = [p for p in net.parameters() if p.requires_grad]
@@ -165,7 +180,13 @@ def run_gpu(args, rank, world, device):
             adv, org = batches[it % len(batches)]
             loss = cl_fn(model, dict(adv), dict(org), world > 1).loss
         else:
-            batch = dict(batches[it % len(batches)])
+            if mixed:   # the whole input path of a TODA stage-1 step: mix -> range mask -> shuffle -> collate, all on the device
+                base = ((it * world + rank) * per_gpu) % len(dataset)
+                batch = dataset.collate_batch([dataset[(base + i) % len(dataset)] for i in range(per_gpu)])
+                batch["gt_boxes"] = torch.from_numpy(batch["gt_boxes"]).float().to(device)
+                batch = {k: batch[k] for k in ("points", "points_per_sample", "gt_boxes", "batch_size")}
+            else:
+                batch = dict(batches[it % len(batches)])
             voxelize_on_gpu(batch, dataset.voxel_cfg)
             ret, tb, _ = model(batch)
             loss = ret["loss"].mean()
@@ -244,7 +265,7 @@ def roofline_from_timer(timer):
     return roof, rows
 
 
-def cpu_baseline(cfg, n_points=180000):
+def cpu_baseline(cfg, n_points=180000, mixed=False):
     """The same train step on the host cores: CPU oracle for the sparse part (oracle/, "port"), torch
     CPU for the dense part, on a BOUNDED sample: ONE full-size scene (bs 1), ONE train step (the C
     port has no warm-up effects; ~20-40 s of CPU work)."""
@@ -256,6 +277,8 @@ def cpu_baseline(cfg, n_points=180000):
 
     cfg = copy.deepcopy(cfg)
     cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = n_points
+    if "KINDS" not in cfg.DATA_CONFIG.SYNTHETIC and "KIND" not in cfg.DATA_CONFIG.SYNTHETIC:
+        cfg.DATA_CONFIG.SYNTHETIC.KINDS = [cfg.DATA_CONFIG.SYNTHETIC.get("SOURCE_KIND", "waymo_toda")]
     dataset = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
     torch.manual_seed(1234)
     from oracle import oracle as O
@@ -272,7 +295,25 @@ def cpu_baseline(cfg, n_points=180000):
     model.train()
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     fn = model_fn_decorator()
-    batch = dataset.collate_batch([dataset[0]])
+    mix_s = 0.0
+    if mixed:   # the CPU path of the mix: numpy restatement of the reference's PolarMix (oracle/mix.py) on a 180k x 35k pair
+        from oracle import mix as OM
+        from toda_amd.pcdet.datasets.synthetic import synth_cloud
+        dc = cfg.DATA_CONFIG
+        frames = []
+        for kind, seed in ((dc.SYNTHETIC.SOURCE_KIND, 5000), (dc.SYNTHETIC.TARGET_KIND, 105000)):
+            pts, bx, _ = synth_cloud(kind, seed, class_count=len(cfg.CLASS_NAMES))
+            frames.append({"points": pts[:, :4].copy(), "gt_boxes": np.concatenate([bx, np.ones((len(bx), 1), np.float32)], 1)})
+        np.random.seed(4321)
+        t0 = time.perf_counter()
+        mixed_scene = OM.polarmix(frames[0], frames[1], int(dc.POLARMIX_RC_NUM), dc.POLARMIX_DEGREE, 0.0, list(dc.POLARMIX_UPDATE_METHOD),
+                                  dc.MIX_INC_METHOD)
+        mix_s = time.perf_counter() - t0
+        data = dataset.data_processor.forward({"points": mixed_scene["points"], "gt_boxes": mixed_scene["gt_boxes"], "use_lead_xyz": True})
+        batch = dataset.collate_batch([data])
+        say(f"PolarMix of one scene pair on the host: {mix_s:.2f} s")
+    else:
+        batch = dataset.collate_batch([dataset[0]])
     say(f"one scene of {n_points} points on {cores} host threads ...")
     with oracle_backend():
         t0 = time.perf_counter()
@@ -283,7 +324,7 @@ def cpu_baseline(cfg, n_points=180000):
         say(f"backward done after {time.perf_counter() - t0:.1f} s")
         torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
         optimizer.step()
-        dt = time.perf_counter() - t0
+        dt = time.perf_counter() - t0 + mix_s
     return {"value": round(1.0 / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"1 scene of {n_points} points (bs 1 instead of 2), one full train step = {dt:.1f} s; "
                       f"sparse part = oracle/ C port (OpenMP, AVX2), dense part = torch CPU"}
@@ -332,7 +373,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(res["cfg"])
+            line["cpu_baseline"] = cpu_baseline(res["cfg"], mixed=args.workload.endswith("mix"))
         print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()

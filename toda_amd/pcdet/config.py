@@ -100,7 +100,7 @@ def merge_new_config(config, new_config, search_dirs=()):
                 base = Path(d) / base
                 break
         with open(base) as f:
-            config.update(AttrDict(yaml.safe_load(f)))
+            merge_new_config(config, yaml.safe_load(f), search_dirs)   # a base may name its own base
     for key, val in new_config.items():
         if key == "_BASE_CONFIG_":
             continue

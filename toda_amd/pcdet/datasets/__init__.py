@@ -10,11 +10,13 @@ from torch.utils.data import DistributedSampler as _DistributedSampler
 from ..utils import common_utils
 from .dataset import DatasetTemplate
 from .synthetic import SyntheticLidarDataset, SyntheticPairDataset
+from .two_dataset import SyntheticMixDataset
 
 __all__ = {
     "DatasetTemplate": DatasetTemplate,
     "SyntheticLidarDataset": SyntheticLidarDataset,
     "SyntheticPairDataset": SyntheticPairDataset,
+    "SyntheticMixDataset": SyntheticMixDataset,
 }
 
 

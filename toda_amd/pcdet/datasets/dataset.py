@@ -4,6 +4,7 @@ depth_downsample_factor), prepare_data and collate_batch."""
 from collections import defaultdict
 
 import numpy as np
+import torch
 import torch.utils.data as torch_data
 
 from .processor.data_processor import DataProcessor
@@ -71,6 +72,11 @@ class DatasetTemplate(torch_data.Dataset):
         for key, vals in merged.items():
             if key in ("voxels", "voxel_num_points"):
                 ret[key] = np.concatenate(vals, axis=0)
+            elif key in ("points", "voxel_coords") and torch.is_tensor(vals[0]):
+                # device-resident samples (GPU input pipeline): the batch column is added on the device
+                ret[key] = torch.cat([torch.nn.functional.pad(v, (1, 0), value=float(i)) for i, v in enumerate(vals)], dim=0)
+                if key == "points":
+                    ret["points_per_sample"] = [int(v.shape[0]) for v in vals]
             elif key in ("points", "voxel_coords"):
                 ret[key] = np.concatenate(
                     [np.pad(v, ((0, 0), (1, 0)), mode="constant", constant_values=i) for i, v in enumerate(vals)], axis=0)

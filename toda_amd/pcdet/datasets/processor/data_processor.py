@@ -9,6 +9,7 @@ transform_points_to_voxels has two modes (config key VOXELIZE_ON, default 'gpu_b
 from functools import partial
 
 import numpy as np
+import torch
 
 from ...utils import box_utils, common_utils
 
@@ -31,9 +32,16 @@ class DataProcessor:
     def mask_points_and_boxes_outside_range(self, data_dict=None, config=None):
         if data_dict is None:
             return partial(self.mask_points_and_boxes_outside_range, config=config)
-        if data_dict.get("points") is not None:
-            keep = common_utils.mask_points_by_range(data_dict["points"], self.point_cloud_range)
-            data_dict["points"] = data_dict["points"][keep]
+        pts = data_dict.get("points")
+        if pts is not None and torch.is_tensor(pts) and pts.is_cuda:
+            # GPU input pipeline: closed x/y range test + stable compaction on the device (csrc/points.hip)
+            from .... import ops
+            r = self.point_cloud_range
+            keep = ops.points_rect(pts.contiguous(), r[0:2], r[3:5], closed=True)
+            data_dict["points"] = ops.RowBuffer(pts.shape[0], pts.shape[1], pts.device).append(pts.contiguous(), keep, 1).finish()
+        elif pts is not None:
+            keep = common_utils.mask_points_by_range(pts, self.point_cloud_range)
+            data_dict["points"] = pts[keep]
         if data_dict.get("gt_boxes") is not None and config.REMOVE_OUTSIDE_BOXES and self.training:
             keep = mask_boxes_outside_range(data_dict["gt_boxes"], self.point_cloud_range,
                                             min_num_corners=config.get("min_num_corners", 1))
@@ -47,7 +55,11 @@ class DataProcessor:
             rng = data_dict.get("_rng")
             n = data_dict["points"].shape[0]
             order = rng.permutation(n) if rng is not None else np.random.permutation(n)
-            data_dict["points"] = data_dict["points"][order]
+            pts = data_dict["points"]
+            if torch.is_tensor(pts):      # the permutation is drawn on the host (same numpy stream as the reference)
+                data_dict["points"] = pts.index_select(0, torch.from_numpy(order).to(pts.device))
+            else:
+                data_dict["points"] = pts[order]
         return data_dict
 
     def _bind_voxel_geometry(self, config):
@@ -78,7 +90,8 @@ class DataProcessor:
             self.voxel_generator = spconv.utils.VoxelGenerator(
                 voxel_size=self.voxel_cfg["voxel_size"], point_cloud_range=self.voxel_cfg["point_cloud_range"],
                 max_num_points=self.voxel_cfg["max_points_per_voxel"], max_voxels=self.voxel_cfg["max_num_voxels"])
-        voxels, coords, num = self.voxel_generator.generate(np.ascontiguousarray(data_dict["points"], np.float32))
+        pts = data_dict["points"]
+        voxels, coords, num = self.voxel_generator.generate(pts if torch.is_tensor(pts) else np.ascontiguousarray(pts, np.float32))
         if not data_dict["use_lead_xyz"]:
             voxels = voxels[..., 3:]
         data_dict.update(voxels=voxels, voxel_coords=coords, voxel_num_points=num)

@@ -1,5 +1,6 @@
 """PointFeatureEncoder (reference pcdet/datasets/processor/point_feature_encoder.py:4-61)."""
 import numpy as np
+import torch
 
 
 class PointFeatureEncoder:
@@ -29,6 +30,9 @@ class PointFeatureEncoder:
             i = self.src_feature_list.index(name)
             col = points[:, i:i + 1]
             if name == "intensity" and self.point_encoding_config.get("normalize_intensity", None):
-                col = col / max(col.max(), 1e-12)
+                top = col.max()
+                col = col / (top.clamp_min(1e-12) if torch.is_tensor(col) else max(top, 1e-12))
             cols.append(col)
+        if torch.is_tensor(points):          # device-resident cloud (GPU input pipeline): same fp32 arithmetic
+            return torch.cat(cols, dim=1).contiguous(), True
         return np.concatenate(cols, axis=1), True

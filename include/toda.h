@@ -203,6 +203,10 @@ int toda_center_assign(const float* gt_boxes, int batch, int n_gt, int code_size
  * ---------------------------------------------------------------------- */
 int toda_boxes_iou_bev(const float* boxes_a, int na, const float* boxes_b, int nb,
                        float* iou /*[na, nb]*/, void* stream);
+/* Intersection AREA of the rotated BEV rectangles (iou3d_nms_kernel.cu boxes_overlap_kernel, used by
+ * iou3d_nms_utils.boxes_iou3d_gpu :52-82 for the recall record of detector3d_template.py:287-328). */
+int toda_boxes_overlap_bev(const float* boxes_a, int na, const float* boxes_b, int nb,
+                           float* overlap /*[na, nb]*/, void* stream);
 size_t toda_nms_workspace_bytes(int n);
 int toda_nms_rotated(const float* boxes_sorted, int n, float thresh, int64_t* keep /*[n]*/,
                      int32_t* n_keep_dev, void* ws, size_t ws_bytes, void* stream);

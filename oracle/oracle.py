@@ -249,3 +249,23 @@ def points_in_boxes(points, boxes, mode=0):
     out = np.empty((bx.shape[0], pts.shape[0]), np.int32)
     lib().oracle_points_in_boxes(_p(pts), pts.shape[0], pts.shape[1], _p(bx), bx.shape[0], bx.shape[1], int(mode), _p(out))
     return out
+
+
+def boxes_overlap_bev(boxes_a, boxes_b):
+    a, b = _f32(boxes_a)[:, :7].copy(), _f32(boxes_b)[:, :7].copy()
+    out = np.zeros((len(a), len(b)), np.float32)
+    if len(a) and len(b):
+        lib().oracle_boxes_overlap_bev(_p(a), len(a), _p(b), len(b), _p(out))
+    return out
+
+
+def boxes_iou3d(boxes_a, boxes_b):
+    """3-D IoU = BEV overlap area x height overlap / union volume (reference iou3d_nms_utils.py:52-82), fp32."""
+    a, b = _f32(boxes_a)[:, :7], _f32(boxes_b)[:, :7]
+    ov = boxes_overlap_bev(a, b)
+    a_hi, a_lo = (a[:, 2] + a[:, 5] / 2)[:, None], (a[:, 2] - a[:, 5] / 2)[:, None]
+    b_hi, b_lo = (b[:, 2] + b[:, 5] / 2)[None, :], (b[:, 2] - b[:, 5] / 2)[None, :]
+    oh = np.clip(np.minimum(a_hi, b_hi) - np.maximum(a_lo, b_lo), 0, None).astype(np.float32)
+    o3 = ov * oh
+    va, vb = (a[:, 3] * a[:, 4] * a[:, 5])[:, None], (b[:, 3] * b[:, 4] * b[:, 5])[None, :]
+    return o3 / np.clip(va + vb - o3, 1e-6, None)

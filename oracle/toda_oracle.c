@@ -630,6 +630,11 @@ void oracle_boxes_iou_bev(const float* a, int na, const float* b, int nb, float*
         for (int j = 0; j < nb; ++j) iou[(size_t)i * nb + j] = oracle_iou_bev(a + 7 * i, b + 7 * j);
 }
 
+void oracle_boxes_overlap_bev(const float* a, int na, const float* b, int nb, float* overlap) {
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) overlap[(size_t)i * nb + j] = oracle_box_overlap(a + 7 * i, b + 7 * j);
+}
+
 /* boxes already sorted by descending score; keep[] receives the kept indices; returns their count */
 int oracle_nms_rotated(const float* boxes, int n, float thresh, int64_t* keep) {
     unsigned char* dead = (unsigned char*)calloc((size_t)n + 1, 1);

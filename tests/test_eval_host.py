@@ -1,0 +1,95 @@
+"""Host logic of the eval / pseudo-label round trip: infos.pkl wire format, thresholding of
+predictions into pseudo labels, the synthetic dataset's infos / PSEUDO_INFO_PATH, centre-distance evaluation, 3-D IoU oracle."""
+import os
+import pickle
+
+import numpy as np
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def toda_cfg(n_points=3000, samples=4):
+    from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(ROOT, "toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml"), cfg)
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = n_points
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_SAMPLES = samples
+    return cfg
+
+
+def test_generate_pseudo_label_samples_wire_format(tmp_path):
+    from toda_amd.tools.eval_utils.generate_pseudo_labels import generate_pseudo_label_samples
+    infos = [{"lidar_path": "samples/LIDAR_TOP/frame_a.pcd.bin".replace(".pcd", ""), "token": "t0", "sweeps": [1, 2],
+              "gt_boxes": np.zeros((3, 7)), "gt_names": np.array(["car"] * 3)},
+             {"point_cloud": {"lidar_idx": "000007"}, "token": "t1"}]
+    src = tmp_path / "unlabel.pkl"
+    with open(src, "wb") as f:
+        pickle.dump(infos, f)
+    preds = [{"frame_id": "frame_a", "name": np.array(["car", "car", "truck"]), "score": np.array([0.9, 0.2, 0.8]),
+              "boxes_lidar": np.arange(21, dtype=np.float32).reshape(3, 7)},
+             {"frame_id": "000007", "name": np.array(["car"]), "score": np.array([0.31]), "boxes_lidar": np.ones((1, 7), np.float32)}]
+    out = tmp_path / "pseudo.pkl"
+    n_infos, n_boxes = generate_pseudo_label_samples(src, preds, out, score_thresh={"car": 0.3})
+    assert (n_infos, n_boxes) == (2, 2)
+    got = pickle.load(open(out, "rb"))
+    assert got[0]["token"] == "t0" and got[0]["sweeps"] == [1, 2]                       # untouched keys survive
+    assert got[0]["gt_names"].tolist() == ["car"] and got[0]["gt_boxes"].tolist() == [list(range(7))]
+    assert got[1]["gt_boxes"].shape == (1, 7)
+    # no threshold: everything is kept, other classes included
+    generate_pseudo_label_samples(src, preds, out, score_thresh=None)
+    assert pickle.load(open(out, "rb"))[0]["gt_names"].tolist() == ["car", "car", "truck"]
+
+
+def test_synthetic_infos_and_pseudo_info_path_round_trip(tmp_path):
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    cfg = toda_cfg()
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=False)
+    assert len(ds.infos) == 4 and ds.infos[2]["lidar_path"].endswith("syn_000002.bin") and ds.infos[0]["gt_boxes"].shape[1] == 7
+    path = tmp_path / "infos.pkl"
+    ds.dump_infos(path)
+    infos = pickle.load(open(path, "rb"))
+    for k, info in enumerate(infos):                                                      # "pseudo labels": k boxes per frame
+        info["gt_boxes"] = np.tile(np.array([[5.0 + k, 1, 0.8, 4, 2, 1.6, 0.1]], np.float32), (k, 1))
+        info["gt_names"] = np.array(["car"] * k)
+    with open(path, "wb") as f:
+        pickle.dump(infos, f)
+    cfg.DATA_CONFIG.PSEUDO_INFO_PATH = str(path)
+    ds2 = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=False)
+    item = ds2[3]
+    assert item["gt_boxes"].shape == (3, 8) and np.allclose(item["gt_boxes"][0], [8, 1, 0.8, 4, 2, 1.6, 0.1, 1])
+    assert item["frame_id"] == "syn_000003"
+    batch = ds2.collate_batch([ds2[1], ds2[3]])
+    assert batch["frame_id"].tolist() == ["syn_000001", "syn_000003"] and batch["gt_boxes"].shape == (2, 3, 8)
+
+
+def test_centre_distance_evaluation_counts():
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    cfg = toda_cfg(samples=2)
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=False)
+    annos = []
+    for k, info in enumerate(ds.infos):
+        boxes = info["gt_boxes"].copy()
+        boxes[:, 0] += 0.5                                     # within 2 m
+        boxes = np.concatenate([boxes[: len(boxes) // 2], boxes[:1] + 30.0], 0)          # half recalled + one false positive
+        annos.append({"frame_id": f"syn_{k:06d}", "name": np.array(["car"] * len(boxes)), "score": np.linspace(1, 0.5, len(boxes)),
+                      "boxes_lidar": boxes})
+    text, res = ds.evaluation(annos, ["car"])
+    n_gt = sum(len(i["gt_boxes"]) for i in ds.infos)
+    n_hit = sum(len(i["gt_boxes"]) // 2 for i in ds.infos)
+    assert abs(res["car/recall_2m"] - n_hit / n_gt) < 1e-9 and abs(res["car/precision_2m"] - n_hit / (n_hit + 2)) < 1e-9
+    assert "recall@2m" in text
+
+
+def test_oracle_iou3d_hand_cases():
+    a = np.array([[0, 0, 0, 2, 2, 2, 0]], np.float32)
+    b = np.array([[0, 0, 0, 2, 2, 2, 0], [1, 0, 0, 2, 2, 2, 0], [0, 0, 1, 2, 2, 2, 0], [0, 0, 3, 2, 2, 2, 0], [0, 0, 0, 2, 2, 2, np.pi / 2]], np.float32)
+    iou = O.boxes_iou3d(a, b)[0]
+    np.testing.assert_allclose(iou, [1.0, 4 / 12, 4 / 12, 0.0, 1.0], atol=1e-5)
+    assert O.boxes_overlap_bev(a, b)[0, 1] == np.float32(2.0)
+
+
+def test_merge_results_single_process():
+    from toda_amd.pcdet.utils.common_utils import merge_results_dist
+    assert merge_results_dist([1, 2, 3, 4], 3) == [1, 2, 3]

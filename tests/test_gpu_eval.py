@@ -1,0 +1,90 @@
+"""Eval / pseudo-label round trip on the MI355X: 3-D IoU through the C ABI against the oracle, the
+recall record, and the CLI chain train -> checkpoint -> test -> generate_pseudo_labels -> stage-2 training on the
+pseudo infos."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rand_boxes(seed, k, span=20.0):
+    rng = np.random.default_rng(seed)
+    return np.concatenate([rng.uniform(-span, span, (k, 2)), rng.uniform(-1, 1, (k, 1)), rng.uniform(1.5, 6, (k, 2)),
+                           rng.uniform(1, 3, (k, 1)), rng.uniform(-np.pi, np.pi, (k, 1))], 1).astype(np.float32)
+
+
+def test_overlap_area_and_iou3d_match_oracle():
+    from toda_amd import ops
+    from toda_amd.pcdet.ops.iou3d_nms import iou3d_nms_utils
+    a, b = rand_boxes(1, 150), rand_boxes(2, 220)
+    b[:40] = a[:40] + np.random.default_rng(3).normal(0, 0.3, (40, 7)).astype(np.float32)         # real overlaps
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    area = ops.boxes_overlap_bev(da, db).cpu().numpy()
+    want = O.boxes_overlap_bev(a, b)
+    assert (want > 0).sum() > 40
+    np.testing.assert_allclose(area, want, rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(area == 0, want == 0)
+    np.testing.assert_allclose(iou3d_nms_utils.boxes_iou3d_gpu(da, db).cpu().numpy(), O.boxes_iou3d(a, b), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(iou3d_nms_utils.boxes_bev_iou_cpu(a, b), O.boxes_iou_bev(a, b), rtol=1e-4, atol=1e-5)
+    assert iou3d_nms_utils.boxes_bev_iou_cpu(a[:0], b).shape == (0, 220)
+
+
+def test_recall_record_counts_recalled_ground_truth():
+    from toda_amd.pcdet.models.detectors.detector3d_template import Detector3DTemplate
+    gt = torch.from_numpy(rand_boxes(5, 12)).cuda()
+    padded = torch.zeros((2, 15, 8), device="cuda")
+    padded[0, :12, :7], padded[0, :12, 7] = gt, 1
+    padded[1, :5, :7], padded[1, :5, 7] = gt[:5], 1
+    preds = gt.clone()
+    preds[6:, 0] += 100.0                                                      # half of the predictions are far away
+    rec = Detector3DTemplate.generate_recall_record(preds, {}, 0, {"gt_boxes": padded}, [0.3, 0.5, 0.7])
+    assert rec == {"gt": 12, "roi_0.3": 0, "rcnn_0.3": 6, "roi_0.5": 0, "rcnn_0.5": 6, "roi_0.7": 0, "rcnn_0.7": 6}
+    rec = Detector3DTemplate.generate_recall_record(preds[:0], rec, 1, {"gt_boxes": padded}, [0.3, 0.5, 0.7])
+    assert rec["gt"] == 17 and rec["rcnn_0.5"] == 6
+
+
+def test_train_test_pseudo_label_stage2_round_trip(tmp_path):
+    from toda_amd.tools import generate_pseudo_labels as gen
+    from toda_amd.tools import test as tester
+    from toda_amd.tools import train as trainer
+
+    cfg_file = os.path.join(ROOT, "toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml")
+    small = ["DATA_CONFIG.SYNTHETIC.NUM_SAMPLES", "4", "DATA_CONFIG.SYNTHETIC.NUM_POINTS", "20000",
+             "DATA_CONFIG.POINT_CLOUD_RANGE", "[-21.6,-21.6,-5.0,21.6,21.6,4.8]",
+             "MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH", "0.0"]
+    out = str(tmp_path / "out")
+    trainer.main(["--cfg_file", cfg_file, "--epochs", "1", "--batch_size", "2", "--output_dir", out, "--fix_random_seed", "--set"] + small)
+    ckpts = sorted((tmp_path / "out").rglob("checkpoint_epoch_1.pth"))
+    assert len(ckpts) == 1
+    state = torch.load(ckpts[0], map_location="cpu")
+    assert {"epoch", "it", "model_state", "optimizer_state", "version"} <= set(state) and state["it"] == 2
+    assert state["model_state"]["backbone_3d.conv_input.0.weight"].shape == (16, 3, 3, 3, 4)      # spconv-2 layout
+
+    ret = tester.main(["--cfg_file", cfg_file, "--ckpt", str(ckpts[0]), "--batch_size", "2", "--output_dir", out, "--set"] + small)
+    assert "recall/rcnn_0.3" in ret and "car/recall_2m" in ret and 0.0 <= ret["recall/rcnn_0.3"] <= 1.0
+    result = sorted((tmp_path / "out").rglob("result.pkl"))
+    annos = pickle.load(open(result[0], "rb"))
+    assert len(annos) == 4 and {"name", "score", "boxes_lidar", "pred_labels", "frame_id"} <= set(annos[0])
+    assert [a["frame_id"] for a in annos] == [f"syn_{i:06d}" for i in range(4)]
+    assert annos[0]["boxes_lidar"].shape[1] == 7 and len(annos[0]["score"]) == len(annos[0]["name"]) <= 83   # NMS_POST_MAXSIZE
+
+    pseudo = gen.main(["--cfg_file", cfg_file, "--ckpt", str(ckpts[0]), "--pseudo_thresh", "0.05", "--batch_size", "2", "--output_dir", out,
+                       "--set"] + small)
+    infos = pickle.load(open(pseudo, "rb"))
+    assert len(infos) == 4 and all(i["gt_boxes"].shape[1:] == (7,) or i["gt_boxes"].shape == (0, 7) for i in infos)
+    kept = sum(len(i["gt_names"]) for i in infos)
+    total = sum(int((a["score"] > 0.05).sum()) for a in annos)
+    assert kept == total                                                      # same model, same frames, same threshold
+    if kept == 0:
+        pytest.skip("random-init model produced no detection above the threshold")
+    # stage 2 trains on the pseudo labels
+    trainer.main(["--cfg_file", cfg_file, "--epochs", "1", "--batch_size", "2", "--output_dir", str(tmp_path / "stage2"),
+                  "--pretrained_model", str(ckpts[0]), "--set"] + small + ["DATA_CONFIG.PSEUDO_INFO_PATH", str(pseudo)])
+    assert len(sorted((tmp_path / "stage2").rglob("checkpoint_epoch_1.pth"))) == 1

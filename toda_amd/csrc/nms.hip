@@ -112,7 +112,7 @@ __device__ __forceinline__ float iou_bev(const float* a, const float* b) {
 }
 
 __global__ void __launch_bounds__(256)
-iou_matrix_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, float* __restrict__ iou) {
+iou_matrix_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb, float* __restrict__ iou, int area_only) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)na * nb) return;
     const int i = (int)(t / nb), j = (int)(t % nb);
@@ -122,7 +122,7 @@ iou_matrix_kernel(const float* __restrict__ a, int na, const float* __restrict__
         ba[k] = a[(size_t)i * 7 + k];
         bb[k] = b[(size_t)j * 7 + k];
     }
-    iou[t] = iou_bev(ba, bb);
+    iou[t] = area_only ? overlap_area(ba, bb) : iou_bev(ba, bb);
 }
 
 // mask[row * cb + col_block] bit j = IoU(row, col_block*64 + j) > thresh, for j after `row` only
@@ -176,7 +176,16 @@ extern "C" int toda_boxes_iou_bev(const float* boxes_a, int na, const float* box
     TODA_CHECK_ARG(na >= 0 && nb >= 0, "boxes_iou_bev: negative size");
     if (na == 0 || nb == 0) return TODA_OK;
     hipLaunchKernelGGL(iou_matrix_kernel, dim3(cdiv((long long)na * nb, 256)), dim3(256), 0, (hipStream_t)stream, boxes_a, na,
-                       boxes_b, nb, iou);
+                       boxes_b, nb, iou, 0);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_boxes_overlap_bev(const float* boxes_a, int na, const float* boxes_b, int nb, float* overlap, void* stream) {
+    TODA_CHECK_ARG(na >= 0 && nb >= 0, "boxes_overlap_bev: negative size");
+    if (na == 0 || nb == 0) return TODA_OK;
+    hipLaunchKernelGGL(iou_matrix_kernel, dim3(cdiv((long long)na * nb, 256)), dim3(256), 0, (hipStream_t)stream, boxes_a, na,
+                       boxes_b, nb, overlap, 1);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

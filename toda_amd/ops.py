@@ -540,6 +540,16 @@ def boxes_iou_bev(boxes_a, boxes_b):
     return iou
 
 
+def boxes_overlap_bev(boxes_a, boxes_b):
+    """Intersection area of rotated BEV rectangles, [N, 7] x [M, 7] -> [N, M]."""
+    lib = L.load()
+    a, b = boxes_a[:, :7].contiguous().float(), boxes_b[:, :7].contiguous().float()
+    out = torch.zeros((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    rc = lib.toda_boxes_overlap_bev(L.ptr(a), a.shape[0], L.ptr(b), b.shape[0], L.ptr(out), L.stream())
+    L.check(rc, "toda_boxes_overlap_bev")
+    return out
+
+
 def nms_rotated(boxes_sorted, thresh):
     """Greedy rotated NMS over boxes sorted by descending score.  Returns (keep [n] int64 padded,
     n_keep [1] int32), both on the device - no host sync."""

@@ -60,6 +60,30 @@ class DatasetTemplate(torch_data.Dataset):
         data_dict.pop("_rng", None)
         return data_dict
 
+    def generate_prediction_dicts(self, batch_dict, pred_dicts, class_names, output_path=None):
+        """Model output -> per-frame annotation dicts {name, score, boxes_lidar, pred_labels, frame_id} - the record the
+        reference's datasets emit (nuscenes_dataset.py:185-230) and generate_pseudo_label_samples consumes."""
+        annos = []
+        for index, box_dict in enumerate(pred_dicts):
+            scores = box_dict["pred_scores"].detach().cpu().numpy()
+            boxes = box_dict["pred_boxes"].detach().cpu().numpy()
+            labels = box_dict["pred_labels"].detach().cpu().numpy().astype(np.int64)
+            n = scores.shape[0]
+            anno = {"name": np.array(class_names)[labels - 1] if n else np.zeros(0, dtype="<U1"), "score": scores,
+                    "boxes_lidar": boxes[:, :7] if n else np.zeros((0, 7), np.float32), "pred_labels": labels,
+                    "frame_id": batch_dict["frame_id"][index]}
+            if "metadata" in batch_dict:
+                anno["metadata"] = batch_dict["metadata"][index]
+            annos.append(anno)
+            if output_path is not None:
+                np.save(str(output_path / f"{anno['frame_id']}.npy"), np.concatenate([anno["boxes_lidar"], scores[:, None], labels[:, None]], 1))
+        return annos
+
+    def evaluation(self, det_annos, class_names, **kwargs):
+        """Dataset-specific metrics (KITTI / nuScenes / Waymo evaluators) are out of scope; a dataset with ground truth
+        in `self.infos` reports BEV-centre-distance recall / precision here."""
+        return "", {}
+
     @staticmethod
     def collate_batch(batch_list, _unused=False):
         """Concatenate voxels, prepend the batch index to points / voxel_coords, zero-pad gt_boxes

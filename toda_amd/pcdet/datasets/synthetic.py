@@ -6,6 +6,8 @@ after `seed` is fixed.
 Point model: azimuth ~ U(-pi, pi); range r = r_min + (r_max - r_min) * u^1.5 (density falls with
 distance); 70 % ground (z = z_ground + N(0, 0.05)), 20 % structure on 200 vertical segments,
 10 % inside 30 vehicle-sized boxes which are also the gt boxes."""
+from pathlib import Path
+
 import numpy as np
 
 from ..config import AttrDict
@@ -72,14 +74,80 @@ class SyntheticLidarDataset(DatasetTemplate):
         self.num_samples = int(syn.get("NUM_SAMPLES", 64))
         self.seed = int(syn.get("SEED", 0))
         self.num_points = syn.get("NUM_POINTS", None)
+        # pseudo-label round trip (reference nuscenes_dataset.py include_nuscenes_data + INFO_PATH['pseudo']): an infos
+        # pickle written by tools/generate_pseudo_labels.py replaces the frames' ground truth
+        self.pseudo_infos = None
+        if dataset_cfg.get("PSEUDO_INFO_PATH", None):
+            import pickle
+            with open(dataset_cfg.PSEUDO_INFO_PATH, "rb") as f:
+                self.pseudo_infos = {Path(i["lidar_path"]).stem: i for i in pickle.load(f)}
+        self._infos = None
 
     def __len__(self):
         return self.num_samples
 
-    def raw_sample(self, index):
+    @staticmethod
+    def frame_id(index):
+        return f"syn_{index:06d}"
+
+    @property
+    def infos(self):
+        """Per-frame records in the nuScenes infos.pkl shape the reference's pseudo-label writer edits
+        (eval_utils/generate_pseudo_labels.py:12-70): lidar_path (stem = frame id), token, gt_boxes [K,7], gt_names."""
+        if self._infos is None:
+            self._infos = []
+            for index in range(self.num_samples):
+                _, boxes, names = self.raw_sample(index, labels_only=True)
+                self._infos.append({"lidar_path": f"synthetic/{self.frame_id(index)}.bin", "token": self.frame_id(index),
+                                    "gt_boxes": boxes, "gt_names": names})
+        return self._infos
+
+    def dump_infos(self, path):
+        import pickle
+        with open(path, "wb") as f:
+            pickle.dump(self.infos, f)
+
+    def evaluation(self, det_annos, class_names, **kwargs):
+        """Centre-distance matching (<= 2 m in BEV, greedy by score) of predictions against the frames' boxes ->
+        recall / precision per class.  Stands in for the KITTI / nuScenes evaluators (out of scope)."""
+        gt_by_frame = {Path(i["lidar_path"]).stem: i for i in self.infos}
+        tp = {c: 0 for c in class_names}
+        n_gt, n_det = dict(tp), dict(tp)
+        for anno in det_annos:
+            info = gt_by_frame[str(anno["frame_id"])]
+            for c in class_names:
+                gt = np.asarray(info["gt_boxes"]).reshape(-1, 7)[np.asarray(info["gt_names"]) == c]
+                sel = np.asarray(anno["name"]) == c
+                det = anno["boxes_lidar"][sel][np.argsort(-anno["score"][sel])]
+                n_gt[c] += len(gt)
+                n_det[c] += len(det)
+                free = np.ones(len(gt), bool)
+                for d in det:
+                    if not free.any():
+                        break
+                    dist = np.hypot(gt[:, 0] - d[0], gt[:, 1] - d[1])
+                    dist[~free] = np.inf
+                    j = int(dist.argmin())
+                    if dist[j] <= 2.0:
+                        free[j] = False
+                        tp[c] += 1
+        result = {}
+        lines = []
+        for c in class_names:
+            result[f"{c}/recall_2m"] = tp[c] / max(n_gt[c], 1)
+            result[f"{c}/precision_2m"] = tp[c] / max(n_det[c], 1)
+            lines.append(f"{c}: recall@2m {result[f'{c}/recall_2m']:.4f} precision@2m {result[f'{c}/precision_2m']:.4f} "
+                         f"({tp[c]} TP / {n_gt[c]} gt / {n_det[c]} det)")
+        return "\n".join(lines), result
+
+    def raw_sample(self, index, labels_only=False):
         kind = self.kinds[index % len(self.kinds)]
         points, boxes, names = synth_cloud(kind, self.seed + index, self.num_points, class_count=len(self.class_names))
         names = np.array([self.class_names[int(n[3:]) - 1] for n in names])
+        if self.pseudo_infos is not None and not labels_only:
+            info = self.pseudo_infos[self.frame_id(index)]
+            boxes = np.asarray(info["gt_boxes"], dtype=np.float32).reshape(-1, 7)
+            names = np.asarray(info["gt_names"]).reshape(-1)
         c = self.point_feature_encoder.num_point_features
         if points.shape[1] < c:
             raise ValueError(f"{kind} clouds have {points.shape[1]} features, config wants {c}")
@@ -87,7 +155,7 @@ class SyntheticLidarDataset(DatasetTemplate):
 
     def __getitem__(self, index):
         points, boxes, names = self.raw_sample(index)
-        data = {"points": points, "gt_boxes": boxes, "gt_names": names, "frame_id": f"syn_{index:06d}",
+        data = {"points": points, "gt_boxes": boxes, "gt_names": names, "frame_id": self.frame_id(index),
                 "_rng": np.random.default_rng(10_000_019 * (self.seed + 1) + index)}
         return self.prepare_data(data)
 

@@ -24,4 +24,10 @@ class CenterPoint(Detector3DTemplate):
         return loss_rpn, {"loss_rpn": loss_rpn.detach(), **tb_dict}, {}
 
     def post_processing(self, batch_dict):
-        return batch_dict["final_box_dicts"], {}
+        """The head already decoded + NMS-ed (final_box_dicts); add the recall record (reference centerpoint.py:49-63)."""
+        final = batch_dict["final_box_dicts"]
+        recall_dict = {}
+        thresholds = self.model_cfg.POST_PROCESSING.RECALL_THRESH_LIST
+        for index in range(batch_dict["batch_size"]):
+            recall_dict = self.generate_recall_record(final[index]["pred_boxes"], recall_dict, index, batch_dict, thresholds)
+        return final, recall_dict

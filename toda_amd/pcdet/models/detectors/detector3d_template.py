@@ -123,6 +123,61 @@ class Detector3DTemplate(nn.Module):
     def forward(self, **kwargs):
         raise NotImplementedError
 
+    # ------------------------------------------------------------- evaluation
+    def post_processing(self, batch_dict):
+        """Single-head, class-agnostic-NMS branch of the reference (detector3d_template.py:178-284): per sample sigmoid
+        scores -> best class -> rotated NMS on the device -> pred dicts, plus the recall record."""
+        from ..model_utils import model_nms_utils
+
+        cfg = self.model_cfg.POST_PROCESSING
+        if cfg.NMS_CONFIG.get("MULTI_CLASSES_NMS", False) or isinstance(batch_dict["batch_cls_preds"], list):
+            raise NotImplementedError("multi-class / multi-head NMS is not on this path")
+        recall_dict, pred_dicts = {}, []
+        for index in range(batch_dict["batch_size"]):
+            if batch_dict.get("batch_index", None) is not None:
+                pick = batch_dict["batch_index"] == index
+            else:
+                pick = index
+            box_preds = batch_dict["batch_box_preds"][pick]
+            raw_cls = batch_dict["batch_cls_preds"][pick]
+            cls_preds = raw_cls if batch_dict["cls_preds_normalized"] else torch.sigmoid(raw_cls)
+            scores, labels = torch.max(cls_preds, dim=-1)
+            labels = labels + 1
+            selected, selected_scores = model_nms_utils.class_agnostic_nms(box_scores=scores, box_preds=box_preds,
+                                                                           nms_config=cfg.NMS_CONFIG, score_thresh=cfg.SCORE_THRESH)
+            if cfg.get("OUTPUT_RAW_SCORE", False):
+                selected_scores = torch.max(raw_cls, dim=-1)[0][selected]
+            final_boxes = box_preds[selected]
+            recall_dict = self.generate_recall_record(final_boxes, recall_dict, index, batch_dict, cfg.RECALL_THRESH_LIST)
+            pred_dicts.append({"pred_boxes": final_boxes, "pred_scores": selected_scores, "pred_labels": labels[selected]})
+        return pred_dicts, recall_dict
+
+    @staticmethod
+    def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+        """#gt boxes whose best 3-D IoU with a prediction exceeds each threshold (reference :286-328); trailing all-zero
+        rows of the padded gt tensor are ignored, as there."""
+        from ...ops.iou3d_nms import iou3d_nms_utils
+
+        if "gt_boxes" not in data_dict:
+            return recall_dict
+        if len(recall_dict) == 0:
+            recall_dict = {"gt": 0}
+            for t in thresh_list:
+                recall_dict[f"roi_{t}"] = 0
+                recall_dict[f"rcnn_{t}"] = 0
+        gt = data_dict["gt_boxes"][batch_index]
+        k = gt.shape[0] - 1
+        while k > 0 and float(gt[k].sum()) == 0:
+            k -= 1
+        gt = gt[:k + 1]
+        if gt.shape[0] > 0:
+            if box_preds.shape[0] > 0:
+                best = iou3d_nms_utils.boxes_iou3d_gpu(box_preds[:, 0:7].contiguous(), gt[:, 0:7].contiguous()).max(dim=0)[0]
+                for t in thresh_list:
+                    recall_dict[f"rcnn_{t}"] += int((best > t).sum().item())
+            recall_dict["gt"] += gt.shape[0]
+        return recall_dict
+
     # ------------------------------------------------------------- checkpoints
     def _load_state_dict(self, model_state_disk, *, strict=True):
         """Accept spconv-1.x weights [kz,ky,kx,Cin,Cout] into our spconv-2.x [Cout,kz,ky,kx,Cin]

@@ -13,7 +13,7 @@ class SECONDNet(Detector3DTemplate):
         if self.training:
             loss_rpn, tb_dict = self.dense_head.get_loss()
             return {"loss": loss_rpn}, {"loss_rpn": loss_rpn.detach(), **tb_dict}, {}
-        return batch_dict, {}
+        return self.post_processing(batch_dict)
 
 
 class PointPillar(SECONDNet):

@@ -103,3 +103,20 @@ def rotate_points_along_z(points, angle):
     xyz = torch.matmul(points[:, :, 0:3], rot)
     out = torch.cat((xyz, points[:, :, 3:]), dim=-1)
     return out.numpy() if is_numpy else out
+
+
+def merge_results_dist(result_part, size, tmpdir=None):
+    """Gather per-rank result lists in dataset order (reference common_utils.py:205-238 does this through pickles in a
+    shared tmpdir; here one all_gather_object over the process group).  The evaluation sampler deals indices round
+    robin, so parts are interleaved and the padded tail is cut at `size`."""
+    rank, world = get_dist_info()
+    if world == 1:
+        return result_part[:size]
+    parts = [None] * world
+    dist.all_gather_object(parts, result_part)
+    if rank != 0:
+        return None
+    ordered = []
+    for group in zip(*parts):
+        ordered.extend(group)
+    return ordered[:size]

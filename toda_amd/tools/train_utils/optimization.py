@@ -120,7 +120,7 @@ class OneCycle:
     def values(self, step):
         lr, mom = self.optimizer.lr, self.optimizer.mom
         for start, end, lr0, lr1, m0, m1 in self.phases:
-            if step >= start:
+            if step >= start and end > start:  # an empty warm-up phase (tiny runs) is skipped instead of dividing by zero
                 pct = (step - start) / (end - start)
                 lr, mom = annealing_cos(lr0, lr1, pct), annealing_cos(m0, m1, pct)
         return lr, mom

@@ -252,6 +252,12 @@ int toda_rows_select_append(const float* src, int n, const int32_t* n_dev, int c
 /* dst[:, 0:2] = fp32(rotation of (x, y) in fp64 by (cosv, sinv)), z and column 3 copied, columns >= 4 zeroed */
 int toda_points_rotate_z(const float* src, int n, const int32_t* n_dev, int c, double cosv, double sinv,
                          float* dst, void* stream);
+/* Global augmentations in one pass, in the reference's order and fp32 arithmetic (pcdet/datasets/augmentor/
+ * augmentor_utils.py:8-81 random_flip_along_x / _y, global_rotation, global_scaling): flip_x: y -> -y; flip_y: x -> -x;
+ * rotate: (x, y) -> (x c - y s, x s + y c); rescale: xyz *= scale.  dst may alias src. */
+int toda_points_world_transform(const float* src, int n, const int32_t* n_dev, int c, int flip_x, int flip_y,
+                                int rotate, float cosv, float sinv, int rescale, float scale, float* dst,
+                                void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,7 +47,7 @@ def setup():
     cu.points_in_boxes_cpu = points_in_boxes_cpu
     iu.boxes_iou_bev_cpu = boxes_iou_bev_cpu
     CR._load("pcdet.datasets.augmentor.augmentor_utils", "pcdet/datasets/augmentor/augmentor_utils.py")
-    M = {}
+    M = {"augmentor_utils": sys.modules["pcdet.datasets.augmentor.augmentor_utils"]}
     for name in ("inter_domain_point_cutmix", "inter_domain_point_polarmix", "inter_domain_point_lasermix",
                  "intra_domain_point_mixup"):
         M[name] = CR._load(f"pcdet.datasets.processor.{name}", f"pcdet/datasets/processor/{name}.py")
@@ -99,6 +99,20 @@ def main():
         np.random.seed(seed)
         out = M["inter_domain_point_lasermix"].inter_domain_point_lasermix(copy(src), copy(tgt), None, areas, angles, PC_RANGE, inc)
         save(name, src, tgt, out, seed=seed, num_areas=areas, num_angles=angles, inc=inc)
+
+    # global augmentations (augmentor_utils.py:8-81): flip x, flip y, rotation, scaling on one scene, seeded
+    sc = scene("nuscenes_toda", 51, 3000, 10)
+    au = M["augmentor_utils"]
+    np.random.seed(505)
+    boxes, pts = sc["gt_boxes"][:, :7].copy(), sc["points"].copy()
+    stages = {}
+    for tag, fn in [("flip_x", lambda b, p: au.random_flip_along_x(b, p)), ("flip_y", lambda b, p: au.random_flip_along_y(b, p)),
+                    ("rot", lambda b, p: au.global_rotation(b, p, [-0.78539816, 0.78539816])),
+                    ("scale", lambda b, p: au.global_scaling(b, p, [0.95, 1.05]))]:
+        boxes, pts = fn(boxes, pts)
+        stages[f"boxes_{tag}"], stages[f"points_{tag}"] = boxes.copy(), np.asarray(pts, np.float32).copy()
+    np.savez_compressed(os.path.join(OUT, "aug_world.npz"), in_points=sc["points"], in_boxes=sc["gt_boxes"][:, :7], seed=505, **stages)
+    print("aug_world", {k: v.shape for k, v in stages.items() if k.startswith("points")})
 
     d1, d2 = scene("nuscenes_toda", 41, 5000, 12), scene("nuscenes_toda", 42, 4000, 40)
     for name, seed, fn in [("mixup", 401, "intra_domain_point_mixup"), ("mixup_cd", 402, "intra_domain_point_mixup_cd")]:

@@ -93,3 +93,55 @@ def test_oracle_iou3d_hand_cases():
 def test_merge_results_single_process():
     from toda_amd.pcdet.utils.common_utils import merge_results_dist
     assert merge_results_dist([1, 2, 3, 4], 3) == [1, 2, 3]
+
+
+def _run_world_augs(points):
+    """The four global augmentations in the order of tests/golden/capture_mix.py, same numpy seed."""
+    from toda_amd.pcdet.datasets.augmentor import augmentor_utils as au
+    z = np.load(os.path.join(ROOT, "tests/golden/aug_world.npz"))
+    np.random.seed(int(z["seed"]))
+    boxes = z["in_boxes"].copy()
+    out = {}
+    for tag, fn in [("flip_x", lambda b, p: au.random_flip_along_x(b, p)), ("flip_y", lambda b, p: au.random_flip_along_y(b, p)),
+                    ("rot", lambda b, p: au.global_rotation(b, p, [-0.78539816, 0.78539816])),
+                    ("scale", lambda b, p: au.global_scaling(b, p, [0.95, 1.05]))]:
+        boxes, points = fn(boxes, points)
+        out[tag] = (boxes.copy(), points.copy() if isinstance(points, np.ndarray) else points.clone())
+    return z, out
+
+
+def test_world_augmentations_host_path_matches_reference():
+    z = np.load(os.path.join(ROOT, "tests/golden/aug_world.npz"))
+    z, out = _run_world_augs(z["in_points"].copy())
+    assert not np.array_equal(z["points_flip_y"], z["in_points"])          # the seeded run really flips
+    for tag, (boxes, pts) in out.items():
+        np.testing.assert_array_equal(boxes, z[f"boxes_{tag}"])
+        np.testing.assert_array_equal(np.asarray(pts), z[f"points_{tag}"])
+
+
+def test_data_augmentor_records_what_it_did():
+    from toda_amd.pcdet.config import AttrDict
+    from toda_amd.pcdet.datasets.augmentor.data_augmentor import DataAugmentor
+    cfg = AttrDict({"AUG_CONFIG_LIST": [AttrDict({"NAME": "random_world_flip", "ALONG_AXIS_LIST": ["x", "y"]}),
+                                        AttrDict({"NAME": "random_world_rotation", "WORLD_ROT_ANGLE": [-0.3925, 0.3925]}),
+                                        AttrDict({"NAME": "random_world_scaling", "WORLD_SCALE_RANGE": [0.95, 1.05]})],
+                    "DISABLE_AUG_LIST": ["placeholder"]})
+    aug = DataAugmentor(None, cfg, ["car"])
+    np.random.seed(1)
+    pts = np.random.rand(50, 4).astype(np.float32)
+    boxes = np.array([[1, 2, 0, 4, 2, 1.5, 3.0], [3, -1, 0, 4, 2, 1.5, -3.0]], np.float32)
+    d = aug.forward({"points": pts.copy(), "gt_boxes": boxes.copy(), "gt_names": np.array(["car", "bus"]),
+                     "gt_boxes_mask": np.array([True, False])})
+    assert d["augmentation_list"] == ["random_world_flip", "random_world_rotation", "random_world_scaling"]
+    assert set(d["augmentation_params"]["random_world_flip"]) <= {"x", "y"} and 0.95 <= d["augmentation_params"]["random_world_scaling"] <= 1.05
+    assert d["gt_boxes"].shape == (1, 7) and d["gt_names"].tolist() == ["car"] and abs(d["gt_boxes"][0, 6]) <= np.pi
+    # undoing the recorded transforms restores the cloud
+    p = d["points"][:, :3] / np.float32(d["augmentation_params"]["random_world_scaling"])
+    a = -d["augmentation_params"]["random_world_rotation"]
+    rot = np.array([[np.cos(a), np.sin(a), 0], [-np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    p = p @ rot
+    if "y" in d["augmentation_params"]["random_world_flip"]:
+        p[:, 0] = -p[:, 0]
+    if "x" in d["augmentation_params"]["random_world_flip"]:
+        p[:, 1] = -p[:, 1]
+    np.testing.assert_allclose(p, pts[:, :3], atol=1e-5)

@@ -216,3 +216,21 @@ def test_mix_dataset_item_matches_the_host_pipeline():
     assert batch["points"].is_cuda and batch["points"].shape[1] == 5 and batch["points_per_sample"][0] == p.shape[0]
     voxelize_on_gpu(batch, ds.voxel_cfg)
     assert batch["voxel_coords"].shape[0] > 20000 and int(batch["voxel_coords"][:, 0].max()) == 1
+
+
+def test_world_augmentations_on_the_device_match_reference():
+    """Flips are exact; rotation / scaling agree with the reference's fp32 torch / numpy result to 1 ulp-level tolerance
+    (the CPU matmul's summation order is not observable)."""
+    from tests.test_eval_host import ROOT, _run_world_augs
+    import os
+    z = np.load(os.path.join(ROOT, "tests/golden/aug_world.npz"))
+    z, out = _run_world_augs(dev(z["in_points"].copy()))
+    for tag, (boxes, pts) in out.items():
+        assert pts.is_cuda
+        np.testing.assert_array_equal(boxes, z[f"boxes_{tag}"])
+        got, want = pts.cpu().numpy(), z[f"points_{tag}"]
+        if tag.startswith("flip"):
+            np.testing.assert_array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=3e-7, atol=2e-6)
+        np.testing.assert_array_equal(got[:, 3], z["in_points"][:, 3])

@@ -170,6 +170,30 @@ points_rotate_z_kernel(const float* __restrict__ src, int n, const int32_t* __re
     for (int ch = 4; ch < c; ++ch) q[ch] = 0.f;
 }
 
+// Global augmentations of a cloud in one pass, applied in the reference's order with fp32 arithmetic
+// (augmentor_utils.py:8-81): flip along x (y -> -y), flip along y (x -> -x), rotation about z
+// (row vector times [[c, s], [-s, c]], c / s are fp32 values), uniform scaling of x, y, z.
+__global__ void __launch_bounds__(PT_BLOCK)
+points_world_transform_kernel(const float* __restrict__ src, int n, const int32_t* __restrict__ n_dev, int c, int flip_x,
+                              int flip_y, int rotate, float cosv, float sinv, int rescale, float scale, float* __restrict__ dst) {
+    const int rows = eff_n(n, n_dev);
+    const int j = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (j >= rows) return;
+    const float* p = src + (size_t)j * c;
+    float x = p[0], y = p[1], z = p[2];
+    if (flip_x) y = -y;
+    if (flip_y) x = -x;
+    if (rotate) {
+        const float nx = x * cosv + y * (-sinv);
+        const float ny = x * sinv + y * cosv;
+        x = nx, y = ny;
+    }
+    if (rescale) x *= scale, y *= scale, z *= scale;
+    float* q = dst + (size_t)j * c;
+    q[0] = x, q[1] = y, q[2] = z;
+    for (int ch = 3; ch < c; ++ch) q[ch] = p[ch];
+}
+
 }  // namespace toda
 
 using namespace toda;
@@ -259,6 +283,15 @@ extern "C" int toda_points_rotate_z(const float* src, int n, const int32_t* n_de
                                     void* stream) {
     PT_COMMON_CHECK("points_rotate_z");
     hipLaunchKernelGGL(points_rotate_z_kernel, dim3(cdiv(n, PT_BLOCK)), dim3(PT_BLOCK), 0, s, src, n, n_dev, c, cosv, sinv, dst);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_points_world_transform(const float* src, int n, const int32_t* n_dev, int c, int flip_x, int flip_y,
+                                           int rotate, float cosv, float sinv, int rescale, float scale, float* dst, void* stream) {
+    PT_COMMON_CHECK("points_world_transform");
+    hipLaunchKernelGGL(points_world_transform_kernel, dim3(cdiv(n, PT_BLOCK)), dim3(PT_BLOCK), 0, s, src, n, n_dev, c, flip_x, flip_y,
+                       rotate, cosv, sinv, rescale, scale, dst);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

@@ -625,6 +625,18 @@ def points_rotate_z(points, cosv, sinv, n_dev=None):
     return out
 
 
+def points_world_transform(points, flip_x=False, flip_y=False, rot=None, scale=None, n_dev=None, out=None):
+    """Flip / rotate about z (rot = (cos, sin) as fp32 values) / scale in one pass; returns a new table unless out is given."""
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    out = torch.empty_like(points) if out is None else out
+    cs, sn = (float(rot[0]), float(rot[1])) if rot is not None else (1.0, 0.0)
+    rc = lib.toda_points_world_transform(L.ptr(points), n, nd, c, int(bool(flip_x)), int(bool(flip_y)), int(rot is not None), cs, sn,
+                                         int(scale is not None), float(scale if scale is not None else 1.0), L.ptr(out), L.stream())
+    L.check(rc, "toda_points_world_transform")
+    return out
+
+
 class RowBuffer:
     """A point table under construction on the device: rows are appended by stable selection at a device-side
     cursor, so a whole mix runs without a host round trip; `finish()` reads the row count (one sync)."""

@@ -24,7 +24,10 @@ class DatasetTemplate(torch_data.Dataset):
         self.point_cloud_range = np.array(dataset_cfg.POINT_CLOUD_RANGE, dtype=np.float32)
         self.point_feature_encoder = PointFeatureEncoder(dataset_cfg.POINT_FEATURE_ENCODING,
                                                          point_cloud_range=self.point_cloud_range)
-        self.data_augmentor = None  # host-side augmentation is out of scope
+        self.data_augmentor = None
+        if training and dataset_cfg.get("DATA_AUGMENTOR", None) is not None:
+            from .augmentor.data_augmentor import DataAugmentor
+            self.data_augmentor = DataAugmentor(root_path, dataset_cfg.DATA_AUGMENTOR, self.class_names, logger=logger)
         self.data_processor = DataProcessor(dataset_cfg.DATA_PROCESSOR, point_cloud_range=self.point_cloud_range,
                                             training=training,
                                             num_point_features=self.point_feature_encoder.num_point_features)
@@ -46,6 +49,9 @@ class DatasetTemplate(torch_data.Dataset):
 
     def prepare_data(self, data_dict):
         """gt filtering by class -> class-id column -> feature encoding -> processor queue."""
+        if self.training and self.data_augmentor is not None and data_dict.get("gt_boxes") is not None:
+            mask = np.array([n in self.class_names for n in data_dict["gt_names"]], dtype=bool)      # reference :127-135
+            data_dict = self.data_augmentor.forward({**data_dict, "gt_boxes_mask": mask})
         if data_dict.get("gt_boxes") is not None:
             names = data_dict["gt_names"]
             keep = np.array([n in self.class_names for n in names], dtype=bool)

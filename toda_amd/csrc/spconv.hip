@@ -255,21 +255,27 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
     }
 }
 
+#ifndef GG_LDS_WAVES_WIDE
+#define GG_LDS_WAVES_WIDE 4   // 512-thread blocks of the 128-channel variant: 2 blocks x 8 waves per CU
+#endif
+#ifndef GG_LDS_WAVES
+#define GG_LDS_WAVES 4   // waves per SIMD asked of the compiler for the <= 64-channel LDS variants (97+32 registers otherwise: 3)
+#endif
 // LDS-staged variant: the offset's weight slice (Q*NT KiB) is loaded ONCE per workgroup and offset
 // into a double-buffered LDS image and read by the 4 waves with ds_read_b128, instead of every wave
 // streaming it through L1 (4x less vector-memory traffic: with per-wave weight loads the CU's
 // 64 B/clk L1 path, not the MFMA pipe, sets the pace - measured 59 % matrix-pipe utilisation).
 // One barrier per offset; waves still skip the MFMAs of offsets without a neighbour in their rows.
-template <int Q, int NT, int RT, bool VEC, bool DB = true>
-__global__ void __launch_bounds__(SC_BLOCK)
+template <int Q, int NT, int RT, bool VEC, bool DB = true, int BLK = SC_BLOCK>
+__global__ void __launch_bounds__(BLK, (Q * NT * RT <= 32 && Q * NT <= 16) ? GG_LDS_WAVES : (BLK > SC_BLOCK ? GG_LDS_WAVES_WIDE : 1))
 gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                        const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
                        float* __restrict__ out) {
     constexpr int SLICE = Q * NT * 64;                    // float4 per offset
-    constexpr int PER_THREAD = (SLICE + SC_BLOCK - 1) / SC_BLOCK;
+    constexpr int PER_THREAD = (SLICE + BLK - 1) / BLK;
     __shared__ f32x4 wl[DB ? 2 : 1][SLICE];  // DB = false: one 64 KiB buffer (128-channel layers), two barriers per offset
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (SC_BLOCK / 64) + (threadIdx.x >> 6);
+    const int wave = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int row0 = wave * (16 * RT);
     const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
@@ -294,7 +300,7 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
     // stage offset 0
 #pragma unroll
     for (int t = 0; t < PER_THREAD; ++t) {
-        const int e = t * SC_BLOCK + threadIdx.x;
+        const int e = t * BLK + threadIdx.x;
         if (e < SLICE) wl[0][e] = wp4[e];
     }
     __syncthreads();
@@ -306,7 +312,7 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
         if (k + 1 < K) {
 #pragma unroll
             for (int t = 0; t < PER_THREAD; ++t) {
-                const int e = t * SC_BLOCK + threadIdx.x;
+                const int e = t * BLK + threadIdx.x;
                 if (e < SLICE) stage[t] = wp4[(size_t)(k + 1) * SLICE + e];
             }
         }
@@ -345,7 +351,7 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
         if (k + 1 < K) {
 #pragma unroll
             for (int t = 0; t < PER_THREAD; ++t) {
-                const int e = t * SC_BLOCK + threadIdx.x;
+                const int e = t * BLK + threadIdx.x;
                 if (e < SLICE) wl[DB ? (cur ^ 1) : 0][e] = stage[t];
             }
         }
@@ -389,8 +395,11 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
 // loads in flight.  The channel interleave of the forward kernel makes the operand loads
 // MTB/NTB-wide vector loads.  Partial sums go to a slab per chunk (plain stores) and a second
 // kernel adds the slabs in fixed order: deterministic, no float atomics.
+#ifndef WG_WAVES
+#define WG_WAVES 4
+#endif
 template <int MTB, int NTB>
-__global__ void __launch_bounds__(SC_BLOCK)
+__global__ void __launch_bounds__(SC_BLOCK, (MTB * NTB <= 16) ? WG_WAVES : 1)
 wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __restrict__ dout, int cout,
              const int* __restrict__ nbr, int n_out, int K, int rows_per_chunk, int MT, int NT, int nsub_n,
              float* __restrict__ slab) {
@@ -604,11 +613,17 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
     static const int env_lds_raw = getenv("TODA_GG_LDS") ? atoi(getenv("TODA_GG_LDS")) : 1;
     const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);
     const bool vec_ok = (c_gather & 3) == 0;
-    static const int env_lds88 = getenv("TODA_GG_LDS88") ? atoi(getenv("TODA_GG_LDS88")) : 1;  // 1: RT=1 single-buffer LDS (0.67 ms), 2: RT=2 (0.76), 0: registers-only RT=2 (0.70) on 97.5k x 27 x 128 x 128
+    static const int env_lds88 = getenv("TODA_GG_LDS88") ? atoi(getenv("TODA_GG_LDS88")) : 3;  // 1: RT=1 single-buffer LDS (0.67 ms), 2: RT=2 (0.76), 0: registers-only RT=2 (0.70) on 97.5k x 27 x 128 x 128
     if (env_lds88 && vec_ok && Q == 8 && NT == 8) {
         if (env_lds88 == 2)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)),
                                dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
+        else if (env_lds88 == 3)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false, 512>), dim3(cdiv(cdiv(n_out, 16), 8)),
+                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
+        else if (env_lds88 == 4)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false, 512>), dim3(cdiv(cdiv(n_out, 32), 8)),
+                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
                                dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtoda_hip.so")
+LIB_PATH = os.environ.get("TODA_HIP_LIB") or os.path.join(_HERE, "libtoda_hip.so")   # env override: A/B of kernel builds
 
 _vp, _i, _sz, _dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_double
 

@@ -49,6 +49,8 @@ class BaseBEVBackbone(nn.Module):
 
     def forward(self, data_dict):
         x = data_dict["spatial_features"]
+        if getattr(self, "dense_channels_last", False):
+            x = x.contiguous(memory_format=torch.channels_last)
         h0 = x.shape[2]
         ups = []
         for lvl, block in enumerate(self.blocks):

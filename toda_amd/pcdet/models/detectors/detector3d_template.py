@@ -45,7 +45,22 @@ class Detector3DTemplate(nn.Module):
         for name in self.module_topology:
             module, info = getattr(self, f"build_{name}")(model_info_dict=info)
             self.add_module(name, module)
+        self.apply_dense_layout()
         return info["module_list"]
+
+    def apply_dense_layout(self):
+        """Opt-in (TODA_DENSE_CHANNELS_LAST=1): run the dense 2-D part (BEV neck + head) in channels-last memory format
+        with MIOpen's find mode on.  Isolated, the neck + head fwd+bwd drops from 13.5 to 12.1 ms at 2 x 256 x 188 x 188
+        (either switch alone does not help), but inside the full C3 / C5 step the gain is within noise (27.1 vs 27.4 ms,
+        37.6 vs 37.3 ms), so NCHW stays the default."""
+        if os.environ.get("TODA_DENSE_CHANNELS_LAST", "0") != "1":
+            return
+        torch.backends.cudnn.benchmark = True
+        for name in ("backbone_2d", "dense_head"):
+            module = getattr(self, name, None)
+            if module is not None:
+                module.to(memory_format=torch.channels_last)
+                module.dense_channels_last = True
 
     def _section(self, key):
         return self.model_cfg.get(key, None)

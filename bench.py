@@ -225,13 +225,13 @@ def run_gpu(args, rank, world, device):
 
 def pmc_traffic(d):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (separate FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_pmc_*.json); None
+    (separate FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_e_pmc_*.json); None
     when no profiled launch shape matches (PMC counters cannot be read from inside bench.py)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_gather_gemm_64x64.json")
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_gather_gemm_64x64.json")
     if not os.path.exists(path) or (d["c_gather"], d["c_produce"], d["K"]) != (64, 64, 27):
         return None
     for shape in json.load(open(path))["launch_shapes"]:
-        if 0 <= shape["rows_upper"] - d["n_out"] < 1024:
+        if 0 <= shape["grid_threads"] // 2 - d["n_out"] < 1024:      # 64 lanes per 32-row tile -> 2 threads per row
             return shape["hbm_bytes"]
     return None
 

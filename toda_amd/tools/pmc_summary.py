@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Fold rocprofv3 --pmc counter_collection CSVs into the per-launch-shape summary bench.py reads for `roofline.traffic`.
+    pmc_summary.py <kernel substring> <out.json> <counter_collection.csv> [more csv ...]
+Every CSV comes from its own pass (one --pmc set per run, as MI355X_MICROARCH.md prescribes).  Counters are averaged
+per (kernel, grid size); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction of the guide's HBM section)."""
+import collections
+import csv
+import json
+import sys
+
+
+def main():
+    pattern, out = sys.argv[1], sys.argv[2]
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = set()
+    for path in sys.argv[3:]:
+        for r in csv.DictReader(open(path)):
+            if pattern not in r["Kernel_Name"]:
+                continue
+            names.add(r["Kernel_Name"].split("(")[0])
+            acc[int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    shapes = []
+    for grid, counters in sorted(acc.items()):
+        row = {"grid_threads": grid, "dispatches": max(len(v) for v in counters.values())}
+        for name, vals in sorted(counters.items()):
+            row[name] = sum(vals) / len(vals)
+        if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
+            row["hbm_bytes"] = int((2 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in row and "SQ_BUSY_CU_CYCLES" in row:
+            row["mfma_pipe_busy"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * row["SQ_BUSY_CU_CYCLES"])
+        shapes.append(row)
+    json.dump({"kernel": sorted(names), "note": "one rocprofv3 --pmc pass per counter set over `python bench.py --steps 2 --warmup 2 "
+               "--no-cpu-baseline`; FETCH_SIZE / WRITE_SIZE in KiB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+               "launch_shapes": shapes}, open(out, "w"), indent=1)
+    for s in shapes:
+        print(s)
+
+
+if __name__ == "__main__":
+    main()

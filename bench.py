@@ -89,36 +89,55 @@ def make_device_pair_batches(dataset, per_gpu, n_batches, rank, device):
 
 
 class KernelTimer:
-    """HIP-event timing of one operator family on the current stream (the stream the C ABI is
-    launched on).  Wraps toda_amd.ops.gather_gemm: label = (rows, K, c_in, c_out)."""
+    """Per-launch durations of the gather-GEMM kernels inside the timed region.  The library stamps a start / stop
+    event pair on each kernel dispatch (toda_timing_begin / toda_timing_end, hipExtLaunchKernelGGL), so a duration is the
+    kernel's own - the number rocprofv3 --kernel-trace reports - and no host sync happens while the clock runs.
+    ops.gather_gemm is wrapped only to remember each launch's shape in launch order."""
+
+    CAPACITY = 4096
 
     def __init__(self):
-        self.records = []
-        self.enabled = False
+        self.records = []          # (nbr table, n_src, c_gather, c_produce) in launch order
+        self.ms = []
+        self._enabled = False
         self._orig = ops.gather_gemm
 
-        def timed(feat, wp, nbr, c_produce, bias=None):
-            if not self.enabled:
-                return self._orig(feat, wp, nbr, c_produce, bias)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = self._orig(feat, wp, nbr, c_produce, bias)
-            e1.record()
-            self.records.append((e0, e1, nbr, feat.shape[0], feat.shape[1], c_produce))
-            return out
+        def labelled(feat, wp, nbr, c_produce, bias=None):
+            if self._enabled and len(self.records) < self.CAPACITY:
+                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+            return self._orig(feat, wp, nbr, c_produce, bias)
 
-        ops.gather_gemm = timed
+        ops.gather_gemm = labelled
+
+    @property
+    def enabled(self):
+        return self._enabled
+
+    @enabled.setter
+    def enabled(self, on):
+        from toda_amd import lib as L
+        lib = L.load()
+        if on and not self._enabled:
+            L.check(lib.toda_timing_begin(self.CAPACITY), "toda_timing_begin")
+        elif not on and self._enabled:
+            import ctypes
+            buf = (ctypes.c_float * self.CAPACITY)()
+            seen = ctypes.c_int(0)
+            L.check(lib.toda_timing_end(ctypes.cast(buf, ctypes.c_void_p), self.CAPACITY, ctypes.cast(ctypes.pointer(seen), ctypes.c_void_p)),
+                    "toda_timing_end")
+            self.ms = list(buf[:min(seen.value, self.CAPACITY, len(self.records))])
+        self._enabled = bool(on)
 
     def summary(self):
         """Per launch shape: mean ms, algorithmic bytes and flops (valid pairs counted exactly)."""
         groups, pair_cache = {}, {}
-        for e0, e1, nbr, n_src, cg, cp in self.records:
+        for (nbr, n_src, cg, cp), ms in zip(self.records, self.ms):
             key = (nbr.data_ptr(), n_src, cg, cp)
             if nbr.data_ptr() not in pair_cache:
                 pair_cache[nbr.data_ptr()] = int((nbr >= 0).sum().item())
             g = groups.setdefault(key, {"ms": [], "pairs": pair_cache[nbr.data_ptr()], "n_out": nbr.shape[1],
                                         "K": nbr.shape[0], "n_src": n_src, "cg": cg, "cp": cp})
-            g["ms"].append(e0.elapsed_time(e1))
+            g["ms"].append(ms)
         return groups
 
 

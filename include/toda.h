@@ -259,6 +259,16 @@ int toda_points_world_transform(const float* src, int n, const int32_t* n_dev, i
                                 int rotate, float cosv, float sinv, int rescale, float scale, float* dst,
                                 void* stream);
 
+/* ------------------------------------------------------------------------
+ * Instrumentation (no counterpart in the reference): per-launch durations of the gather-GEMM kernels, taken
+ * from start / stop events stamped on the kernel dispatch itself (hipExtLaunchKernelGGL), i.e. the number
+ * rocprofv3 --kernel-trace reports.  toda_timing_begin arms up to `capacity` launches of
+ * toda_spconv_gather_gemm (process-wide, one stream at a time); toda_timing_end waits for them and returns the
+ * milliseconds in launch order (*n_out = launches seen).
+ * ---------------------------------------------------------------------- */
+int toda_timing_begin(int capacity);
+int toda_timing_end(float* ms_out_host, int cap, int* n_out_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,10 @@
 
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
+#include <vector>
+
 #include "common.h"
 
 namespace toda {
@@ -590,6 +594,58 @@ extern "C" int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int 
     return TODA_OK;
 }
 
+// ---- optional per-launch timestamps of the gather-GEMM kernels -------------------------------
+// hipExtLaunchKernelGGL stamps a start / stop event pair on the kernel dispatch itself, so the
+// elapsed time is the kernel's own duration (what rocprofv3 --kernel-trace reports).  Events
+// recorded around a launch with hipEventRecord also time the cache write-back their release
+// fence triggers (measured +60 us on the 64->64 level).  Used by bench.py for `roofline`.
+namespace toda {
+struct LaunchTimer {
+    std::vector<hipEvent_t> ev;   // start0, stop0, start1, stop1, ...
+    int used = 0;
+    bool on = false;
+};
+static LaunchTimer g_timer;
+static inline void timer_next(hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (!g_timer.on || 2 * (g_timer.used + 1) > (int)g_timer.ev.size()) return;
+    *start = g_timer.ev[2 * g_timer.used];
+    *stop = g_timer.ev[2 * g_timer.used + 1];
+    g_timer.used++;
+}
+}  // namespace toda
+
+#define GG_LAUNCH(kernel, grid, block, shmem, stream, ...)                                              \
+    do {                                                                                               \
+        hipEvent_t t0_, t1_;                                                                           \
+        toda::timer_next(&t0_, &t1_);                                                                  \
+        hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, t0_, t1_, 0, __VA_ARGS__);           \
+    } while (0)
+
+extern "C" int toda_timing_begin(int capacity) {
+    TODA_CHECK_ARG(capacity > 0 && capacity <= (1 << 20), "timing_begin: capacity in (0, 2^20]");
+    for (hipEvent_t e : g_timer.ev) (void)hipEventDestroy(e);
+    g_timer.ev.assign((size_t)2 * capacity, nullptr);
+    for (auto& e : g_timer.ev) TODA_HIP(hipEventCreate(&e));
+    g_timer.used = 0;
+    g_timer.on = true;
+    return TODA_OK;
+}
+
+extern "C" int toda_timing_end(float* ms_out, int cap, int* n_out) {
+    g_timer.on = false;
+    const int n = g_timer.used < cap ? g_timer.used : cap;
+    for (int i = 0; i < n; ++i) {
+        TODA_HIP(hipEventSynchronize(g_timer.ev[2 * i + 1]));
+        TODA_HIP(hipEventElapsedTime(&ms_out[i], g_timer.ev[2 * i], g_timer.ev[2 * i + 1]));
+    }
+    if (n_out) *n_out = g_timer.used;
+    for (hipEvent_t e : g_timer.ev) (void)hipEventDestroy(e);
+    g_timer.ev.clear();
+    g_timer.used = 0;
+    return TODA_OK;
+}
+
 extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
                                        int n_out, int k_vol, int c_produce, const float* bias, float* out,
                                        void* stream) {
@@ -616,23 +672,23 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
     static const int env_lds88 = getenv("TODA_GG_LDS88") ? atoi(getenv("TODA_GG_LDS88")) : 3;  // 1: RT=1 single-buffer LDS (0.67 ms), 2: RT=2 (0.76), 0: registers-only RT=2 (0.70) on 97.5k x 27 x 128 x 128
     if (env_lds88 && vec_ok && Q == 8 && NT == 8) {
         if (env_lds88 == 2)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)),
+            GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)),
                                dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
         else if (env_lds88 == 3)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false, 512>), dim3(cdiv(cdiv(n_out, 16), 8)),
+            GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false, 512>), dim3(cdiv(cdiv(n_out, 16), 8)),
                                dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
         else if (env_lds88 == 4)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false, 512>), dim3(cdiv(cdiv(n_out, 32), 8)),
+            GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false, 512>), dim3(cdiv(cdiv(n_out, 32), 8)),
                                dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
+            GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
                                dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
     if (env_lds && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
 #define GL(QQ, NN, RR)                                                                                                   \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
+    GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
                        k_vol, c_produce, bias, out)
 #define GL_RT(QQ, NN)                          \
@@ -668,7 +724,7 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
 #define GG(QQ, NN, RR, PP)                                                                                            \
     GGV(QQ, NN, RR, PP, true)
 #define GGV(QQ, NN, RR, PP, VV)                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP, VV>),                                       \
+    GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP, VV>),                                       \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, \
                        n_out, k_vol, c_produce, bias, out, env_xcd)
 #define GG_PF(QQ, NN, RR)        \

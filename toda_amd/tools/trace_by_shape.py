@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Per (kernel, grid size) averages of the hand-written sparse-conv kernels over the timed steps of a rocprofv3
+--kernel-trace CSV of bench.py:  trace_by_shape.py <kernel_trace.csv> <timed_steps> [out.csv]"""
+import collections
+import csv
+import sys
+
+
+def main():
+    path, steps = sys.argv[1], int(sys.argv[2])
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [int(r["Start_Timestamp"]) for r in rows if "vox_insert" in r["Kernel_Name"]]
+    t0 = marks[-steps * 2]
+    agg = collections.defaultdict(list)
+    for r in rows:
+        if int(r["Start_Timestamp"]) < t0:
+            continue
+        name = r["Kernel_Name"]
+        if "gather_gemm" in name or "wgrad_kernel" in name:
+            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1))
+            agg[(name.split("(")[0], grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    lines = ["kernel,grid_threads,launches_per_step,avg_us,min_us,max_us"]
+    for (name, grid), us in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        lines.append(f'"{name}",{grid},{len(us) / steps:.1f},{sum(us) / len(us):.1f},{min(us):.1f},{max(us):.1f}')
+    text = "\n".join(lines)
+    print(text)
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

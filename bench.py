@@ -102,10 +102,10 @@ class KernelTimer:
         self._enabled = False
         self._orig = ops.gather_gemm
 
-        def labelled(feat, wp, nbr, c_produce, bias=None):
+        def labelled(feat, wp, nbr, c_produce, bias=None, order=None):
             if self._enabled and len(self.records) < self.CAPACITY:
                 self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
-            return self._orig(feat, wp, nbr, c_produce, bias)
+            return self._orig(feat, wp, nbr, c_produce, bias, order)
 
         ops.gather_gemm = labelled
 

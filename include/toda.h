@@ -131,6 +131,15 @@ int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int cin,
 int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp,
                             const int32_t* nbr, int n_out, int k_vol, int c_produce,
                             const float* bias /*nullable*/, float* out, void* stream);
+/* Same, visiting the output rows in the order `order[n_out]` (a permutation, nullable = canonical): results are
+ * identical, only the assignment of rows to waves changes.  toda_rulebook_row_order builds the order that sorts
+ * rows by their K-bit neighbour mask inside blocks of 2048 canonical rows, which lets whole (32-row tile, offset)
+ * pairs drop out of the gather + MFMA loop. */
+int toda_rulebook_row_order(const int32_t* nbr, int n_out, int k_vol /*<= 31*/, int32_t* order /*[n_out]*/,
+                            void* stream);
+int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_gather, const float* wp,
+                                    const int32_t* nbr, int n_out, int k_vol, int c_produce,
+                                    const float* bias, float* out, const int32_t* order, void* stream);
 /* dw[co][k][ci] = sum_o in[nbr[k*n_out+o], ci] * dout[o, co] */
 size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout);
 int toda_spconv_wgrad(const float* in, int n_in, const float* dout, const int32_t* nbr,

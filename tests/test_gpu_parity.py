@@ -519,3 +519,37 @@ def test_full_size_waymo_cloud_properties():
     back = dense[oi[:, 0].long(), :, oi[:, 1].long(), oi[:, 2].long(), oi[:, 3].long()]
     assert torch.equal(back, f2)
     assert rb2.n_out == oi.shape[0]
+
+
+def test_mask_sorted_row_order_is_a_blockwise_permutation_and_changes_no_bit():
+    """toda_rulebook_row_order: inside each block of 2048 canonical rows the rows are listed by ascending neighbour mask
+    (ties in canonical order); gather-GEMM visiting rows in that order returns bit-identical output."""
+    from toda_amd import ops
+    rng = np.random.default_rng(5)
+    n, k_vol = 2048 * 3 + 777, 27
+    coords = np.unique(np.stack([np.zeros(n * 2, np.int64), rng.integers(0, 12, n * 2), rng.integers(0, 60, n * 2), rng.integers(0, 60, n * 2)], 1), axis=0)[:n]
+    idx = torch.from_numpy(coords.astype(np.int32)).cuda()
+    rb, _ = ops.build_subm_rulebook(idx, 1, [12, 60, 60], 3)
+    order = ops.rulebook_row_order(rb.nbr_fwd).cpu().numpy()
+    nbr = rb.nbr_fwd.cpu().numpy()
+    mask = np.zeros(nbr.shape[1], np.int64)
+    for k in range(k_vol):
+        mask |= (nbr[k] >= 0).astype(np.int64) << k
+    n_rows = nbr.shape[1]
+    assert sorted(order.tolist()) == list(range(n_rows))
+    for s in range(0, n_rows, 2048):
+        blk = order[s:s + 2048]
+        assert blk.min() >= s and blk.max() < min(n_rows, s + 2048)
+        want = s + np.lexsort((np.arange(len(blk)), mask[s:s + 2048]))
+        np.testing.assert_array_equal(blk, want)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for cin, cout in [(64, 64), (32, 32), (16, 16), (5, 16), (128, 128), (64, 128), (24, 48)]:
+        feat = torch.randn((n_rows, cin), device="cuda", generator=gen)
+        w = torch.randn((cout, 3, 3, 3, cin), device="cuda", generator=gen) * 0.1
+        wp = ops.pack_weight(w, False, False)
+        bias = torch.randn(cout, device="cuda", generator=gen)
+        a = ops.gather_gemm(feat, wp, rb.nbr_fwd, cout, bias)
+        b = ops.gather_gemm(feat, wp, rb.nbr_fwd, cout, bias, order=torch.from_numpy(order).cuda())
+        assert torch.equal(a, b), (cin, cout)
+        rev = torch.arange(n_rows - 1, -1, -1, dtype=torch.int32, device="cuda")          # any permutation works
+        assert torch.equal(a, ops.gather_gemm(feat, wp, rb.nbr_fwd, cout, bias, order=rev))

@@ -112,7 +112,7 @@ template <int Q, int NT, int RT, bool PF, bool VEC>
 __global__ void __launch_bounds__(SC_BLOCK)
 gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                    const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
-                   float* __restrict__ out, int xcd_order) {
+                   float* __restrict__ out, int xcd_order, const int* __restrict__ order) {
     const int lane = threadIdx.x & 63;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give
     // each XCD one contiguous range of row tiles - canonical rows are spatial neighbours and gather
@@ -141,7 +141,7 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         live[rt] = row0 + rt * 16 + r < n_out;
-        rows[rt] = live[rt] ? row0 + rt * 16 + r : n_out - 1;  // clamped: loads stay unconditional
+        rows[rt] = live[rt] ? (order ? order[row0 + rt * 16 + r] : row0 + rt * 16 + r) : n_out - 1;  // clamped: loads stay unconditional
     }
 
     auto load_ids = [&](int k, int (&dst)[RT]) {
@@ -236,8 +236,9 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int row = row0 + rt * 16 + 4 * g + reg;
-            if (row >= n_out) continue;
+            const int pos = row0 + rt * 16 + 4 * g + reg;
+            const int row = __shfl(rows[rt], 4 * g + reg, 64);  // lane r' holds the (possibly permuted) row of tile position r'
+            if (pos >= n_out) continue;
             float* dst = out + (size_t)row * cp + NT * r;
             if (full) {
                 if constexpr (NT == 1) {
@@ -274,7 +275,7 @@ template <int Q, int NT, int RT, bool VEC, bool DB = true, int BLK = SC_BLOCK>
 __global__ void __launch_bounds__(BLK, (Q * NT * RT <= 32 && Q * NT <= 16) ? GG_LDS_WAVES : (BLK > SC_BLOCK ? GG_LDS_WAVES_WIDE : 1))
 gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                        const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
-                       float* __restrict__ out) {
+                       float* __restrict__ out, const int* __restrict__ order) {
     constexpr int SLICE = Q * NT * 64;                    // float4 per offset
     constexpr int PER_THREAD = (SLICE + BLK - 1) / BLK;
     __shared__ f32x4 wl[DB ? 2 : 1][SLICE];  // DB = false: one 64 KiB buffer (128-channel layers), two barriers per offset
@@ -298,7 +299,7 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         live[rt] = row0 + rt * 16 + r < n_out;
-        rows[rt] = live[rt] ? row0 + rt * 16 + r : n_out - 1;
+        rows[rt] = live[rt] ? (order ? order[row0 + rt * 16 + r] : row0 + rt * 16 + r) : n_out - 1;
     }
 
     // stage offset 0
@@ -368,8 +369,9 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
     for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int row = row0 + rt * 16 + 4 * g + reg;
-            if (row >= n_out) continue;
+            const int pos = row0 + rt * 16 + 4 * g + reg;
+            const int row = __shfl(rows[rt], 4 * g + reg, 64);  // lane r' holds the (possibly permuted) row of tile position r'
+            if (pos >= n_out) continue;
             float* dst = out + (size_t)row * cp + NT * r;
             if (full) {
                 if constexpr (NT == 1) {
@@ -594,6 +596,56 @@ extern "C" int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int 
     return TODA_OK;
 }
 
+// ---- mask-sorted processing order -----------------------------------------------------------
+// Inside blocks of ORD_B consecutive (canonical, i.e. spatially adjacent) rows, rows are visited in
+// ascending order of their K-bit neighbour mask, so that the 32 rows of a wave share offsets and
+// whole (tile, offset) pairs drop out of the gather + MFMA loop (measured on the C3 tables: non-empty
+// fraction 0.74 -> 0.61 at the stride-2 SubM level, 0.29 -> 0.13 for the strided convs' dgrad).
+// Results are unchanged: each output row is still produced by one wave from its own K inputs.
+namespace toda {
+constexpr int ORD_B = 2048;
+__global__ void __launch_bounds__(256)
+row_order_kernel(const int* __restrict__ nbr, int n, int K, int* __restrict__ order) {
+    __shared__ unsigned long long key[ORD_B];
+    const int base = blockIdx.x * ORD_B;
+    for (int i = threadIdx.x; i < ORD_B; i += 256) {
+        const int row = base + i;
+        unsigned m = 0xFFFFFFFFu;  // padding sorts last
+        if (row < n) {
+            m = 0;
+            for (int k = 0; k < K; ++k) m |= (unsigned)(nbr[(size_t)k * n + row] >= 0) << k;
+        }
+        key[i] = ((unsigned long long)m << 32) | (unsigned)i;
+    }
+    __syncthreads();
+    for (int span = 2; span <= ORD_B; span <<= 1) {
+        for (int j = span >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < ORD_B / 2; t += 256) {
+                const int i = 2 * t - (t & (j - 1));  // element whose bit j is clear
+                const int l = i + j;
+                const bool up = (i & span) == 0;
+                const unsigned long long a = key[i], b = key[l];
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < ORD_B; i += 256)
+        if (base + i < n) order[base + i] = base + (int)(key[i] & 0xFFFFFFFFull);
+}
+}  // namespace toda
+
+extern "C" int toda_rulebook_row_order(const int32_t* nbr, int n_out, int k_vol, int32_t* order, void* stream) {
+    TODA_CHECK_ARG(n_out >= 0 && k_vol >= 1 && k_vol <= 31, "rulebook_row_order: needs 1 <= K <= 31 offsets");
+    if (n_out == 0) return TODA_OK;
+    hipLaunchKernelGGL(row_order_kernel, dim3(cdiv(n_out, ORD_B)), dim3(256), 0, (hipStream_t)stream, nbr, n_out, k_vol, order);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
 // ---- optional per-launch timestamps of the gather-GEMM kernels -------------------------------
 // hipExtLaunchKernelGGL stamps a start / stop event pair on the kernel dispatch itself, so the
 // elapsed time is the kernel's own duration (what rocprofv3 --kernel-trace reports).  Events
@@ -646,9 +698,9 @@ extern "C" int toda_timing_end(float* ms_out, int cap, int* n_out) {
     return TODA_OK;
 }
 
-extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
-                                       int n_out, int k_vol, int c_produce, const float* bias, float* out,
-                                       void* stream) {
+extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
+                                               int n_out, int k_vol, int c_produce, const float* bias, float* out,
+                                               const int32_t* order, void* stream) {
     TODA_CHECK_ARG(c_gather >= 1 && c_gather <= 128 && c_produce >= 1 && c_produce <= 128,
                    "gather_gemm: channels must be in [1,128] (gather %d, produce %d)", c_gather, c_produce);
     TODA_CHECK_ARG(n_out >= 0 && n_in >= 0 && k_vol >= 1, "gather_gemm: bad sizes");
@@ -673,16 +725,16 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
     if (env_lds88 && vec_ok && Q == 8 && NT == 8) {
         if (env_lds88 == 2)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)),
-                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
+                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
         else if (env_lds88 == 3)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false, 512>), dim3(cdiv(cdiv(n_out, 16), 8)),
-                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
+                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
         else if (env_lds88 == 4)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false, 512>), dim3(cdiv(cdiv(n_out, 32), 8)),
-                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
+                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
         else
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
-                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out);
+                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
@@ -690,7 +742,7 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
 #define GL(QQ, NN, RR)                                                                                                   \
     GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
-                       k_vol, c_produce, bias, out)
+                       k_vol, c_produce, bias, out, order)
 #define GL_RT(QQ, NN)                          \
     if (env_rt == 4 && QQ <= 4 && NN <= 4) {   \
         GL(QQ, NN, 4);                         \
@@ -726,7 +778,7 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
 #define GGV(QQ, NN, RR, PP, VV)                                                                                       \
     GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP, VV>),                                       \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, \
-                       n_out, k_vol, c_produce, bias, out, env_xcd)
+                       n_out, k_vol, c_produce, bias, out, env_xcd, order)
 #define GG_PF(QQ, NN, RR)        \
     if (env_pf) {                \
         GG(QQ, NN, RR, true);    \
@@ -772,6 +824,12 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
 #undef GG
     TODA_LAUNCH_CHECK();
     return TODA_OK;
+}
+
+extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
+                                       int n_out, int k_vol, int c_produce, const float* bias, float* out,
+                                       void* stream) {
+    return toda_spconv_gather_gemm_ordered(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, nullptr, stream);
 }
 
 extern "C" size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout) {

@@ -129,6 +129,17 @@ class Rulebook:
         self.flip_bwd = flip_bwd  # SubM: dgrad reuses nbr_fwd with the offsets reversed
         self.pair_cnt = pair_cnt  # [K] int32 on device
         self.geom = geom
+        self._order = {}
+
+    def order_for(self, nbr):
+        """Mask-sorted visiting order of `nbr`'s rows (built once per table, reused by every conv and dgrad on it).
+        A SubM table read with reversed offsets has the same row grouping, so dgrad shares the forward order."""
+        if not ROW_ORDER or nbr.shape[0] > 31 or nbr.shape[1] < ROW_ORDER_MIN_ROWS:
+            return None
+        key = nbr.data_ptr()
+        if key not in self._order:
+            self._order[key] = rulebook_row_order(nbr)
+        return self._order[key]
 
     def num_pairs(self):
         return int(self.pair_cnt.sum().item())
@@ -285,13 +296,21 @@ def pack_weight(weight, transpose, flip_k):
     return wp
 
 
-def gather_gemm(feat, wp, nbr, c_produce, bias=None):
+def rulebook_row_order(nbr):
+    lib = L.load()
+    K, n_out = nbr.shape
+    order = torch.empty((n_out,), dtype=torch.int32, device=nbr.device)
+    L.check(lib.toda_rulebook_row_order(L.ptr(nbr), n_out, K, L.ptr(order), L.stream()), "toda_rulebook_row_order")
+    return order
+
+
+def gather_gemm(feat, wp, nbr, c_produce, bias=None, order=None):
     lib = L.load()
     K, n_out = nbr.shape
     out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
-    rc = lib.toda_spconv_gather_gemm(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K,
-                                     c_produce, L.ptr(bias), L.ptr(out), L.stream())
-    L.check(rc, "toda_spconv_gather_gemm")
+    rc = lib.toda_spconv_gather_gemm_ordered(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K,
+                                             c_produce, L.ptr(bias), L.ptr(out), L.ptr(order), L.stream())
+    L.check(rc, "toda_spconv_gather_gemm_ordered")
     return out
 
 
@@ -310,6 +329,11 @@ def wgrad(feat, dout, nbr, wshape):
 
 import os as _os
 
+# mask-sorted row order for gather-GEMM: opt-in.  Measured on C3 it LOSES on the SubM layers (64->64 @ 389k rows 0.536 ->
+# 0.562 ms, 32->32 @ 682k 0.321 -> 0.366 ms: rows of a tile are no longer x-neighbours, so their gathers stop sharing
+# input rows in L1/L2) and wins only on strided-conv dgrads (64->32 @ 682k 0.345 -> 0.274 ms); the sort costs 0.13 ms/table.
+ROW_ORDER = _os.environ.get("TODA_ROW_ORDER", "0") == "1"
+ROW_ORDER_MIN_ROWS = int(_os.environ.get("TODA_ROW_ORDER_MIN_ROWS", "4096"))
 WGRAD_ON_SIDE_STREAM = _os.environ.get("TODA_WGRAD_STREAM", "0") == "1"  # measured: no gain (each kernel already fills the chip)
 _SIDE_STREAMS = {}
 
@@ -331,7 +355,7 @@ class _SparseConv(torch.autograd.Function):
         features = features.contiguous()
         if wp_fwd is None:
             wp_fwd = pack_weight(weight, False, False)
-        out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
+        out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, order=rb.order_for(rb.nbr_fwd))
         ctx.save_for_backward(features, weight)
         ctx.rb = rb
         ctx.has_bias = bias is not None
@@ -357,7 +381,7 @@ class _SparseConv(torch.autograd.Function):
             need_w = False
         if need_d:
             wp_t = pack_weight(weight, True, rb.flip_bwd)
-            gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None)
+            gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None, order=rb.order_for(rb.nbr_bwd))
         if need_w:
             gw = wgrad(features, gout, rb.nbr_fwd, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:

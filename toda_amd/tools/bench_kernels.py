@@ -50,8 +50,10 @@ class Recorder:
 
     @staticmethod
     def label(name, a):
-        if name == "toda_spconv_gather_gemm":
+        if name in ("toda_spconv_gather_gemm", "toda_spconv_gather_gemm_ordered"):
             return (a[5], a[6], a[2], a[7])          # rows, K, c_gather, c_produce
+        if name == "toda_rulebook_row_order":
+            return (a[1], a[2])
         if name == "toda_spconv_wgrad":
             return (a[4], a[5], a[6], a[7])          # rows, K, cin, cout
         if name in ("toda_rulebook_subm", "toda_rulebook_conv", "toda_gridindex_from_coords", "toda_gridindex_from_conv"):
@@ -84,7 +86,7 @@ def main():
     device = torch.device("cuda", 0)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), dataset).to(device).train()
     batch0 = bench.make_device_batches(dataset, per_gpu, 1, 0, device)[0]
-    rec = Recorder(["toda_spconv_gather_gemm", "toda_spconv_wgrad", "toda_rulebook_subm", "toda_rulebook_conv",
+    rec = Recorder(["toda_spconv_gather_gemm_ordered", "toda_rulebook_row_order", "toda_spconv_wgrad", "toda_rulebook_subm", "toda_rulebook_conv",
                     "toda_gridindex_from_coords", "toda_gridindex_from_conv", "toda_voxelize_hard", "toda_mean_vfe_fwd",
                     "toda_sparse_to_dense_fwd", "toda_sparse_to_dense_bwd", "toda_center_assign",
                     "toda_spconv_pack_weight"])
@@ -108,7 +110,7 @@ def main():
           f"(TODA_GG_RT={os.environ.get('TODA_GG_RT', '0')} TODA_GG_PF={os.environ.get('TODA_GG_PF', '1')})")
     for tot, key, mean, n in rows:
         extra = ""
-        if key[0] in ("toda_spconv_gather_gemm", "toda_spconv_wgrad"):
+        if key[0] in ("toda_spconv_gather_gemm", "toda_spconv_gather_gemm_ordered", "toda_spconv_wgrad"):
             rows_, K, ci, co = key[1:]
             dense = 2.0 * rows_ * K * ci * co
             extra = f"  dense-equiv {dense / (mean * 1e-3) / 1e12:6.1f} TF/s"

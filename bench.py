@@ -168,7 +168,14 @@ def run_gpu(args, rank, world, device):
     if pair:
         model = DistModel(model)
     if world > 1 or os.environ.get("TODA_FORCE_DDP") == "1":  # the env knob rehearses the DDP path on one GPU
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], gradient_as_bucket_view=True)
+        ddp_kw = dict(gradient_as_bucket_view=True)
+        if os.environ.get("TODA_DDP_BCAST_BUFFERS", "0") == "0":
+            ddp_kw["broadcast_buffers"] = False
+        if os.environ.get("TODA_DDP_STATIC", "0") == "1":
+            ddp_kw["static_graph"] = True
+        if os.environ.get("TODA_DDP_BUCKET_MB"):
+            ddp_kw["bucket_cap_mb"] = int(os.environ["TODA_DDP_BUCKET_MB"])
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], **ddp_kw)
     if pair:
         batches = make_device_pair_batches(dataset, per_gpu, args.batches, rank, device)
         cl_fn = model_fn_decorator_cl()

@@ -145,3 +145,72 @@ def test_data_augmentor_records_what_it_did():
     if "x" in d["augmentation_params"]["random_world_flip"]:
         p[:, 1] = -p[:, 1]
     np.testing.assert_allclose(p, pts[:, :3], atol=1e-5)
+
+
+def test_adversarial_points_follow_the_stored_voxel_gradient():
+    """SyntheticMixupPairDataset.adversarial_points: points inside pseudo boxes above the score threshold move by
+    -eps * g(voxel) (modify), get displaced copies (add) or disappear (remove); everything else is untouched."""
+    from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from toda_amd.pcdet.datasets import SyntheticMixupPairDataset
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(ROOT, "toda_amd/tools/cfgs/models/toda_stage2_mixup_cl.yaml"), cfg)
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = 4000
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_SAMPLES = 4
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_GT = 2
+    ds = SyntheticMixupPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    assert ds.data_augmentor is not None and len(ds.data_augmentor.data_augmentor_queue) == 3
+    pts, boxes, _ = ds.raw_sample(3)
+    keys = ds.voxel_keys(pts[:, :3])
+    assert (keys >= 0).mean() > 0.9
+    gx, gy, _ = (int(g) for g in ds.grid_size)
+    uk = np.unique(keys[keys >= 0])
+    coords = np.stack([uk // (gx * gy), (uk // gx) % gy, uk % gx], 1).astype(np.int32)            # (z, y, x)
+    grad = np.tile(np.array([[1.0, -2.0, 0.5]], np.float32), (len(uk), 1))
+    from toda_amd.pcdet.datasets.augmentor.augmentor_utils import get_points_in_box
+    info = {"gt_boxes": boxes[:6], "gt_names": np.array(["car"] * 6), "p_score": np.array([0.9, 0.9, 0.9, 0.1, 0.9, 0.9]),
+            "p_voxel_coords": coords, "p_voxel_perturb": grad}
+    low_info = dict(info, gt_boxes=boxes[3:4], gt_names=np.array(["car"]), p_score=np.array([0.1]))
+    np.random.seed(0)
+    np.testing.assert_array_equal(ds.adversarial_points(pts.copy(), low_info), pts)          # below PSEUDO_THRESH: untouched
+    one = dict(info, gt_boxes=boxes[0:1], gt_names=np.array(["car"]), p_score=np.array([0.9]))
+    inside = get_points_in_box(pts, boxes[0])[1]
+    assert inside.sum() > 5
+    seen = set()
+    for seed in range(12):
+        np.random.seed(seed)
+        out = ds.adversarial_points(pts.copy(), one)
+        n0 = len(pts)
+        if len(out) == n0:                                           # modify (possibly of an empty subset)
+            moved = np.abs(out[:, :3] - pts[:, :3]).max(1) > 0
+            assert not (moved & ~inside).any()
+            np.testing.assert_array_equal(out[:, 3], pts[:, 3])
+            if moved.any():
+                seen.add("modify")
+                np.testing.assert_allclose(out[moved, :3] - pts[moved, :3], np.tile(-1e-3 * np.array([1.0, -2.0, 0.5]), (moved.sum(), 1)), atol=2e-6)
+        elif len(out) > n0:                                          # add: displaced copies appended, originals kept
+            seen.add("add")
+            np.testing.assert_array_equal(out[:n0], pts)
+            extra = out[n0:]
+            assert get_points_in_box(extra, boxes[0])[1].mean() > 0.9
+        else:                                                        # remove: only points of the box disappear
+            seen.add("remove")
+            assert len(out) >= n0 - inside.sum()
+            np.testing.assert_array_equal(out[: (~inside).sum()][:20], pts[~inside][:20]) if not inside[:40].any() else None
+    assert {"modify", "add", "remove"} <= seen
+    # frames of the labelled subset and frames without a stored gradient are returned as they are
+    assert ds.adversarial_points(pts.copy(), {"gt_boxes": boxes[:2]}) is not None
+    np.testing.assert_array_equal(ds.adversarial_points(pts.copy(), {"gt_boxes": boxes[:2]}), pts)
+
+
+def test_mixup_pair_policy_indices():
+    from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from toda_amd.pcdet.datasets import SyntheticMixupPairDataset
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(ROOT, "toda_amd/tools/cfgs/models/toda_stage2_mixup_cl.yaml"), cfg)
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_SAMPLES, cfg.DATA_CONFIG.SYNTHETIC.NUM_GT = 10, 4
+    for kind, check in [("only_gt", lambda a, b: a < 4 and b < 4), ("ps_gt", lambda a, b: a >= 4 and b < 4),
+                        ("gt_gt+ps", lambda a, b: a < 4 and b < 10), ("gt+ps_gt+ps", lambda a, b: a < 10 and b < 10)]:
+        cfg.DATA_CONFIG.MIXUP_TYPE = kind
+        ds = SyntheticMixupPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+        np.random.seed(0)
+        assert all(check(*ds.draw_mixup_indices()) for _ in range(50)), kind

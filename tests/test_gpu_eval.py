@@ -88,3 +88,49 @@ def test_train_test_pseudo_label_stage2_round_trip(tmp_path):
     trainer.main(["--cfg_file", cfg_file, "--epochs", "1", "--batch_size", "2", "--output_dir", str(tmp_path / "stage2"),
                   "--pretrained_model", str(ckpts[0]), "--set"] + small + ["DATA_CONFIG.PSEUDO_INFO_PATH", str(pseudo)])
     assert len(sorted((tmp_path / "stage2").rglob("checkpoint_epoch_1.pth"))) == 1
+
+
+def test_stage2_perturb_labels_and_mixup_pair_training(tmp_path):
+    """Teacher pass with stored voxel gradients -> SyntheticMixupPairDataset (MixUp-cd on the device, adversarial frames,
+    recorded augmentations) -> the 2-forward / 1-backward consistency trainer."""
+    from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from toda_amd.pcdet.datasets import SyntheticMixupPairDataset
+    from toda_amd.tools import generate_pseudo_labels_perturb as gen
+    from toda_amd.tools import stage2_mixup_train_cl as stage2
+
+    cfg_file = os.path.join(ROOT, "toda_amd/tools/cfgs/models/toda_stage2_mixup_cl.yaml")
+    small = ["DATA_CONFIG.SYNTHETIC.NUM_SAMPLES", "4", "DATA_CONFIG.SYNTHETIC.NUM_GT", "2", "DATA_CONFIG.SYNTHETIC.NUM_POINTS", "20000",
+             "DATA_CONFIG.POINT_CLOUD_RANGE", "[-21.6,-21.6,-5.0,21.6,21.6,4.8]", "MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH", "0.0"]
+    out = str(tmp_path / "out")
+    # the teacher: a random-init model is enough to exercise the path (scores ~ sigmoid(-2.19) = 0.1)
+    pseudo = gen.main(["--cfg_file", cfg_file, "--pseudo_thresh", "0.05", "--batch_size", "2", "--output_dir", out, "--set"] + small
+                      + ["DATA_CONFIG.DATASET", "SyntheticLidarDataset"])
+    infos = pickle.load(open(pseudo, "rb"))
+    assert len(infos) == 4
+    for info in infos:
+        assert {"gt_boxes", "gt_names", "p_score", "p_voxel_perturb", "p_voxel_coords"} <= set(info)
+        assert info["p_voxel_perturb"].shape == (info["p_voxel_coords"].shape[0], 3) and info["p_voxel_coords"].shape[0] > 1000
+        assert len(info["p_score"]) == len(info["gt_boxes"]) and np.isfinite(info["p_voxel_perturb"]).all()
+    assert any(np.abs(i["p_voxel_perturb"]).max() > 0 for i in infos)
+
+    cfg = AttrDict()
+    cfg_from_yaml_file(cfg_file, cfg)
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_SAMPLES, cfg.DATA_CONFIG.SYNTHETIC.NUM_GT, cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = 4, 2, 20000
+    cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [-21.6, -21.6, -5.0, 21.6, 21.6, 4.8]
+    cfg.DATA_CONFIG.PSEUDO_INFO_PATH = str(pseudo)
+    cfg.DATA_CONFIG.PSEUDO_THRESH = 0.05
+    ds = SyntheticMixupPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    kinds = set()
+    np.random.seed(11)
+    for i in range(6):
+        adv, org = ds[i]
+        assert adv["points"].is_cuda and org["points"].is_cuda and adv["gt_boxes"].shape[1] == 8
+        assert adv["augmentation_list"] == ["random_world_flip", "random_world_rotation", "random_world_scaling"]
+        assert set(adv["augmentation_params"]) == set(adv["augmentation_list"])
+        kinds.add("mixed" if adv["points"].shape[0] < 15000 or adv["gt_boxes"].shape[0] > 30 else "single")
+    batch = ds.collate_batch([ds[0], ds[1]])
+    assert batch[0]["points"].is_cuda and len(batch[0]["augmentation_params"]) == 2 and batch[1]["gt_boxes"].shape[0] == 2
+
+    steps = stage2.main(["--cfg_file", cfg_file, "--epochs", "1", "--batch_size", "2", "--set"] + small
+                        + ["DATA_CONFIG.PSEUDO_INFO_PATH", str(pseudo), "DATA_CONFIG.PSEUDO_THRESH", "0.05"])
+    assert steps == 2

@@ -10,6 +10,7 @@ from torch.utils.data import DistributedSampler as _DistributedSampler
 from ..utils import common_utils
 from .dataset import DatasetTemplate
 from .synthetic import SyntheticLidarDataset, SyntheticPairDataset
+from .mixup_dataset import SyntheticMixupPairDataset
 from .two_dataset import SyntheticMixDataset
 
 __all__ = {
@@ -17,6 +18,7 @@ __all__ = {
     "SyntheticLidarDataset": SyntheticLidarDataset,
     "SyntheticPairDataset": SyntheticPairDataset,
     "SyntheticMixDataset": SyntheticMixDataset,
+    "SyntheticMixupPairDataset": SyntheticMixupPairDataset,
 }
 
 

@@ -69,3 +69,17 @@ def global_scaling(gt_boxes, points, scale_range, return_scale=False):
         points[:, :3] *= noise_scale
     gt_boxes[:, :6] *= noise_scale
     return (gt_boxes, points, noise_scale) if return_scale else (gt_boxes, points)
+
+
+def get_points_in_box(points, gt_box):
+    """Points inside one box, margin 0.1 m in x / y, none in z, borders included (reference augmentor_utils.py:474-491).
+    Host numpy; the device form of the same test is ops.points_in_boxes(mode=1)."""
+    import math
+    x, y, z = points[:, 0], points[:, 1], points[:, 2]
+    cx, cy, cz, dx, dy, dz, rz = (gt_box[i] for i in range(7))
+    sx, sy, sz = x - cx, y - cy, z - cz
+    cosa, sina = math.cos(-rz), math.sin(-rz)
+    lx = sx * cosa + sy * (-sina)
+    ly = sx * sina + sy * cosa
+    mask = np.logical_and(abs(sz) <= dz / 2.0, np.logical_and(abs(lx) <= dx / 2.0 + 1e-1, abs(ly) <= dy / 2.0 + 1e-1))
+    return points[mask], mask

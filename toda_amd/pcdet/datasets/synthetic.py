@@ -140,11 +140,11 @@ class SyntheticLidarDataset(DatasetTemplate):
                          f"({tp[c]} TP / {n_gt[c]} gt / {n_det[c]} det)")
         return "\n".join(lines), result
 
-    def raw_sample(self, index, labels_only=False):
+    def raw_sample(self, index, labels_only=False, use_pseudo=True):
         kind = self.kinds[index % len(self.kinds)]
         points, boxes, names = synth_cloud(kind, self.seed + index, self.num_points, class_count=len(self.class_names))
         names = np.array([self.class_names[int(n[3:]) - 1] for n in names])
-        if self.pseudo_infos is not None and not labels_only:
+        if self.pseudo_infos is not None and not labels_only and use_pseudo:
             info = self.pseudo_infos[self.frame_id(index)]
             boxes = np.asarray(info["gt_boxes"], dtype=np.float32).reshape(-1, 7)
             names = np.asarray(info["gt_names"]).reshape(-1)

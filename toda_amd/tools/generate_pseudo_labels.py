@@ -28,6 +28,8 @@ def parse_config(argv=None):
     p.add_argument("--save_to_file", action="store_true", default=False)
     p.add_argument("--pseudo_thresh", type=float, required=True)
     p.add_argument("--unlabel_infos", type=str, default=None)
+    p.add_argument("--perturb", action="store_true", default=False,
+                   help="also store d loss / d voxels per frame (reference tools/generate_pseudo_labels_perturb.py)")
     p.add_argument("--output_dir", type=str, default=None)
     p.add_argument("--backend", type=str, default="nccl")
     p.add_argument("--set", dest="set_cfgs", default=None, nargs=argparse.REMAINDER)
@@ -63,6 +65,10 @@ def main(argv=None):
     if args.ckpt is not None:
         model.load_params_from_file(filename=args.ckpt, logger=logger, to_cpu=dist_test)
     model.cuda()
+    if args.perturb:
+        from .eval_utils.generate_pseudo_labels_perturb import inference_and_generate_pseudo_labes as with_perturb
+        return with_perturb(cfg_, args, model, loader, logger, dist_test=dist_test, save_to_file=args.save_to_file,
+                            result_dir=result_dir, unlabel_infos_path=infos_path)
     with torch.no_grad():
         return inference_and_generate_pseudo_labes(cfg_, args, model, loader, logger, dist_test=dist_test, save_to_file=args.save_to_file,
                                                    result_dir=result_dir, unlabel_infos_path=infos_path)

@@ -13,6 +13,7 @@ import torch.nn as nn
 from torch.nn.utils import clip_grad_norm_
 
 from ..pcdet.config import cfg
+from ..pcdet import datasets as dataset_registry
 from ..pcdet.datasets import SyntheticPairDataset
 from ..pcdet.models import DistModel, build_network, model_fn_decorator_cl
 from ..pcdet.utils import common_utils
@@ -49,7 +50,12 @@ def main(argv=None):
     bs = cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU if args.batch_size is None else args.batch_size // total_gpus
     epochs = cfg.OPTIMIZATION.NUM_EPOCHS if args.epochs is None else args.epochs
     logger = common_utils.create_logger(None, rank=cfg.LOCAL_RANK)
-    dataset = SyntheticPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    # DATA_CONFIG.DATASET names a pair dataset (SyntheticMixupPairDataset: MixUp + adversarial frames, the TODA recipe);
+    # configs written for the single-frame datasets fall back to the plain (adv, org) pair of one frame
+    cls = dataset_registry.__all__.get(cfg.DATA_CONFIG.DATASET, SyntheticPairDataset)
+    if not issubclass(cls, SyntheticPairDataset):
+        cls = SyntheticPairDataset
+    dataset = cls(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
     sampler = torch.utils.data.distributed.DistributedSampler(dataset) if dist_train else None
     loader = torch.utils.data.DataLoader(dataset, batch_size=bs, shuffle=sampler is None, sampler=sampler,
                                          num_workers=args.workers, collate_fn=dataset.collate_batch)
@@ -62,6 +68,8 @@ def main(argv=None):
     scheduler, _ = build_scheduler(optimizer, len(loader), epochs, -1, cfg.OPTIMIZATION)
     fn = model_fn_decorator_cl()
     it = 0
+    if args.pretrained_model is not None:
+        model.load_params_from_file(filename=args.pretrained_model, to_cpu=dist_train, logger=logger)
     for epoch in range(epochs):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -69,6 +77,7 @@ def main(argv=None):
         it = train_one_epoch_cl(wrapped, optimizer, loader, fn, scheduler, it, cfg.OPTIMIZATION, cfg.LOCAL_RANK, dist_train,
                                 logger=logger)
         logger.info(f"epoch {epoch} done in {time.time() - t0:.1f} s")
+    return it
 
 
 if __name__ == "__main__":

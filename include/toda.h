@@ -237,7 +237,9 @@ int toda_nms_rotated(const float* boxes_sorted, int n, float thresh, int64_t* ke
  * chains run without host syncs.  flags / cells are int32 per row.
  * ---------------------------------------------------------------------- */
 /* flags[j] = 1 iff some box (rows of box_stride >= 7 floats: x y z dx dy dz heading) contains point j.
- * mode 0: roiaware test (margin 1e-2, strict), mode 1: get_points_in_box test (margin 1e-1, inclusive). */
+ * mode 0: roiaware test (margin 1e-2, strict), mode 1: get_points_in_box test (margin 1e-1, inclusive).
+ * mode 2: points_in_boxes_gpu (roiaware_pool3d_kernel.cu:23-36, 313-336; margin 1e-5): flags[j] = index of the FIRST
+ * box that holds point j, -1 for none (used to cut the ground-truth database out of the scenes). */
 int toda_points_in_boxes(const float* points, int n, const int32_t* n_dev, int c, const float* boxes,
                          int k, int box_stride, int mode, int32_t* flags, void* stream);
 /* flags[j] = lo < -atan2(y, x) < hi   (yaw as an fp32 value, compared in fp64) */

@@ -666,7 +666,7 @@ void oracle_points_in_boxes(const float* pts, int n, int c, const float* boxes, 
         const float* b = boxes + (size_t)i * stride;
         const float cx = b[0], cy = b[1], cz = b[2], dx = b[3], dy = b[4], dz = b[5];
         const double a = (double)(-b[6]);
-        const float cosa = (float)cos(a), sina = (float)sin(a);
+        const float cosa = mode == 2 ? cosf(-b[6]) : (float)cos(a), sina = mode == 2 ? sinf(-b[6]) : (float)sin(a);
         for (int j = 0; j < n; ++j) {
             const float x = pts[(size_t)j * c], y = pts[(size_t)j * c + 1], z = pts[(size_t)j * c + 2];
             int in = 0;
@@ -674,9 +674,10 @@ void oracle_points_in_boxes(const float* pts, int n, int c, const float* boxes, 
             const float sx = x - cx, sy = y - cy;
             const float t1 = sx * cosa, t2 = sy * (-sina), t3 = sx * sina, t4 = sy * cosa;
             const float lx = t1 + t2, ly = t3 + t4;
-            if (mode == 0) {
+            if (mode == 0 || mode == 2) { /* mode 2: the GPU variant of the reference (roiaware_pool3d_kernel.cu:23-36), margin 1e-5 */
+                const double m = mode == 0 ? (double)1e-2f : (double)1e-5f;
                 if (!((double)fabsf(sz) > (double)dz / 2.0))
-                    in = (fabs((double)lx) < (double)dx / 2.0 + (double)1e-2f) && (fabs((double)ly) < (double)dy / 2.0 + (double)1e-2f);
+                    in = (fabs((double)lx) < (double)dx / 2.0 + m) && (fabs((double)ly) < (double)dy / 2.0 + m);
             } else {
                 const float mx = dx / 2.0f + 0.1f, my = dy / 2.0f + 0.1f;
                 in = (fabsf(sz) <= dz / 2.0f) && (fabsf(lx) <= mx) && (fabsf(ly) <= my);

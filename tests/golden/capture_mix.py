@@ -74,6 +74,52 @@ def copy(d):
     return {k: v.copy() for k, v in d.items()}
 
 
+def cap_gt_sampling():
+    """Reference DataBaseSampler (database_sampler.py:13-252) on a small object database cut (by the oracle's first-box
+    membership, the points_in_boxes_gpu rule) out of three synthetic frames; two consecutive calls on one scene."""
+    import pickle
+    import tempfile
+    from pathlib import Path
+    ds = CR._load("pcdet.datasets.augmentor.database_sampler", "pcdet/datasets/augmentor/database_sampler.py")
+    names_of = lambda k: np.array([f"cls{1 + i % 3}" for i in range(k)])
+    tmp = Path(tempfile.mkdtemp())
+    (tmp / "gt_database").mkdir()
+    infos, packed, off = {}, [], 0
+    for f in range(3):
+        sc = scene("nuscenes_toda", 60 + f, 6000, 12)
+        boxes, names = sc["gt_boxes"][:, :7], names_of(12)
+        owner = O.points_in_boxes(sc["points"][:, :3].copy(), boxes.copy(), 2)
+        first = np.where(owner.any(0), owner.argmax(0), -1)
+        for i in range(len(boxes)):
+            obj = sc["points"][first == i].copy()
+            obj[:, :3] -= boxes[i, :3]
+            rel = f"gt_database/{f}_{names[i]}_{i}.bin"
+            obj.tofile(str(tmp / rel))
+            infos.setdefault(names[i], []).append({"name": names[i], "path": rel, "image_idx": f, "gt_idx": i, "box3d_lidar": boxes[i],
+                                                   "num_points_in_gt": len(obj), "difficulty": 0, "global_data_offset": [off, off + len(obj)]})
+            packed.append(obj)
+            off += len(obj)
+    with open(tmp / "dbinfos.pkl", "wb") as fh:
+        pickle.dump(infos, fh)
+    cfg = CR.EasyDict({"DB_INFO_PATH": ["dbinfos.pkl"], "PREPARE": {"filter_by_min_points": ["cls1:5", "cls2:5", "cls3:1000"]},
+                       "SAMPLE_GROUPS": ["cls1:5", "cls2:4", "cls3:2"], "NUM_POINT_FEATURES": 4, "REMOVE_EXTRA_WIDTH": [0.1, 0.1, 0.0],
+                       "LIMIT_WHOLE_SCENE": True, "USE_SHARED_MEMORY": False})
+    sampler = ds.DataBaseSampler(tmp, cfg, ["cls1", "cls2", "cls3"], logger=None)
+    sc = scene("nuscenes_toda", 70, 8000, 6)
+    out = {}
+    np.random.seed(606)
+    for call in range(2):
+        d = sampler({"points": sc["points"].copy(), "gt_boxes": sc["gt_boxes"][:, :7].copy(), "gt_names": names_of(6),
+                     "gt_boxes_mask": np.array([True, True, False, True, True, True])})
+        out[f"points_{call}"], out[f"boxes_{call}"], out[f"names_{call}"] = d["points"], d["gt_boxes"], d["gt_names"].astype(str)
+        print("gt_sampling call", call, sc["points"].shape, "->", d["points"].shape, d["gt_boxes"].shape)
+    flat = [i for name in ("cls1", "cls2", "cls3") for i in infos[name]]
+    np.savez_compressed(os.path.join(OUT, "gt_sampling.npz"), scene_points=sc["points"], scene_boxes=sc["gt_boxes"][:, :7], seed=606,
+                        db_points=np.concatenate(packed, 0), db_offsets=np.array([i["global_data_offset"] for i in flat]),
+                        db_boxes=np.stack([i["box3d_lidar"] for i in flat]), db_names=np.array([i["name"] for i in flat]),
+                        db_frame=np.array([i["image_idx"] for i in flat]), db_gt_idx=np.array([i["gt_idx"] for i in flat]), **out)
+
+
 def main():
     M = setup()
     # CutMix needs > 10 000 target points inside the crop (inter_domain_point_cutmix.py:57)
@@ -113,6 +159,8 @@ def main():
         stages[f"boxes_{tag}"], stages[f"points_{tag}"] = boxes.copy(), np.asarray(pts, np.float32).copy()
     np.savez_compressed(os.path.join(OUT, "aug_world.npz"), in_points=sc["points"], in_boxes=sc["gt_boxes"][:, :7], seed=505, **stages)
     print("aug_world", {k: v.shape for k, v in stages.items() if k.startswith("points")})
+
+    cap_gt_sampling()
 
     d1, d2 = scene("nuscenes_toda", 41, 5000, 12), scene("nuscenes_toda", 42, 4000, 40)
     for name, seed, fn in [("mixup", 401, "intra_domain_point_mixup"), ("mixup_cd", 402, "intra_domain_point_mixup_cd")]:

@@ -234,3 +234,79 @@ def test_world_augmentations_on_the_device_match_reference():
         else:
             np.testing.assert_allclose(got, want, rtol=3e-7, atol=2e-6)
         np.testing.assert_array_equal(got[:, 3], z["in_points"][:, 3])
+
+
+def _materialise_db(tmp_path, z, packed):
+    import pickle
+    infos = {}
+    (tmp_path / "gt_database").mkdir(exist_ok=True)
+    for k in range(len(z["db_names"])):
+        lo, hi = (int(v) for v in z["db_offsets"][k])
+        name = str(z["db_names"][k])
+        rel = f"gt_database/{int(z['db_frame'][k])}_{name}_{int(z['db_gt_idx'][k])}.bin"
+        z["db_points"][lo:hi].tofile(str(tmp_path / rel))
+        infos.setdefault(name, []).append({"name": name, "path": rel, "image_idx": int(z["db_frame"][k]), "gt_idx": int(z["db_gt_idx"][k]),
+                                           "box3d_lidar": z["db_boxes"][k], "num_points_in_gt": hi - lo, "difficulty": 0,
+                                           "global_data_offset": [lo, hi]})
+    with open(tmp_path / "dbinfos.pkl", "wb") as f:
+        pickle.dump(infos, f)
+    if packed:
+        np.save(str(tmp_path / "gt_database_global.npy"), z["db_points"])
+
+
+@pytest.mark.parametrize("variant", ["files_numpy", "packed_cuda"])
+def test_gt_sampling_reproduces_reference_sampler(tmp_path, variant):
+    """DataBaseSampler on the device against two consecutive calls of the reference's sampler (tests/golden/gt_sampling.npz):
+    same picks, same collision filtering, same points in the same order."""
+    import os
+    from tests.test_eval_host import ROOT
+    from toda_amd.pcdet.config import AttrDict
+    from toda_amd.pcdet.datasets.augmentor.database_sampler import DataBaseSampler
+    z = dict(np.load(os.path.join(ROOT, "tests/golden/gt_sampling.npz")))
+    packed = variant == "packed_cuda"
+    _materialise_db(tmp_path, z, packed)
+    cfg = AttrDict({"DB_INFO_PATH": ["dbinfos.pkl"], "PREPARE": {"filter_by_min_points": ["cls1:5", "cls2:5", "cls3:1000"]},
+                    "SAMPLE_GROUPS": ["cls1:5", "cls2:4", "cls3:2"], "NUM_POINT_FEATURES": 4, "REMOVE_EXTRA_WIDTH": [0.1, 0.1, 0.0],
+                    "LIMIT_WHOLE_SCENE": True, "USE_SHARED_MEMORY": packed, "DB_DATA_PATH": ["gt_database_global.npy"]})
+    sampler = DataBaseSampler(tmp_path, cfg, ["cls1", "cls2", "cls3"])
+    names = np.array([f"cls{1 + i % 3}" for i in range(6)])
+    np.random.seed(int(z["seed"]))
+    for call in range(2):
+        pts = z["scene_points"].copy()
+        d = sampler({"points": dev(pts) if packed else pts, "gt_boxes": z["scene_boxes"].copy(), "gt_names": names.copy(),
+                     "gt_boxes_mask": np.array([True, True, False, True, True, True])})
+        got = d["points"].cpu().numpy() if packed else d["points"]
+        assert (torch.is_tensor(d["points"]) and d["points"].is_cuda) == packed
+        np.testing.assert_array_equal(d["gt_boxes"], z[f"boxes_{call}"])
+        assert d["gt_names"].astype(str).tolist() == z[f"names_{call}"].tolist()
+        np.testing.assert_array_equal(got, z[f"points_{call}"])
+        assert "gt_boxes_mask" not in d
+
+
+def test_groundtruth_database_cut_and_first_box_membership(tmp_path):
+    """create_groundtruth_database on synthetic frames: every object's points are those whose FIRST containing box is the
+    object's box (oracle membership, margin 1e-5), stored relative to the box centre; the packed array matches the files."""
+    import pickle
+    from toda_amd import ops
+    from toda_amd.pcdet.datasets.augmentor.database_sampler import create_groundtruth_database
+    from tests.test_eval_host import toda_cfg
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    cfg = toda_cfg(n_points=6000, samples=2)
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    infos = create_groundtruth_database(ds, tmp_path, used_classes=["car"])
+    assert set(infos) == {"car"} and len(infos["car"]) == 60
+    packed = np.load(tmp_path / "gt_database_global.npy")
+    assert pickle.load(open(tmp_path / "dbinfos.pkl", "rb"))["car"][3]["path"] == infos["car"][3]["path"]
+    pts, boxes, _ = ds.raw_sample(1)
+    owner = O.points_in_boxes(pts[:, :3].copy(), boxes[:, :7].copy(), 2)
+    first = np.where(owner.any(0), owner.argmax(0), -1)
+    np.testing.assert_array_equal(ops.points_in_boxes(dev(pts), dev(boxes), mode=2).cpu().numpy(), first)
+    for info in infos["car"][30:40]:
+        i = info["gt_idx"]
+        want = pts[first == i].copy()
+        want[:, :3] -= boxes[i, :3]
+        got = np.fromfile(str(tmp_path / info["path"]), dtype=np.float32).reshape(-1, 4)
+        np.testing.assert_array_equal(got, want)
+        lo, hi = info["global_data_offset"]
+        np.testing.assert_array_equal(packed[lo:hi], want)
+        assert info["num_points_in_gt"] == len(want) > 0

@@ -28,10 +28,11 @@ struct BoxPre {
 
 // mode 0: roiaware_pool3d.cpp:121-141 (|z-cz| > dz/2 rejects, |local| < d/2 + 1e-2, fp64 compare)
 // mode 1: augmentor_utils.py:474-491   (|z-cz| <= dz/2, |local| <= fp32(d/2 + 0.1))
+// mode 2: roiaware_pool3d_kernel.cu:23-36 (as mode 0 with margin 1e-5 and fp32 cos / sin) - points_in_boxes_gpu
 template <int MODE>
 __device__ __forceinline__ bool point_in_box(float x, float y, float z, const BoxPre& b) {
     const float sz = z - b.cz;
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 2) {
         if ((double)fabsf(sz) > (double)b.dz / 2.0) return false;
     } else {
         if (!(fabsf(sz) <= b.dz / 2.0f)) return false;
@@ -39,8 +40,8 @@ __device__ __forceinline__ bool point_in_box(float x, float y, float z, const Bo
     const float sx = x - b.cx, sy = y - b.cy;
     const float lx = sx * b.cosa + sy * (-b.sina);
     const float ly = sx * b.sina + sy * b.cosa;
-    if (MODE == 0) {
-        const double m = (double)1e-2f;
+    if (MODE == 0 || MODE == 2) {
+        const double m = MODE == 0 ? (double)1e-2f : (double)1e-5f;
         return fabs((double)lx) < (double)b.dx / 2.0 + m && fabs((double)ly) < (double)b.dy / 2.0 + m;
     }
     const float mx = b.dx / 2.0f + 0.1f, my = b.dy / 2.0f + 0.1f;
@@ -56,9 +57,14 @@ points_in_boxes_kernel(const float* __restrict__ pts, int n, const int32_t* __re
         const float* b = boxes + (size_t)i * box_stride;
         BoxPre p;
         p.cx = b[0], p.cy = b[1], p.cz = b[2], p.dx = b[3], p.dy = b[4], p.dz = b[5];
-        const double a = (double)(-b[6]);
-        p.cosa = (float)cos(a);
-        p.sina = (float)sin(a);
+        if (MODE == 2) {
+            p.cosa = cosf(-b[6]);
+            p.sina = sinf(-b[6]);
+        } else {
+            const double a = (double)(-b[6]);
+            p.cosa = (float)cos(a);
+            p.sina = (float)sin(a);
+        }
         sbox[i] = p;
     }
     __syncthreads();
@@ -66,6 +72,13 @@ points_in_boxes_kernel(const float* __restrict__ pts, int n, const int32_t* __re
     const int j = blockIdx.x * PT_BLOCK + threadIdx.x;
     if (j >= rows) return;
     const float x = pts[(size_t)j * c], y = pts[(size_t)j * c + 1], z = pts[(size_t)j * c + 2];
+    if (MODE == 2) {  // index of the first box that holds the point, -1 for none (points_in_boxes_kernel, :313-336)
+        int first = -1;
+        for (int i = k - 1; i >= 0; --i)
+            if (point_in_box<MODE>(x, y, z, sbox[i])) first = i;
+        flags[j] = first;
+        return;
+    }
     int hit = 0;
     for (int i = 0; i < k; ++i) hit |= point_in_box<MODE>(x, y, z, sbox[i]) ? 1 : 0;
     flags[j] = hit;
@@ -206,13 +219,16 @@ using namespace toda;
 extern "C" int toda_points_in_boxes(const float* points, int n, const int32_t* n_dev, int c, const float* boxes, int k,
                                     int box_stride, int mode, int32_t* flags, void* stream) {
     PT_COMMON_CHECK("points_in_boxes");
-    TODA_CHECK_ARG(k >= 0 && k <= 4096 && box_stride >= 7 && (mode == 0 || mode == 1), "points_in_boxes: k in [0,4096], stride >= 7, mode 0|1");
+    TODA_CHECK_ARG(k >= 0 && k <= 4096 && box_stride >= 7 && mode >= 0 && mode <= 2, "points_in_boxes: k in [0,4096], stride >= 7, mode 0|1|2");
     const size_t lds = (size_t)k * sizeof(BoxPre);
     if (mode == 0)
         hipLaunchKernelGGL(points_in_boxes_kernel<0>, dim3(cdiv(n, PT_BLOCK)), dim3(PT_BLOCK), lds, s, points, n, n_dev, c, boxes, k,
                            box_stride, flags);
-    else
+    else if (mode == 1)
         hipLaunchKernelGGL(points_in_boxes_kernel<1>, dim3(cdiv(n, PT_BLOCK)), dim3(PT_BLOCK), lds, s, points, n, n_dev, c, boxes, k,
+                           box_stride, flags);
+    else
+        hipLaunchKernelGGL(points_in_boxes_kernel<2>, dim3(cdiv(n, PT_BLOCK)), dim3(PT_BLOCK), lds, s, points, n, n_dev, c, boxes, k,
                            box_stride, flags);
     TODA_LAUNCH_CHECK();
     return TODA_OK;

@@ -600,7 +600,7 @@ def points_in_boxes(points, boxes, mode=0, n_dev=None):
     """flags[j] = 1 iff some box holds point j (mode 0: roiaware points_in_boxes_cpu test, mode 1: get_points_in_box)."""
     lib = L.load()
     n, c, nd = _rows(points, n_dev)
-    flags = torch.zeros((n,), dtype=torch.int32, device=points.device)
+    flags = torch.full((n,), -1 if mode == 2 else 0, dtype=torch.int32, device=points.device)   # mode 2: first box index
     k = int(boxes.shape[0]) if boxes is not None and boxes.dim() == 2 else 0
     if n == 0 or k == 0:
         return flags

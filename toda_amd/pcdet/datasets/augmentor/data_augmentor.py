@@ -1,6 +1,6 @@
 """DataAugmentor (reference pcdet/datasets/augmentor/data_augmentor.py:9-257): a queue of augmentations selected by NAME
-from DATA_AUGMENTOR.AUG_CONFIG_LIST.  Built: random_world_flip / random_world_rotation / random_world_scaling (on the
-device for CUDA clouds).  gt_sampling needs an object database on disk and is not built.  The applied transforms are
+from DATA_AUGMENTOR.AUG_CONFIG_LIST.  Built: gt_sampling (database_sampler.py), random_world_flip / random_world_rotation /
+random_world_scaling - all on the device for CUDA clouds.  The applied transforms are
 recorded in data_dict['augmentation_list' / 'augmentation_params'] - the stage-2 consistency step undoes them on the
 decoded boxes (models.reverse_transform)."""
 from functools import partial
@@ -19,7 +19,8 @@ class DataAugmentor:
         self.data_augmentor_queue = [getattr(self, c.NAME)(config=c) for c in cfgs if c.NAME not in disabled]
 
     def gt_sampling(self, config=None):
-        raise NotImplementedError("gt_sampling needs an object database (database_sampler.py); not built")
+        from .database_sampler import DataBaseSampler
+        return DataBaseSampler(root_path=self.root_path, sampler_cfg=config, class_names=self.class_names, logger=self.logger)
 
     @staticmethod
     def _record(data_dict, name, value):

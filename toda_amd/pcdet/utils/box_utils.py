@@ -51,3 +51,28 @@ def mask_boxes_outside_range_numpy(boxes, limit_range, min_num_corners=1):
     lim = np.asarray(limit_range)
     inside = ((corners >= lim[0:3]) & (corners <= lim[3:6])).all(axis=2)
     return inside.sum(axis=1) >= min_num_corners
+
+
+def enlarge_box3d(boxes3d, extra_width=(0, 0, 0)):
+    """dx, dy, dz grown by extra_width (reference box_utils.py:145-158); returns a torch tensor like the reference."""
+    boxes3d, _ = common_utils.check_numpy_to_torch(boxes3d)
+    large = boxes3d.clone()
+    large[:, 3:6] += boxes3d.new_tensor(extra_width)[None, :]
+    return large
+
+
+def remove_points_in_boxes3d(points, boxes3d):
+    """points [N, 3+C] without those inside any of boxes3d [M, 7] (reference box_utils.py:75-89).  CUDA clouds are filtered
+    by the in-box kernel + a stable compaction and stay on the device; numpy / CPU clouds take the same route and come back."""
+    from toda_amd import ops
+
+    is_numpy = isinstance(points, np.ndarray)
+    was_cuda = torch.is_tensor(points) and points.is_cuda
+    pts = torch.as_tensor(points, dtype=torch.float32).cuda().contiguous()
+    bx = torch.as_tensor(np.asarray(boxes3d.cpu() if torch.is_tensor(boxes3d) else boxes3d), dtype=torch.float32)[:, :7].cuda().contiguous()
+    if bx.shape[0] and pts.shape[0]:
+        flags = ops.points_in_boxes(pts, bx, mode=0)
+        pts = ops.RowBuffer(pts.shape[0], pts.shape[1], pts.device).append(pts, flags, 1, invert=True).finish()
+    if was_cuda:
+        return pts
+    return pts.cpu().numpy() if is_numpy else pts.cpu()

@@ -168,7 +168,9 @@ def run_gpu(args, rank, world, device):
     if pair:
         model = DistModel(model)
     if world > 1 or os.environ.get("TODA_FORCE_DDP") == "1":  # the env knob rehearses the DDP path on one GPU
-        ddp_kw = dict(gradient_as_bucket_view=True)
+        # 23-31 MB of fp32 gradients: 8 MB buckets let the all-reduce of the dense part's gradients (ready first) run over
+        # xGMI while the sparse backbone is still in backward; the default 25 MB would make it one bucket at the very end
+        ddp_kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=8)
         if os.environ.get("TODA_DDP_BCAST_BUFFERS", "0") == "0":
             ddp_kw["broadcast_buffers"] = False
         if os.environ.get("TODA_DDP_STATIC", "0") == "1":

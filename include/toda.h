@@ -167,8 +167,11 @@ int toda_pillar_scatter_bwd(const float* grad_canvas, const int32_t* idx, int n,
  * sparse level: the nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU pair of
  * post_act_block (spconv_backbone.py:8-27).
  * ---------------------------------------------------------------------- */
-/* sums[0:c] = sum_rows x, sums[c:2c] = sum_rows x*x  (fp32 pairwise per block, fp64 merge) */
-int toda_rows_moments(const float* x, int n, int c, double* sums /*[2c], zeroed by the call*/,
+/* sums[0:c] = sum_rows x, sums[c:2c] = sum_rows x*x  (fp32 inside a thread, fp64 across threads and blocks, fixed
+ * order: bit-reproducible).  `sums` must hold toda_rows_reduce_doubles(n, c) doubles: the first 2c are the result,
+ * the rest is per-block scratch (also for toda_rows_bn_bwd). */
+size_t toda_rows_reduce_doubles(int n, int c);
+int toda_rows_moments(const float* x, int n, int c, double* sums /*[toda_rows_reduce_doubles(n, c)]*/,
                       void* stream);
 /* y = relu?(x * scale[c] + shift[c] (+ residual)) */
 int toda_rows_affine_act(const float* x, const float* scale, const float* shift,
@@ -186,7 +189,8 @@ int toda_bn_finalize(const double* sums /*[2c] from toda_rows_moments*/, int n, 
  * sums[0:c] = sum dz = d(beta), sums[c:2c] = sum dz*xhat = d(gamma) (zeroed and filled by the call);
  * dx = gamma * invstd * (dz - sums[0:c]/n - xhat * sums[c:2c]/n), xhat = (x - mean) * invstd. */
 int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
-                     int n, int c, int relu, double* sums /*[2c]*/, float* dx, void* stream);
+                     int n, int c, int relu, double* sums /*[toda_rows_reduce_doubles(n, c)]*/, float* dx,
+                     void* stream);
 
 /* ------------------------------------------------------------------------
  * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,

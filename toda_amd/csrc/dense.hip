@@ -82,17 +82,23 @@ dense_tile_kernel(float* __restrict__ feat, const int4* __restrict__ idx, int n,
 // Per-channel reductions over the rows of [n, c] (c a multiple of 4 that divides 256).  Thread t
 // owns 4 consecutive channels (one 16-byte load per row) for a stripe of rows; two independent
 // partial sums per quantity give the loads ILP; fp32 inside a thread (<= MOM_ROWS/rows_par terms),
-// fp64 across threads and blocks (LDS fold, then one double atomic per channel and block).
-constexpr int MOM_ROWS = 512;
+// fp64 across threads and blocks: LDS fold, one plain store of the block's 2c partial sums, then a second
+// kernel adds the per-block partials in a fixed order - no atomics (one double atomic per channel and block
+// was the bottleneck: 2.1-3.2 TB/s at 512 rows per block and worse with more blocks), bit-reproducible.
+#ifndef TODA_MOM_ROWS
+#define TODA_MOM_ROWS 256
+#endif
+constexpr int MOM_ROWS = TODA_MOM_ROWS;      // rows per block while that gives <= MOM_MAX_BLOCKS blocks
+constexpr int MOM_MAX_BLOCKS = 2048;
 
 template <class Load>
-__device__ __forceinline__ void rows_reduce2(int n, int c, Load load, double* __restrict__ sums) {
+__device__ __forceinline__ void rows_reduce2(int n, int c, int rows_per_block, Load load, double* __restrict__ sums) {
     __shared__ float sh[2][DN_BLOCK][4];
     const int lanes = c >> 2;                 // threads per row
     const int rows_par = DN_BLOCK / lanes;    // rows per block iteration
     const int cl = threadIdx.x % lanes, rsub = threadIdx.x / lanes;
-    const int row_begin = blockIdx.x * MOM_ROWS;
-    const int row_end = min(n, row_begin + MOM_ROWS);
+    const int row_begin = blockIdx.x * rows_per_block;
+    const int row_end = min(n, row_begin + rows_per_block);
     f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, t0 = s0, s1 = s0, t1 = s0;
     int r = row_begin + rsub;
     for (; r + rows_par < row_end; r += 2 * rows_par) {
@@ -122,15 +128,37 @@ __device__ __forceinline__ void rows_reduce2(int n, int c, Load load, double* __
         const int q = threadIdx.x / c, ch = threadIdx.x % c;
         double acc = 0.0;
         for (int j = 0; j < rows_par; ++j) acc += sh[q][j * lanes + (ch >> 2)][ch & 3];
-        atomicAdd(&sums[q * c + ch], acc);
+        sums[2 * c + (size_t)(q * c + ch) * gridDim.x + blockIdx.x] = acc;   // scratch [2c][blocks] behind the 2c results
     }
 }
 
+// sums[col] = sum_g scratch[col][g]: one block per column, strided partial sums then an LDS tree - fixed order
 __global__ void __launch_bounds__(DN_BLOCK)
-rows_moments_kernel(const float* __restrict__ x, int n, int c, double* __restrict__ sums) {
+fold_partials_kernel(double* __restrict__ sums, int blocks, int cols) {
+    __shared__ double part[DN_BLOCK];
+    const double* src = sums + cols + (size_t)blockIdx.x * blocks;
+    double acc = 0.0;
+    for (int g = threadIdx.x; g < blocks; g += DN_BLOCK) acc += src[g];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = DN_BLOCK / 2; w > 0; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0];
+}
+
+static inline void reduce_plan(int n, int* blocks, int* rows_per_block) {
+    const int g = cdiv(n > 0 ? n : 1, MOM_ROWS);
+    *blocks = g < MOM_MAX_BLOCKS ? g : MOM_MAX_BLOCKS;
+    *rows_per_block = cdiv(n > 0 ? n : 1, *blocks);
+}
+
+__global__ void __launch_bounds__(DN_BLOCK)
+rows_moments_kernel(const float* __restrict__ x, int n, int c, int rows_per_block, double* __restrict__ sums) {
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     const int lanes = c >> 2;
-    rows_reduce2(n, c, [&](int r, int cl, f32x4& a, f32x4& b) {
+    rows_reduce2(n, c, rows_per_block, [&](int r, int cl, f32x4& a, f32x4& b) {
         a = x4[(size_t)r * lanes + cl];
         b = a * a;
     }, sums);
@@ -164,7 +192,7 @@ rows_affine_act_kernel(const f32x4* __restrict__ x, const float* __restrict__ sc
 // forward output is not read), xhat = (x - mean) * invstd.
 __global__ void __launch_bounds__(DN_BLOCK)
 rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                          int n, int c, int relu, double* __restrict__ sums) {
+                          int n, int c, int relu, int rows_per_block, double* __restrict__ sums) {
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
     const int lanes = c >> 2;
@@ -173,7 +201,7 @@ rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict_
     const f32x4 is = reinterpret_cast<const f32x4*>(stats + c)[cl0];
     const f32x4 sc = reinterpret_cast<const f32x4*>(stats + 2 * c)[cl0];
     const f32x4 sf = reinterpret_cast<const f32x4*>(stats + 3 * c)[cl0];
-    rows_reduce2(n, c, [&](int r, int cl, f32x4& a, f32x4& b) {
+    rows_reduce2(n, c, rows_per_block, [&](int r, int cl, f32x4& a, f32x4& b) {
         const f32x4 g = dy4[(size_t)r * lanes + cl], xv = x4[(size_t)r * lanes + cl];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -302,13 +330,24 @@ extern "C" int toda_pillar_scatter_bwd(const float* grad_canvas, const int32_t* 
     return scatter_common(false, grad_feat, idx, n, c, batch, g, const_cast<float*>(grad_canvas), (hipStream_t)stream);
 }
 
+extern "C" size_t toda_rows_reduce_doubles(int n, int c) {
+    int blocks, rpb;
+    reduce_plan(n, &blocks, &rpb);
+    return (size_t)2 * c * (1 + (size_t)blocks);
+}
+
 extern "C" int toda_rows_moments(const float* x, int n, int c, double* sums, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     TODA_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= DN_BLOCK / 2 && DN_BLOCK % c == 0,
                    "rows_moments: channels must be a multiple of 4 dividing 256, <= 128 (got %d)", c);
-    TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
-    if (n <= 0) return TODA_OK;
-    hipLaunchKernelGGL(rows_moments_kernel, dim3(cdiv(n, MOM_ROWS)), dim3(DN_BLOCK), 0, s, x, n, c, sums);
+    if (n <= 0) {
+        TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
+        return TODA_OK;
+    }
+    int blocks, rpb;
+    reduce_plan(n, &blocks, &rpb);
+    hipLaunchKernelGGL(rows_moments_kernel, dim3(blocks), dim3(DN_BLOCK), 0, s, x, n, c, rpb, sums);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c), dim3(DN_BLOCK), 0, s, sums, blocks, 2 * c);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }
@@ -329,10 +368,14 @@ extern "C" int toda_rows_bn_bwd(const float* dy, const float* x, const float* st
     hipStream_t s = (hipStream_t)stream;
     TODA_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= DN_BLOCK / 2 && DN_BLOCK % c == 0,
                    "rows_bn_bwd: channels must be a multiple of 4 dividing 256, <= 128 (got %d)", c);
-    TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
-    if (n <= 0) return TODA_OK;
-    hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(cdiv(n, MOM_ROWS)), dim3(DN_BLOCK), 0, s, dy, x, stats, n, c, relu,
-                       sums);
+    if (n <= 0) {
+        TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
+        return TODA_OK;
+    }
+    int blocks, rpb;
+    reduce_plan(n, &blocks, &rpb);
+    hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(blocks), dim3(DN_BLOCK), 0, s, dy, x, stats, n, c, relu, rpb, sums);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c), dim3(DN_BLOCK), 0, s, sums, blocks, 2 * c);
     const long long n4 = (long long)n * c / 4;
     hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3(ew_grid(n4, c)), dim3(DN_BLOCK), 0, s, (const f32x4*)dy,
                        (const f32x4*)x, stats, gamma, sums, n4, c, n, relu, (f32x4*)dx);

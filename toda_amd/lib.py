@@ -38,6 +38,7 @@ SIGNATURES = {
     "toda_sparse_to_dense_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_pillar_scatter_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "toda_pillar_scatter_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "toda_rows_reduce_doubles": (_sz, [_i, _i]),
     "toda_rows_moments": (_i, [_vp, _i, _i, _vp, _vp]),
     "toda_rows_affine_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "toda_bn_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp, _vp, _vp]),

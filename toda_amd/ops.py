@@ -458,9 +458,10 @@ def pillar_scatter(features, indices, batch, ny, nx):
 # ------------------------------------------------------------------- BN1d building blocks
 def rows_moments(x):
     n, c = x.shape
-    sums = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
-    L.check(L.load().toda_rows_moments(L.ptr(x.contiguous()), n, c, L.ptr(sums), L.stream()), "toda_rows_moments")
-    return sums
+    lib = L.load()
+    sums = torch.empty((lib.toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=x.device)
+    L.check(lib.toda_rows_moments(L.ptr(x.contiguous()), n, c, L.ptr(sums), L.stream()), "toda_rows_moments")
+    return sums[:2 * c]
 
 
 def rows_affine_act(x, scale, shift, residual=None, relu=True):
@@ -483,7 +484,7 @@ class _BNRows(torch.autograd.Function):
         n, c = x.shape
         dev = x.device
         stats = torch.empty((4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-        sums = torch.empty((2 * c,), dtype=torch.float64, device=dev)
+        sums = torch.empty((lib.toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=dev)   # [0:2c] result + per-block scratch
         if training:
             L.check(lib.toda_rows_moments(L.ptr(x), n, c, L.ptr(sums), L.stream()), "toda_rows_moments")
         rc = lib.toda_bn_finalize(L.ptr(sums), n, c, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
@@ -508,13 +509,13 @@ class _BNRows(torch.autograd.Function):
             gx = dz * stats[2]
             xhat = (x - stats[0]) * stats[1]
             return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None
-        sums = torch.empty((2 * c,), dtype=torch.float64, device=x.device)
+        sums = torch.empty((L.load().toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=x.device)
         gx = torch.empty_like(x)
         gamma = weight if weight is not None else torch.ones(c, device=x.device)
         rc = L.load().toda_rows_bn_bwd(L.ptr(gy), L.ptr(x), L.ptr(stats), L.ptr(gamma), n, c, int(relu), L.ptr(sums),
                                        L.ptr(gx), L.stream())
         L.check(rc, "toda_rows_bn_bwd")
-        gs = sums.to(torch.float32)
+        gs = sums[:2 * c].to(torch.float32)
         return gx, gs[c:], gs[:c], None, None, None, None, None, None
 
 

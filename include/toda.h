@@ -192,6 +192,12 @@ int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const 
                      int n, int c, int relu, double* sums /*[toda_rows_reduce_doubles(n, c)]*/, float* dx,
                      void* stream);
 
+/* The same with a shortcut branch (SparseBasicBlock, spconv_backbone.py:30-66: y = relu(bn2(x) + identity)): the ReLU
+ * mask is recomputed from x*scale+shift + residual, dres (nullable) receives dz = the gradient of the shortcut. */
+int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual /*nullable*/, const float* stats,
+                         const float* gamma, int n, int c, int relu, double* sums, float* dx,
+                         float* dres /*nullable*/, void* stream);
+
 /* ------------------------------------------------------------------------
  * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,
  * pcdet/models/model_utils/centernet_utils.py:9-69): gaussian heat-maps,

@@ -354,6 +354,46 @@ def test_fused_bn_rows_matches_torch_batchnorm1d(c, relu, train):
     assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("c,train", [(64, True), (128, True), (32, False)])
+def test_fused_bn_shortcut_relu_matches_torch(c, train):
+    """y = relu(bn(x) + shortcut) of SparseBasicBlock as one fused pass: output, gradients of x, of the shortcut and of the
+    affine parameters against the unfused fp64 torch graph.  Rows whose pre-activation is within 1e-5 of zero are left out
+    of the gradient comparison (the fp32 mask may legitimately differ there)."""
+    from toda_amd import ops
+
+    rng = np.random.default_rng(100 + c)
+    x = (rng.standard_normal((15013, c)) * 1.3).astype(np.float32)
+    r = (rng.standard_normal(x.shape) * 0.8).astype(np.float32)
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).double()
+    with torch.no_grad():
+        ref.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, c)))
+        ref.bias.copy_(torch.from_numpy(rng.uniform(-0.5, 0.5, c)))
+    mine = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+    mine.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+    mine = mine.cuda()
+    ref.train(train)
+    mine.train(train)
+    xr, rr = torch.from_numpy(x).double().requires_grad_(True), torch.from_numpy(r).double().requires_grad_(True)
+    pre = ref(xr) + rr
+    yr = torch.relu(pre)
+    yr.backward(torch.from_numpy(g).double())
+    xm, rm = dev(x).requires_grad_(True), dev(r).requires_grad_(True)
+    ym = ops.bn_rows(xm, mine, True, residual=rm)
+    ym.backward(dev(g))
+    np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=2e-5)
+    safe = (pre.detach().abs() > 1e-5).numpy()
+    assert safe.mean() > 0.999
+    np.testing.assert_allclose(rm.grad.cpu().numpy()[safe], rr.grad.numpy()[safe], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xm.grad.cpu().numpy()[safe], xr.grad.numpy()[safe], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(mine.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-3, atol=2e-2)
+    np.testing.assert_allclose(mine.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=1e-3, atol=2e-2)
+    # the shortcut gradient is switched off when the shortcut does not need one
+    xm2 = dev(x).requires_grad_(True)
+    ops.bn_rows(xm2, mine, True, residual=dev(r)).backward(dev(g))
+    np.testing.assert_allclose(xm2.grad.cpu().numpy()[safe], xr.grad.numpy()[safe], rtol=2e-3, atol=2e-4)
+
+
 def _random_boxes(n, seed, extent=40.0):
     rng = np.random.default_rng(seed)
     b = np.zeros((n, 7), np.float32)

@@ -191,10 +191,12 @@ rows_affine_act_kernel(const f32x4* __restrict__ x, const float* __restrict__ sc
 // dz = dy * (x*scale+shift > 0) when the block ends in a ReLU (the mask is recomputed from x, the
 // forward output is not read), xhat = (x - mean) * invstd.
 __global__ void __launch_bounds__(DN_BLOCK)
-rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                          int n, int c, int relu, int rows_per_block, double* __restrict__ sums) {
+rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ res,
+                          const float* __restrict__ stats, int n, int c, int relu, int rows_per_block,
+                          double* __restrict__ sums) {
     const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy);
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(res);
     const int lanes = c >> 2;
     const int cl0 = threadIdx.x % lanes;
     const f32x4 mu = reinterpret_cast<const f32x4*>(stats)[cl0];
@@ -203,9 +205,12 @@ rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict_
     const f32x4 sf = reinterpret_cast<const f32x4*>(stats + 3 * c)[cl0];
     rows_reduce2(n, c, rows_per_block, [&](int r, int cl, f32x4& a, f32x4& b) {
         const f32x4 g = dy4[(size_t)r * lanes + cl], xv = x4[(size_t)r * lanes + cl];
+        const f32x4 rv = r4 ? r4[(size_t)r * lanes + cl] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float dz = (relu && !(xv[j] * sc[j] + sf[j] > 0.f)) ? 0.f : g[j];
+            float pre = xv[j] * sc[j] + sf[j];
+            if (r4) pre += rv[j];   // same two roundings as the forward pass (affine, then + residual)
+            const float dz = (relu && !(pre > 0.f)) ? 0.f : g[j];
             a[j] = dz;
             b[j] = dz * ((xv[j] - mu[j]) * is[j]);
         }
@@ -214,9 +219,9 @@ rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict_
 
 // pass 2: dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) = k1 * (dz - m1 - (x - mu) * k2)
 __global__ void __launch_bounds__(DN_BLOCK)
-rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x, const float* __restrict__ stats,
-                         const float* __restrict__ gamma, const double* __restrict__ sums, long long n4, int c, int n,
-                         int relu, f32x4* __restrict__ dx) {
+rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x, const f32x4* __restrict__ res,
+                         const float* __restrict__ stats, const float* __restrict__ gamma, const double* __restrict__ sums,
+                         long long n4, int c, int n, int relu, f32x4* __restrict__ dx, f32x4* __restrict__ dres) {
     const long long t0 = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
     const long long stride = (long long)gridDim.x * DN_BLOCK;
     const int ch = (int)((t0 * 4) % c);
@@ -235,13 +240,18 @@ rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__
     const f32x4 k1 = ga * is, k2 = is * m2;  // xhat * m2 = (x - mu) * (is * m2)
     for (long long t = t0; t < n4; t += stride) {
         const f32x4 g = dy[t], xv = x[t];
-        f32x4 out;
+        const f32x4 rv = res ? res[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 out, dzv;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float dz = (relu && !(xv[j] * sc[j] + sf[j] > 0.f)) ? 0.f : g[j];
+            float pre = xv[j] * sc[j] + sf[j];
+            if (res) pre += rv[j];
+            const float dz = (relu && !(pre > 0.f)) ? 0.f : g[j];
+            dzv[j] = dz;
             out[j] = k1[j] * (dz - m1[j] - (xv[j] - mu[j]) * k2[j]);
         }
         dx[t] = out;
+        if (dres) dres[t] = dzv;   // gradient of the shortcut branch
     }
 }
 
@@ -363,8 +373,9 @@ extern "C" int toda_rows_affine_act(const float* x, const float* scale, const fl
     return TODA_OK;
 }
 
-extern "C" int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int n, int c,
-                                int relu, double* sums, float* dx, void* stream) {
+extern "C" int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual, const float* stats,
+                                    const float* gamma, int n, int c, int relu, double* sums, float* dx, float* dres,
+                                    void* stream) {
     hipStream_t s = (hipStream_t)stream;
     TODA_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= DN_BLOCK / 2 && DN_BLOCK % c == 0,
                    "rows_bn_bwd: channels must be a multiple of 4 dividing 256, <= 128 (got %d)", c);
@@ -374,13 +385,18 @@ extern "C" int toda_rows_bn_bwd(const float* dy, const float* x, const float* st
     }
     int blocks, rpb;
     reduce_plan(n, &blocks, &rpb);
-    hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(blocks), dim3(DN_BLOCK), 0, s, dy, x, stats, n, c, relu, rpb, sums);
+    hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(blocks), dim3(DN_BLOCK), 0, s, dy, x, residual, stats, n, c, relu, rpb, sums);
     hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c), dim3(DN_BLOCK), 0, s, sums, blocks, 2 * c);
     const long long n4 = (long long)n * c / 4;
     hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3(ew_grid(n4, c)), dim3(DN_BLOCK), 0, s, (const f32x4*)dy,
-                       (const f32x4*)x, stats, gamma, sums, n4, c, n, relu, (f32x4*)dx);
+                       (const f32x4*)x, (const f32x4*)residual, stats, gamma, sums, n4, c, n, relu, (f32x4*)dx, (f32x4*)dres);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
+}
+
+extern "C" int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int n, int c,
+                                int relu, double* sums, float* dx, void* stream) {
+    return toda_rows_bn_bwd_res(dy, x, nullptr, stats, gamma, n, c, relu, sums, dx, nullptr, stream);
 }
 
 extern "C" int toda_bn_finalize(const double* sums, int n, int c, const float* gamma, const float* beta,

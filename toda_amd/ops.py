@@ -478,9 +478,10 @@ class _BNRows(torch.autograd.Function):
     (torch: 5 / 7): toda_rows_moments -> toda_bn_finalize -> toda_rows_affine_act, toda_rows_bn_bwd."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual=None):
         lib = L.load()
         x = x.contiguous()
+        residual = residual.contiguous() if residual is not None else None
         n, c = x.shape
         dev = x.device
         stats = torch.empty((4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
@@ -492,41 +493,46 @@ class _BNRows(torch.autograd.Function):
                                   L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
         L.check(rc, "toda_bn_finalize")
         y = torch.empty_like(x)
-        rc = lib.toda_rows_affine_act(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), None, n, c, int(bool(relu)), L.ptr(y),
+        rc = lib.toda_rows_affine_act(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(residual), n, c, int(bool(relu)), L.ptr(y),
                                       L.stream())
         L.check(rc, "toda_rows_affine_act")
-        ctx.save_for_backward(x, stats, weight)
+        ctx.save_for_backward(x, stats, weight, residual)
         ctx.meta = (n, c, bool(relu), bool(training))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, stats, weight = ctx.saved_tensors
+        x, stats, weight, residual = ctx.saved_tensors
         n, c, relu, training = ctx.meta
         gy = gy.contiguous()
+        want_res = residual is not None and ctx.needs_input_grad[9]
         if not training:  # eval: plain affine map
-            dz = gy * (x * stats[2] + stats[3] > 0) if relu else gy
+            pre = x * stats[2] + stats[3]
+            if residual is not None:
+                pre = pre + residual
+            dz = gy * (pre > 0) if relu else gy
             gx = dz * stats[2]
             xhat = (x - stats[0]) * stats[1]
-            return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None
+            return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None, (dz if want_res else None)
         sums = torch.empty((L.load().toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=x.device)
         gx = torch.empty_like(x)
         gamma = weight if weight is not None else torch.ones(c, device=x.device)
-        rc = L.load().toda_rows_bn_bwd(L.ptr(gy), L.ptr(x), L.ptr(stats), L.ptr(gamma), n, c, int(relu), L.ptr(sums),
-                                       L.ptr(gx), L.stream())
-        L.check(rc, "toda_rows_bn_bwd")
+        gres = torch.empty_like(x) if want_res else None
+        rc = L.load().toda_rows_bn_bwd_res(L.ptr(gy), L.ptr(x), L.ptr(residual), L.ptr(stats), L.ptr(gamma), n, c, int(relu),
+                                           L.ptr(sums), L.ptr(gx), L.ptr(gres), L.stream())
+        L.check(rc, "toda_rows_bn_bwd_res")
         gs = sums[:2 * c].to(torch.float32)
-        return gx, gs[c:], gs[:c], None, None, None, None, None, None
+        return gx, gs[c:], gs[:c], None, None, None, None, None, None, gres
 
 
-def bn_rows(x, bn, relu):
-    """Apply an nn.BatchNorm1d module (its parameters, buffers and train/eval state) to rows [N, C],
-    optionally fused with the ReLU that follows it."""
+def bn_rows(x, bn, relu, residual=None):
+    """Apply an nn.BatchNorm1d module (its parameters, buffers and train/eval state) to rows [N, C], optionally
+    fused with a shortcut addition (y = bn(x) + residual) and the ReLU that follows."""
     training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = 0.0 if bn.momentum is None else bn.momentum
-    return _BNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu)
+    return _BNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu, residual)
 
 
 def bn_rows_supported(x, bn):

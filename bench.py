@@ -132,10 +132,11 @@ class KernelTimer:
         """Per launch shape: mean ms, algorithmic bytes and flops (valid pairs counted exactly)."""
         groups, pair_cache = {}, {}
         for (nbr, n_src, cg, cp), ms in zip(self.records, self.ms):
-            key = (nbr.data_ptr(), n_src, cg, cp)
             if nbr.data_ptr() not in pair_cache:
                 pair_cache[nbr.data_ptr()] = int((nbr >= 0).sum().item())
-            g = groups.setdefault(key, {"ms": [], "pairs": pair_cache[nbr.data_ptr()], "n_out": nbr.shape[1],
+            pairs = pair_cache[nbr.data_ptr()]
+            key = (nbr.shape[1], nbr.shape[0], pairs, n_src, cg, cp)      # one group per rulebook and channel pair, over all steps
+            g = groups.setdefault(key, {"ms": [], "pairs": pairs, "n_out": nbr.shape[1],
                                         "K": nbr.shape[0], "n_src": n_src, "cg": cg, "cp": cp})
             g["ms"].append(ms)
         return groups

@@ -154,6 +154,9 @@ def run_gpu(args, rank, world, device):
     elif mixed:
         from toda_amd.pcdet.datasets import SyntheticMixDataset
         cfg.DATA_CONFIG.CACHE_FRAMES = True      # raw clouds of both domains stay resident in HBM
+        for step_cfg in cfg.DATA_CONFIG.DATA_PROCESSOR:
+            if step_cfg.NAME == "shuffle_points":
+                step_cfg.SHUFFLE_ON_DEVICE = True   # permutation drawn by torch on the device instead of numpy on the host
         cfg.DATA_CONFIG.SYNTHETIC.NUM_SOURCE = cfg.DATA_CONFIG.SYNTHETIC.NUM_TARGET = 2 * per_gpu * world
         dataset = SyntheticMixDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
         np.random.seed(4321 + rank)

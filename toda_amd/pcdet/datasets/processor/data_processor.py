@@ -52,6 +52,12 @@ class DataProcessor:
         if data_dict is None:
             return partial(self.shuffle_points, config=config)
         if config.SHUFFLE_ENABLED[self.mode]:
+            pts = data_dict["points"]
+            if config.get("SHUFFLE_ON_DEVICE", False) and torch.is_tensor(pts) and pts.is_cuda:
+                # opt-in: draw the permutation on the device (torch's generator instead of numpy's stream; saves the host
+                # permutation + its 8 B/point upload, ~0.5 ms per 180k-point cloud)
+                data_dict["points"] = pts.index_select(0, torch.randperm(pts.shape[0], device=pts.device))
+                return data_dict
             rng = data_dict.get("_rng")
             n = data_dict["points"].shape[0]
             order = rng.permutation(n) if rng is not None else np.random.permutation(n)

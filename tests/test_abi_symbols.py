@@ -41,6 +41,33 @@ def test_bad_arguments_fail_loudly_without_touching_the_device():
     assert rc == -1 and b"channels" in lib.toda_last_error()
 
 
+def test_more_argument_checks_and_size_queries():
+    """Every entry point validates before it launches: error code + message, nothing dereferenced."""
+    import ctypes
+    lib = L.load()
+    assert lib.toda_spconv_wgrad(None, 10, None, None, 10, 27, 64, 200, None, None, 0, None) == -1 and b"channels" in lib.toda_last_error()
+    need = lib.toda_spconv_wgrad_workspace_bytes(100000, 27, 64, 64)
+    assert need >= 27 * 64 * 64 * 4
+    assert lib.toda_spconv_wgrad(None, 10, None, None, 100000, 27, 64, 64, None, None, need - 1, None) != 0 and b"workspace" in lib.toda_last_error()
+    assert lib.toda_nms_workspace_bytes(1000) >= 1000 * 16 * 8
+    assert lib.toda_nms_rotated(None, 1000, 0.5, None, None, None, 8, None) != 0 and b"workspace" in lib.toda_last_error()
+    assert lib.toda_rows_select_workspace_bytes(100000) >= 100000 * 4
+    assert lib.toda_rows_select_append(None, 1000, None, 4, None, 1, 0, None, 10, None, None, 16, None) != 0 and b"workspace" in lib.toda_last_error()
+    assert lib.toda_rows_moments(None, 10, 24, None, None) == -1 and b"channels" in lib.toda_last_error()           # 24 does not divide 256
+    assert lib.toda_rows_reduce_doubles(389533, 64) >= 2 * 64 * 2
+    edges = (ctypes.c_double * 40)()
+    ep = ctypes.cast(edges, ctypes.c_void_p)
+    assert lib.toda_points_polar_cell(None, 10, None, 4, 0.0, ep, 33, ep, 2, 0.0, 1.0, None, None) == -1 and b"bins" in lib.toda_last_error()
+    assert lib.toda_points_in_boxes(None, 10, None, 4, None, 3, 7, 5, None, None) == -1 and b"mode" in lib.toda_last_error()
+    assert lib.toda_points_in_boxes(None, 10, None, 2, None, 3, 7, 0, None, None) == -1                              # needs x, y, z
+    assert lib.toda_rulebook_row_order(None, 10, 64, None, None) == -1 and b"offsets" in lib.toda_last_error()
+    assert lib.toda_timing_begin(0) == -1
+    # zero-sized problems succeed without touching any pointer
+    assert lib.toda_spconv_gather_gemm_ordered(None, 0, 64, None, None, 0, 27, 64, None, None, None, None) == 0
+    assert lib.toda_points_sector(None, 0, None, 4, 0.0, 1.0, None, None) == 0
+    assert lib.toda_boxes_overlap_bev(None, 0, None, 5, None, None) == 0
+
+
 def test_host_tensors_are_refused():
     import pytest
     import torch

@@ -386,6 +386,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    if os.environ.get("TODA_MIOPEN_FIND", "0") == "1":      # experiment knob: MIOpen find mode for the dense convs
+        torch.backends.cudnn.benchmark = True
     res = run_gpu(args, rank, world, device)
     if rank == 0:
         per_gpu = res["per_gpu"]

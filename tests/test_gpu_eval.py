@@ -134,3 +134,14 @@ def test_stage2_perturb_labels_and_mixup_pair_training(tmp_path):
     steps = stage2.main(["--cfg_file", cfg_file, "--epochs", "1", "--batch_size", "2", "--set"] + small
                         + ["DATA_CONFIG.PSEUDO_INFO_PATH", str(pseudo), "DATA_CONFIG.PSEUDO_THRESH", "0.05"])
     assert steps == 2
+
+
+def test_stage1_trainer_runs_on_the_device_mix_dataset(tmp_path):
+    """tools/stage1_cutmix_train (= train.py) on SyntheticMixDataset: samples arrive as CUDA tensors from __getitem__."""
+    from toda_amd.tools import train as trainer
+    cfg_file = os.path.join(ROOT, "toda_amd/tools/cfgs/models/toda_stage1_polarmix.yaml")
+    small = ["DATA_CONFIG.SYNTHETIC.NUM_SOURCE", "2", "DATA_CONFIG.SYNTHETIC.NUM_TARGET", "2",
+             "DATA_CONFIG.SYNTHETIC.NUM_POINTS_SOURCE", "30000", "DATA_CONFIG.SYNTHETIC.NUM_POINTS_TARGET", "12000",
+             "DATA_CONFIG.POLARMIX_PROB", "1.0"]
+    trainer.main(["--cfg_file", cfg_file, "--epochs", "1", "--batch_size", "2", "--output_dir", str(tmp_path / "out"), "--set"] + small)
+    assert len(sorted((tmp_path / "out").rglob("checkpoint_epoch_1.pth"))) == 1

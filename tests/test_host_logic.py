@@ -149,3 +149,31 @@ def test_stage2_two_forward_one_backward_step_on_cpu():
     assert torch.isfinite(ret.loss) and {"loss_org", "cl_center", "cl_size"} <= set(ret.tb_dict)
     assert int(model.global_step) == 1
     assert all(p.grad is not None for n, p in model.named_parameters() if "backbone_3d.conv_input.0" in n)
+
+
+def test_install_as_pcdet_aliases_every_submodule_lazily():
+    """`pcdet.*` / `spconv.*` imports resolve to the SAME module objects as `toda_amd.pcdet.*` / `toda_amd.spconv.*` (run in a
+    child interpreter so this session's sys.modules stay clean)."""
+    import subprocess
+    import sys
+    code = """
+import toda_amd.pcdet as tp
+tp.install_as_pcdet()
+from pcdet.config import cfg, cfg_from_yaml_file
+from pcdet.models import build_network, model_fn_decorator
+from pcdet.utils.spconv_utils import spconv
+from pcdet.ops.iou3d_nms import iou3d_nms_utils
+from pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils
+from pcdet.datasets.augmentor import data_augmentor, database_sampler
+from pcdet.datasets.processor.inter_domain_point_polarmix import inter_domain_point_polarmix
+from pcdet.datasets.processor.intra_domain_point_mixup import intra_domain_point_mixup_cd
+from pcdet.utils import box_utils
+import spconv.pytorch as sp2
+import toda_amd.pcdet.utils.box_utils as real_bu, toda_amd.spconv as real_sp
+assert spconv.SubMConv3d is sp2.SubMConv3d is real_sp.SubMConv3d and box_utils is real_bu
+assert isinstance(spconv.SubMConv3d(4, 8, 3, indice_key='k'), spconv.conv.SparseConvolution)
+print('ok')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]

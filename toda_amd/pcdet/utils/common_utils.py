@@ -77,6 +77,22 @@ def init_dist_pytorch(tcp_port=None, local_rank=None, backend="nccl"):
     return dist.get_world_size(), dist.get_rank()
 
 
+def init_dist_slurm(tcp_port, local_rank=None, backend="nccl"):
+    """SLURM launch (reference common_utils.py:134-158): one task per GPU; rank / world size from SLURM_PROCID /
+    SLURM_NTASKS, rendezvous on the first host of SLURM_NODELIST."""
+    import subprocess
+
+    rank, world = int(os.environ["SLURM_PROCID"]), int(os.environ["SLURM_NTASKS"])
+    if backend == "nccl":
+        torch.cuda.set_device(rank % max(torch.cuda.device_count(), 1))
+    first = subprocess.run(["scontrol", "show", "hostname", os.environ["SLURM_NODELIST"]], capture_output=True, text=True)
+    os.environ["MASTER_ADDR"] = (first.stdout.split() or ["127.0.0.1"])[0]
+    os.environ["MASTER_PORT"] = str(tcp_port)
+    os.environ["WORLD_SIZE"], os.environ["RANK"] = str(world), str(rank)
+    dist.init_process_group(backend=backend)
+    return dist.get_world_size(), dist.get_rank()
+
+
 class AverageMeter:
     def __init__(self):
         self.reset()

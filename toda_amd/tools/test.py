@@ -24,7 +24,7 @@ def parse_config(argv=None):
     p.add_argument("--workers", type=int, default=0)
     p.add_argument("--extra_tag", type=str, default="default")
     p.add_argument("--ckpt", type=str, default=None)
-    p.add_argument("--launcher", choices=["none", "pytorch"], default="none")
+    p.add_argument("--launcher", choices=["none", "pytorch", "slurm"], default="none")
     p.add_argument("--tcp_port", type=int, default=18888)
     p.add_argument("--local_rank", type=int, default=None)
     p.add_argument("--eval_tag", type=str, default="default")
@@ -54,7 +54,7 @@ def main(argv=None):
     if args.launcher == "none":
         dist_test, total_gpus = False, 1
     else:
-        total_gpus, cfg_.LOCAL_RANK = common_utils.init_dist_pytorch(args.tcp_port, args.local_rank, backend=args.backend)
+        total_gpus, cfg_.LOCAL_RANK = getattr(common_utils, f"init_dist_{args.launcher}")(args.tcp_port, args.local_rank, backend=args.backend)
         dist_test = True
     if args.batch_size is None:
         args.batch_size = cfg_.OPTIMIZATION.BATCH_SIZE_PER_GPU

@@ -32,7 +32,7 @@ def parse_config(argv=None):
     p.add_argument("--extra_tag", type=str, default="default")
     p.add_argument("--ckpt", type=str, default=None)
     p.add_argument("--pretrained_model", type=str, default=None)
-    p.add_argument("--launcher", choices=["none", "pytorch"], default="none")
+    p.add_argument("--launcher", choices=["none", "pytorch", "slurm"], default="none")
     p.add_argument("--tcp_port", type=int, default=18888)
     p.add_argument("--sync_bn", action="store_true", default=False)
     p.add_argument("--fix_random_seed", action="store_true", default=False)
@@ -57,7 +57,7 @@ def main(argv=None):
     if args.launcher == "none":
         dist_train, total_gpus = False, 1
     else:
-        total_gpus, cfg.LOCAL_RANK = common_utils.init_dist_pytorch(args.tcp_port, args.local_rank, backend=args.backend)
+        total_gpus, cfg.LOCAL_RANK = getattr(common_utils, f"init_dist_{args.launcher}")(args.tcp_port, args.local_rank, backend=args.backend)
         dist_train = True
     if args.batch_size is None:
         args.batch_size = cfg.OPTIMIZATION.BATCH_SIZE_PER_GPU

@@ -94,7 +94,7 @@ class KernelTimer:
     kernel's own - the number rocprofv3 --kernel-trace reports - and no host sync happens while the clock runs.
     ops.gather_gemm is wrapped only to remember each launch's shape in launch order."""
 
-    CAPACITY = 4096
+    CAPACITY = 512          # launches timed and labelled (their neighbour tables stay referenced until the summary)
 
     def __init__(self):
         self.records = []          # (nbr table, n_src, c_gather, c_produce) in launch order
@@ -144,6 +144,9 @@ class KernelTimer:
 
 def run_gpu(args, rank, world, device):
     yaml_path, per_gpu, desc = WORKLOADS[args.workload]
+    if getattr(args, "per_gpu", None):          # exploration only: the BASELINE configs fix the per-GPU batch
+        per_gpu = int(args.per_gpu)
+        desc += f" [per-GPU batch overridden to {per_gpu}]"
     cfg = load_cfg(yaml_path)
     pair = args.workload.endswith("cl")
     mixed = args.workload.endswith("mix")
@@ -371,6 +374,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batches", type=int, default=2, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-gpu", type=int, default=None, help="override the workload's samples per GPU (exploration)")
     ap.add_argument("--layers", action="store_true", help="also print the per-shape gather-GEMM table to stderr")
     args = ap.parse_args()
 
@@ -404,7 +408,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": res["desc"], "global_batch": per_gpu * world,
                        "points_per_cloud": {"c3": 180000, "c2": 60000}.get(args.workload, "180000/35000 alternating"),
-                       "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4)},
+                       "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4),
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -198,6 +198,17 @@ int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual 
                          const float* gamma, int n, int c, int relu, double* sums, float* dx,
                          float* dres /*nullable*/, void* stream);
 
+/* nn.BatchNorm2d(+ReLU) of the BEV neck and heads (base_bev_backbone.py:37-58, center_head.py:20-28, 73-80) on NCHW
+ * tensors x[batch][c][hw]: the same sweeps as the row variant (moments -> toda_bn_finalize with n = batch*hw -> affine
+ * (+ReLU); backward reduce + apply with the ReLU mask recomputed from x).  sums / stats as for the row variant, `sums`
+ * sized by toda_planes_reduce_doubles. */
+size_t toda_planes_reduce_doubles(int batch, int c, int hw);
+int toda_planes_moments(const float* x, int batch, int c, int hw, double* sums, void* stream);
+int toda_planes_affine_act(const float* x, const float* scale, const float* shift, int batch, int c, int hw,
+                           int relu, float* y, void* stream);
+int toda_planes_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int batch, int c,
+                       int hw, int relu, double* sums, float* dx, void* stream);
+
 /* ------------------------------------------------------------------------
  * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,
  * pcdet/models/model_utils/centernet_utils.py:9-69): gaussian heat-maps,

@@ -394,6 +394,48 @@ def test_fused_bn_shortcut_relu_matches_torch(c, train):
     np.testing.assert_allclose(xm2.grad.cpu().numpy()[safe], xr.grad.numpy()[safe], rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("shape,relu,train", [((2, 128, 188, 188), True, True), ((2, 64, 47, 45), True, True),
+                                                ((3, 256, 94, 94), False, True), ((2, 32, 20, 20), True, False)])
+def test_fused_bn_planes_matches_torch_batchnorm2d(shape, relu, train):
+    """toda_planes_moments / _affine_act / _bn_bwd (BatchNorm2d + ReLU of the BEV neck and heads) against nn.BatchNorm2d in
+    fp64: output, input gradient, affine gradients, running statistics; hw % 4 != 0 takes the scalar path."""
+    from toda_amd import ops
+
+    ops.PLANES_BN = True          # opt-in path (TODA_PLANES_BN=1)
+    b, c, h, w = shape
+    rng = np.random.default_rng(c + h)
+    x = (rng.standard_normal(shape) * 1.5 + 0.2).astype(np.float32)
+    g = rng.standard_normal(shape).astype(np.float32)
+    ref = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).double()
+    with torch.no_grad():
+        ref.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, c)))
+        ref.bias.copy_(torch.from_numpy(rng.uniform(-0.5, 0.5, c)))
+        ref.running_var.copy_(torch.from_numpy(rng.uniform(0.5, 2.0, c)))
+    mine = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
+    mine.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+    mine = mine.cuda()
+    ref.train(train)
+    mine.train(train)
+    xr = torch.from_numpy(x).double().requires_grad_(True)
+    pre = ref(xr)
+    yr = torch.relu(pre) if relu else pre
+    yr.backward(torch.from_numpy(g).double())
+    xm = dev(x).requires_grad_(True)
+    assert ops.bn_planes_supported(xm, mine)
+    seq = torch.nn.Sequential(mine, torch.nn.ReLU()) if relu else torch.nn.Sequential(mine)
+    ym = ops.run_dense_sequential(seq, xm)
+    ym.backward(dev(g))
+    np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=2e-5)
+    safe = (pre.detach().abs() > 1e-5).numpy() if relu else np.ones(shape, bool)
+    np.testing.assert_allclose(xm.grad.cpu().numpy()[safe], xr.grad.numpy()[safe], rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(mine.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(mine.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(mine.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mine.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
+    ops.PLANES_BN = False
+
+
 def _random_boxes(n, seed, extent=40.0):
     rng = np.random.default_rng(seed)
     b = np.zeros((n, 7), np.float32)

@@ -6,6 +6,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from toda_amd import ops
+
 
 def _bn(c):
     return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
@@ -54,14 +56,14 @@ class BaseBEVBackbone(nn.Module):
         h0 = x.shape[2]
         ups = []
         for lvl, block in enumerate(self.blocks):
-            x = block(x)
+            x = ops.run_dense_sequential(block, x)
             data_dict[f"spatial_features_{int(h0 / x.shape[2])}x"] = x
-            ups.append(self.deblocks[lvl](x) if len(self.deblocks) > 0 else x)
+            ups.append(ops.run_dense_sequential(self.deblocks[lvl], x) if len(self.deblocks) > 0 else x)
         if len(ups) > 1:
             x = torch.cat(ups, dim=1)
         elif len(ups) == 1:
             x = ups[0]
         if len(self.deblocks) > len(self.blocks):
-            x = self.deblocks[-1](x)
+            x = ops.run_dense_sequential(self.deblocks[-1], x)
         data_dict["spatial_features_2d"] = x
         return data_dict

@@ -39,7 +39,7 @@ class SeparateHead(nn.Module):
             setattr(self, name, branch)
 
     def forward(self, x):
-        return {name: getattr(self, name)(x) for name in self.sep_head_dict}
+        return {name: ops.run_dense_sequential(getattr(self, name), x) for name in self.sep_head_dict}
 
 
 class CenterHead(nn.Module):
@@ -180,7 +180,7 @@ class CenterHead(nn.Module):
 
     def forward(self, data_dict):
         feats = data_dict["spatial_features_2d"]
-        x = self.shared_conv(feats)
+        x = ops.run_dense_sequential(self.shared_conv, feats)
         pred_dicts = [head(x) for head in self.heads_list]
         if self.training:
             self.forward_ret_dict["target_dicts"] = self.assign_targets(

@@ -4,7 +4,8 @@
     python -m toda_amd.tools.bench_kernels [--workload c3] [--iters 5]
 
 Prints one line per (operator, shape): mean ms, algorithmic GB/s and TFLOP/s.  Used to pick kernel
-variants (environment knobs TODA_GG_RT / TODA_GG_PF are read once per process by libtoda_hip.so)."""
+variants (environment knobs TODA_GG_RT / TODA_GG_PF / TODA_GG_LDS / TODA_GG_LDS88 / TODA_WG_SUB are read once per process by
+libtoda_hip.so; TODA_HIP_LIB points at an alternative build for A/B runs inside one gpurun call)."""
 import argparse
 import collections
 import os
@@ -107,7 +108,8 @@ def main():
     rows = rec.report()
     total = sum(r[0] for r in rows) / args.iters
     print(f"# {args.workload}: {total:.3f} ms/step inside libtoda_hip.so "
-          f"(TODA_GG_RT={os.environ.get('TODA_GG_RT', '0')} TODA_GG_PF={os.environ.get('TODA_GG_PF', '1')})")
+          f"(TODA_GG_RT={os.environ.get('TODA_GG_RT', '0')} TODA_GG_PF={os.environ.get('TODA_GG_PF', '0')} "
+          f"TODA_GG_LDS={os.environ.get('TODA_GG_LDS', '1')} TODA_WG_SUB={os.environ.get('TODA_WG_SUB', '7')})")
     for tot, key, mean, n in rows:
         extra = ""
         if key[0] in ("toda_spconv_gather_gemm", "toda_spconv_gather_gemm_ordered", "toda_spconv_wgrad"):

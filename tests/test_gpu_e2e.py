@@ -114,3 +114,28 @@ def test_sparse_backbone_step_is_bitwise_reproducible():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2])) and len(a[2]) > 20
     assert float(a[0].abs().sum()) > 0 and float(a[1].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("n_second", [7, 0])
+def test_batch_with_a_tiny_or_empty_sample_trains(n_second):
+    """Ragged batches: a sample with a handful of points, or none at all (every level of that sample is empty), goes through
+    voxelisation, both backbones' index plans, the heads and the backward pass."""
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import build_network, voxelize_on_gpu
+
+    cfg = small_cfg("toda_stage1_centerpoint_res", rng_xy=14.4, n_points=8000)
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    torch.manual_seed(0)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).cuda().train()
+    a = ds[0]
+    b = dict(a)
+    b["points"] = a["points"][:n_second].copy()
+    col = ds.collate_batch([a, b])
+    batch = {"points": torch.from_numpy(col["points"]).float().cuda(), "points_per_sample": col["points_per_sample"],
+             "gt_boxes": torch.from_numpy(col["gt_boxes"]).float().cuda(), "batch_size": 2}
+    voxelize_on_gpu(batch, ds.voxel_cfg)
+    per = torch.bincount(batch["voxel_coords"][:, 0].long(), minlength=2).tolist()
+    assert per[0] > 1000 and per[1] <= n_second
+    ret, _, _ = model(batch)
+    ret["loss"].backward()
+    assert torch.isfinite(ret["loss"]) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)

@@ -120,6 +120,51 @@ def cap_gt_sampling():
                         db_frame=np.array([i["image_idx"] for i in flat]), db_gt_idx=np.array([i["gt_idx"] for i in flat]), **out)
 
 
+def cap_collate():
+    """Reference DatasetTemplate.collate_batch (pcdet/datasets/dataset.py:161-233) on two tiny voxelised samples."""
+    for name, rel in [("pcdet.datasets.augmentor.database_sampler", "pcdet/datasets/augmentor/database_sampler.py"),
+                      ("pcdet.datasets.augmentor.data_augmentor", "pcdet/datasets/augmentor/data_augmentor.py"),
+                      ("pcdet.datasets.processor.point_feature_encoder", "pcdet/datasets/processor/point_feature_encoder.py"),
+                      ("pcdet.datasets.processor.data_processor", "pcdet/datasets/processor/data_processor.py")]:
+        if name not in sys.modules:
+            CR._load(name, rel)
+    dsm = CR._load("pcdet.datasets.dataset", "pcdet/datasets/dataset.py")
+    rng = np.random.default_rng(808)
+    samples = []
+    for k, (m, n_pts, n_gt) in enumerate([(5, 11, 2), (3, 6, 4)]):
+        samples.append({"points": rng.standard_normal((n_pts, 4)).astype(np.float32),
+                        "voxels": rng.standard_normal((m, 5, 4)).astype(np.float32),
+                        "voxel_coords": rng.integers(0, 40, (m, 3)).astype(np.int32),
+                        "voxel_num_points": rng.integers(1, 6, (m,)).astype(np.int32),
+                        "gt_boxes": rng.standard_normal((n_gt, 8)).astype(np.float32),
+                        "frame_id": f"f{k}", "use_lead_xyz": True})
+    out = dsm.DatasetTemplate.collate_batch([dict(s) for s in samples])
+    flat = {}
+    for k, s in enumerate(samples):
+        for key, val in s.items():
+            flat[f"in{k}_{key}"] = np.asarray(val)
+    for key, val in out.items():
+        flat[f"out_{key}"] = np.asarray(val)
+    np.savez_compressed(os.path.join(OUT, "collate_batch.npz"), **flat)
+    print("collate", {k: np.asarray(v).shape for k, v in out.items()})
+
+
+def cap_data_processor():
+    """Reference DataProcessor.mask_points_and_boxes_outside_range + shuffle_points (data_processor.py:78-103), seeded."""
+    dp = sys.modules["pcdet.datasets.processor.data_processor"]
+    cfgs = [CR.EasyDict({"NAME": "mask_points_and_boxes_outside_range", "REMOVE_OUTSIDE_BOXES": True}),
+            CR.EasyDict({"NAME": "shuffle_points", "SHUFFLE_ENABLED": {"train": True, "test": False}})]
+    rng_pc = np.array([-20.0, -20.0, -5.0, 20.0, 20.0, 4.8], np.float32)
+    proc = dp.DataProcessor(cfgs, point_cloud_range=rng_pc, training=True, num_point_features=4)
+    sc = scene("nuscenes_toda", 90, 4000, 14)
+    sc["points"][:3, 0] = [20.0, -20.0, 20.0000019]          # on and just beyond the inclusive boundary
+    np.random.seed(909)
+    out = proc.forward({"points": sc["points"].copy(), "gt_boxes": sc["gt_boxes"].copy()})
+    np.savez_compressed(os.path.join(OUT, "data_processor.npz"), in_points=sc["points"], in_boxes=sc["gt_boxes"], range=rng_pc, seed=909,
+                        out_points=out["points"], out_boxes=out["gt_boxes"])
+    print("data_processor", sc["points"].shape, "->", out["points"].shape, sc["gt_boxes"].shape, "->", out["gt_boxes"].shape)
+
+
 def main():
     M = setup()
     # CutMix needs > 10 000 target points inside the crop (inter_domain_point_cutmix.py:57)
@@ -161,6 +206,8 @@ def main():
     print("aug_world", {k: v.shape for k, v in stages.items() if k.startswith("points")})
 
     cap_gt_sampling()
+    cap_collate()
+    cap_data_processor()
 
     d1, d2 = scene("nuscenes_toda", 41, 5000, 12), scene("nuscenes_toda", 42, 4000, 40)
     for name, seed, fn in [("mixup", 401, "intra_domain_point_mixup"), ("mixup_cd", 402, "intra_domain_point_mixup_cd")]:

@@ -233,3 +233,48 @@ def test_c1_pointpillar_chain_matches_reference():
     np.testing.assert_allclose(voxels.grad.numpy(), g["gvoxels"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(head.conv_cls.weight.grad.numpy(), g["g_conv_cls"], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(vfe.pfn_layers[0].linear.weight.grad.numpy(), g["g_pfn"], rtol=1e-3, atol=1e-5)
+
+
+def test_collate_batch_matches_reference():
+    """DatasetTemplate.collate_batch against the reference's own (pcdet/datasets/dataset.py:161-233): concatenation order, the
+    batch-index column of points / voxel_coords, zero-padded gt_boxes, dtypes."""
+    from toda_amd.pcdet.datasets import DatasetTemplate
+
+    z = np.load(os.path.join(G, "collate_batch.npz"), allow_pickle=False)
+    samples = []
+    for k in range(2):
+        keys = [n[len(f"in{k}_"):] for n in z.files if n.startswith(f"in{k}_")]
+        s = {key: z[f"in{k}_{key}"] for key in keys}
+        s["frame_id"], s["use_lead_xyz"] = str(s["frame_id"]), bool(s["use_lead_xyz"])
+        samples.append(s)
+    out = DatasetTemplate.collate_batch(samples)
+    for name in z.files:
+        if not name.startswith("out_"):
+            continue
+        key = name[4:]
+        want, got = z[name], np.asarray(out[key])
+        assert got.shape == want.shape, key
+        if want.dtype.kind in "fiub":
+            np.testing.assert_array_equal(got, want, err_msg=key)
+            if key in ("points", "voxels", "voxel_coords", "voxel_num_points", "gt_boxes"):
+                assert got.dtype == want.dtype, (key, got.dtype, want.dtype)
+        else:
+            assert got.astype(str).tolist() == want.astype(str).tolist(), key
+    assert out["points_per_sample"] == [11, 6]      # this build's extra key (sizes for the device voxeliser)
+
+
+def test_data_processor_mask_and_shuffle_match_reference():
+    """mask_points_and_boxes_outside_range (x / y only, inclusive ends, boxes by >= 1 corner in the 3-D range) and the seeded
+    shuffle against the reference's DataProcessor (data_processor.py:78-103)."""
+    from toda_amd.pcdet.config import AttrDict
+    from toda_amd.pcdet.datasets.processor.data_processor import DataProcessor
+
+    z = np.load(os.path.join(G, "data_processor.npz"))
+    cfgs = [AttrDict({"NAME": "mask_points_and_boxes_outside_range", "REMOVE_OUTSIDE_BOXES": True}),
+            AttrDict({"NAME": "shuffle_points", "SHUFFLE_ENABLED": {"train": True, "test": False}})]
+    proc = DataProcessor(cfgs, point_cloud_range=z["range"], training=True, num_point_features=4)
+    np.random.seed(int(z["seed"]))
+    out = proc.forward({"points": z["in_points"].copy(), "gt_boxes": z["in_boxes"].copy()})
+    np.testing.assert_array_equal(out["gt_boxes"], z["out_boxes"])
+    np.testing.assert_array_equal(out["points"], z["out_points"])
+    assert 0 < len(z["out_boxes"]) < len(z["in_boxes"]) and len(z["out_points"]) < len(z["in_points"])

@@ -310,3 +310,20 @@ def test_groundtruth_database_cut_and_first_box_membership(tmp_path):
         lo, hi = info["global_data_offset"]
         np.testing.assert_array_equal(packed[lo:hi], want)
         assert info["num_points_in_gt"] == len(want) > 0
+
+
+def test_device_data_processor_matches_reference_fixture():
+    """Range mask (toda_points_rect + compaction) and shuffle on a CUDA cloud against the reference DataProcessor's output."""
+    import os
+    from tests.test_eval_host import ROOT
+    from toda_amd.pcdet.config import AttrDict
+    from toda_amd.pcdet.datasets.processor.data_processor import DataProcessor
+    z = np.load(os.path.join(ROOT, "tests/golden/data_processor.npz"))
+    cfgs = [AttrDict({"NAME": "mask_points_and_boxes_outside_range", "REMOVE_OUTSIDE_BOXES": True}),
+            AttrDict({"NAME": "shuffle_points", "SHUFFLE_ENABLED": {"train": True, "test": False}})]
+    proc = DataProcessor(cfgs, point_cloud_range=z["range"], training=True, num_point_features=4)
+    np.random.seed(int(z["seed"]))
+    out = proc.forward({"points": dev(z["in_points"].copy()), "gt_boxes": z["in_boxes"].copy()})
+    assert out["points"].is_cuda
+    np.testing.assert_array_equal(out["gt_boxes"], z["out_boxes"])
+    np.testing.assert_array_equal(out["points"].cpu().numpy(), z["out_points"])

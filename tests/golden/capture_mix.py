@@ -165,6 +165,59 @@ def cap_data_processor():
     print("data_processor", sc["points"].shape, "->", out["points"].shape, sc["gt_boxes"].shape, "->", out["gt_boxes"].shape)
 
 
+def cap_decode():
+    """Reference centernet_utils.decode_bbox_from_heatmap (centernet_utils.py:154-216) on random head outputs."""
+    cu = sys.modules["pcdet.models.model_utils.centernet_utils"]
+    g = torch.Generator().manual_seed(77)
+    b, ncls, h, w = 2, 3, 24, 20
+    heat = torch.rand((b, ncls, h, w), generator=g) ** 3
+    ins = {"heatmap": heat, "rot_cos": torch.randn((b, 1, h, w), generator=g), "rot_sin": torch.randn((b, 1, h, w), generator=g),
+           "center": torch.rand((b, 2, h, w), generator=g), "center_z": torch.randn((b, 1, h, w), generator=g),
+           "dim": torch.rand((b, 3, h, w), generator=g) * 3 + 0.5}
+    out = cu.decode_bbox_from_heatmap(point_cloud_range=[-9.6, -12.0, -5.0, 9.6, 12.0, 3.0], voxel_size=[0.1, 0.125, 0.2],
+                                      feature_map_stride=8, K=40, circle_nms=False, score_thresh=0.2,
+                                      post_center_limit_range=torch.tensor([-9.0, -11.0, -6.0, 9.0, 11.0, 4.0]), **ins)
+    flat = {f"in_{k}": v.numpy() for k, v in ins.items()}
+    for i, d in enumerate(out):
+        for k, v in d.items():
+            flat[f"out{i}_{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "decode_bbox.npz"), **flat)
+    print("decode", [tuple(d["pred_boxes"].shape) for d in out])
+
+
+def cap_consistency():
+    """Reference reverse_transform / get_consistency_loss of the stage-2 step (pcdet/models/__init__.py:127-260).  The file
+    imports `.detectors` (the whole detector zoo) - served by a stub with a dummy build_detector - and uses `F` without
+    importing torch.nn.functional (a defect of the reference as shipped); the name is injected."""
+    import types
+    det = types.ModuleType("pcdet.models.detectors")
+    det.build_detector = lambda **kw: None
+    sys.modules["pcdet.models.detectors"] = det
+    sys.modules["pcdet.models._ref_init.detectors"] = det       # the file is an __init__.py: it resolves `.detectors` under itself
+    m = CR._load("pcdet.models._ref_init", "pcdet/models/__init__.py")
+    m.F = torch.nn.functional
+    g = torch.Generator().manual_seed(99)
+
+    def boxes(n):
+        b = torch.cat([torch.rand((n, 3), generator=g) * 20 - 10, torch.rand((n, 3), generator=g) * 3 + 1, torch.rand((n, 1), generator=g) * 6 - 3], 1)
+        return b
+
+    org = [boxes(9), boxes(0), boxes(6)]
+    adv = [org[0][:7] + torch.randn((7, 7), generator=g) * 0.2, boxes(4), boxes(5)]
+    aug_list = [["random_world_flip", "random_world_rotation", "random_world_scaling"], ["random_world_rotation"], ["gt_sampling", "random_world_flip"]]
+    aug_params = [{"random_world_flip": ["x", "y"], "random_world_rotation": 0.3, "random_world_scaling": 1.04},
+                  {"random_world_rotation": -0.2}, {"gt_sampling": None, "random_world_flip": ["y"]}]
+    fwd = m.forward_transform([{"pred_boxes": b.clone()} for b in org], {"augmentation_list": aug_list, "augmentation_params": aug_params})
+    back = m.reverse_transform([{"pred_boxes": d["pred_boxes"].clone()} for d in fwd], {"augmentation_list": aug_list, "augmentation_params": aug_params})
+    closs, sloss = m.get_consistency_loss([{"pred_boxes": b.clone()} for b in adv], [{"pred_boxes": b.clone()} for b in org])
+    flat = {"center_loss": closs.numpy(), "size_loss": sloss.numpy()}
+    for i in range(3):
+        flat[f"org{i}"], flat[f"adv{i}"] = org[i].numpy(), adv[i].numpy()
+        flat[f"fwd{i}"], flat[f"back{i}"] = fwd[i]["pred_boxes"].numpy(), back[i]["pred_boxes"].numpy()
+    np.savez_compressed(os.path.join(OUT, "consistency.npz"), **flat)
+    print("consistency", float(closs), float(sloss))
+
+
 def main():
     M = setup()
     # CutMix needs > 10 000 target points inside the crop (inter_domain_point_cutmix.py:57)
@@ -208,6 +261,8 @@ def main():
     cap_gt_sampling()
     cap_collate()
     cap_data_processor()
+    cap_decode()
+    cap_consistency()
 
     d1, d2 = scene("nuscenes_toda", 41, 5000, 12), scene("nuscenes_toda", 42, 4000, 40)
     for name, seed, fn in [("mixup", 401, "intra_domain_point_mixup"), ("mixup_cd", 402, "intra_domain_point_mixup_cd")]:

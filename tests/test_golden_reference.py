@@ -278,3 +278,42 @@ def test_data_processor_mask_and_shuffle_match_reference():
     np.testing.assert_array_equal(out["gt_boxes"], z["out_boxes"])
     np.testing.assert_array_equal(out["points"], z["out_points"])
     assert 0 < len(z["out_boxes"]) < len(z["in_boxes"]) and len(z["out_points"]) < len(z["in_points"])
+
+
+def test_decode_bbox_from_heatmap_matches_reference():
+    """Top-K decode of the CenterHead outputs (centernet_utils.py:154-216): boxes, scores, labels per sample."""
+    from toda_amd.pcdet.models.model_utils import centernet_utils
+
+    z = np.load(os.path.join(G, "decode_bbox.npz"))
+    ins = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    out = centernet_utils.decode_bbox_from_heatmap(point_cloud_range=[-9.6, -12.0, -5.0, 9.6, 12.0, 3.0], voxel_size=[0.1, 0.125, 0.2],
+                                                   feature_map_stride=8, K=40, circle_nms=False, score_thresh=0.2,
+                                                   post_center_limit_range=torch.tensor([-9.0, -11.0, -6.0, 9.0, 11.0, 4.0]), **ins)
+    assert len(out) == 2
+    for i, d in enumerate(out):
+        assert 0 < len(z[f"out{i}_pred_scores"]) < 40
+        for key in ("pred_boxes", "pred_scores", "pred_labels"):
+            np.testing.assert_array_equal(d[key].numpy(), z[f"out{i}_{key}"], err_msg=f"{i} {key}")
+
+
+def test_consistency_helpers_match_reference():
+    """reverse_transform (and the forward direction) and get_consistency_loss of the stage-2 step against the reference's
+    functions (pcdet/models/__init__.py:127-260) on three samples: flips + rotation + scaling, an empty sample, gt_sampling in
+    the augmentation list."""
+    from toda_amd.pcdet import models as M
+
+    z = np.load(os.path.join(G, "consistency.npz"))
+    aug_list = [["random_world_flip", "random_world_rotation", "random_world_scaling"], ["random_world_rotation"], ["gt_sampling", "random_world_flip"]]
+    aug_params = [{"random_world_flip": ["x", "y"], "random_world_rotation": 0.3, "random_world_scaling": 1.04},
+                  {"random_world_rotation": -0.2}, {"gt_sampling": None, "random_world_flip": ["y"]}]
+    meta = {"augmentation_list": aug_list, "augmentation_params": aug_params}
+    fwd = [{"pred_boxes": torch.from_numpy(z[f"fwd{i}"].copy())} for i in range(3)]
+    back = M.reverse_transform(fwd, meta)
+    for i in range(3):
+        np.testing.assert_array_equal(back[i]["pred_boxes"].numpy(), z[f"back{i}"], err_msg=f"sample {i}")
+        np.testing.assert_allclose(z[f"back{i}"], z[f"org{i}"], atol=2e-5)        # and the round trip really is one
+    adv = [{"pred_boxes": torch.from_numpy(z[f"adv{i}"].copy())} for i in range(3)]
+    org = [{"pred_boxes": torch.from_numpy(z[f"org{i}"].copy())} for i in range(3)]
+    closs, sloss = M.get_consistency_loss(adv, org)
+    np.testing.assert_allclose(float(closs), float(z["center_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(float(sloss), float(z["size_loss"]), rtol=1e-6)

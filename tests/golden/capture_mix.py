@@ -218,6 +218,30 @@ def cap_consistency():
     print("consistency", float(closs), float(sloss))
 
 
+def cap_small_utils():
+    """PointFeatureEncoder (point_feature_encoder.py:4-61) and the box / angle helpers the data path leans on
+    (box_utils.py:28-72,145-158, common_utils.py:24-57)."""
+    pfe = sys.modules["pcdet.datasets.processor.point_feature_encoder"]
+    bu = sys.modules["pcdet.utils.box_utils"]
+    cu = sys.modules["pcdet.utils.common_utils"]
+    rng = np.random.default_rng(4242)
+    pts = rng.standard_normal((500, 5)).astype(np.float32)
+    pts[:, 3] = rng.uniform(0, 255, 500)
+    enc = pfe.PointFeatureEncoder(CR.EasyDict({"encoding_type": "absolute_coordinates_encoding", "used_feature_list": ["x", "y", "z", "intensity"],
+                                               "src_feature_list": ["x", "y", "z", "intensity", "timestamp"], "normalize_intensity": True}),
+                                  point_cloud_range=PC_RANGE)
+    out = enc.forward({"points": pts.copy()})
+    boxes = np.concatenate([rng.uniform(-30, 30, (40, 3)), rng.uniform(0.5, 6, (40, 3)), rng.uniform(-7, 7, (40, 1))], 1).astype(np.float32)
+    limit = np.array([-20, -25, -3, 22, 18, 2.5], np.float32)
+    np.savez_compressed(os.path.join(OUT, "small_utils.npz"), points=pts, enc_points=out["points"], enc_use_lead_xyz=out["use_lead_xyz"],
+                        enc_num_features=enc.num_point_features, boxes=boxes, limit=limit,
+                        corners=bu.boxes_to_corners_3d(boxes), mask_c1=bu.mask_boxes_outside_range_numpy(boxes, limit, 1),
+                        mask_c8=bu.mask_boxes_outside_range_numpy(boxes, limit, 8), enlarged=bu.enlarge_box3d(boxes, (0.2, 0.3, 0.1)).numpy(),
+                        limited_pi=cu.limit_period(boxes[:, 6], offset=0.5, period=np.pi), limited_2pi=cu.limit_period(boxes[:, 6], offset=0.5, period=2 * np.pi),
+                        rotated=cu.rotate_points_along_z(pts[None, :50, :], np.array([0.77]))[0])
+    print("small_utils", out["points"].shape)
+
+
 def main():
     M = setup()
     # CutMix needs > 10 000 target points inside the crop (inter_domain_point_cutmix.py:57)
@@ -263,6 +287,7 @@ def main():
     cap_data_processor()
     cap_decode()
     cap_consistency()
+    cap_small_utils()
 
     d1, d2 = scene("nuscenes_toda", 41, 5000, 12), scene("nuscenes_toda", 42, 4000, 40)
     for name, seed, fn in [("mixup", 401, "intra_domain_point_mixup"), ("mixup_cd", 402, "intra_domain_point_mixup_cd")]:

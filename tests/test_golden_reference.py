@@ -317,3 +317,26 @@ def test_consistency_helpers_match_reference():
     closs, sloss = M.get_consistency_loss(adv, org)
     np.testing.assert_allclose(float(closs), float(z["center_loss"]), rtol=1e-6)
     np.testing.assert_allclose(float(sloss), float(z["size_loss"]), rtol=1e-6)
+
+
+def test_feature_encoder_and_box_helpers_match_reference():
+    from toda_amd.pcdet.config import AttrDict
+    from toda_amd.pcdet.datasets.processor.point_feature_encoder import PointFeatureEncoder
+    from toda_amd.pcdet.utils import box_utils, common_utils
+
+    z = np.load(os.path.join(G, "small_utils.npz"))
+    enc = PointFeatureEncoder(AttrDict({"encoding_type": "absolute_coordinates_encoding", "used_feature_list": ["x", "y", "z", "intensity"],
+                                        "src_feature_list": ["x", "y", "z", "intensity", "timestamp"], "normalize_intensity": True}),
+                              point_cloud_range=np.array([-54.0, -54.0, -5.0, 54.0, 54.0, 4.8], np.float32))
+    out = enc.forward({"points": z["points"].copy()})
+    assert enc.num_point_features == int(z["enc_num_features"]) and bool(out["use_lead_xyz"]) == bool(z["enc_use_lead_xyz"])
+    np.testing.assert_array_equal(out["points"], z["enc_points"])
+    boxes, limit = z["boxes"], z["limit"]
+    np.testing.assert_array_equal(box_utils.boxes_to_corners_3d(boxes), z["corners"])
+    np.testing.assert_array_equal(box_utils.mask_boxes_outside_range_numpy(boxes, limit, 1), z["mask_c1"])
+    np.testing.assert_array_equal(box_utils.mask_boxes_outside_range_numpy(boxes, limit, 8), z["mask_c8"])
+    assert 0 < z["mask_c1"].sum() < len(boxes) and z["mask_c8"].sum() <= z["mask_c1"].sum()
+    np.testing.assert_array_equal(box_utils.enlarge_box3d(boxes, (0.2, 0.3, 0.1)).numpy(), z["enlarged"])
+    np.testing.assert_array_equal(common_utils.limit_period(boxes[:, 6], offset=0.5, period=np.pi), z["limited_pi"])
+    np.testing.assert_array_equal(common_utils.limit_period(boxes[:, 6], offset=0.5, period=2 * np.pi), z["limited_2pi"])
+    np.testing.assert_array_equal(common_utils.rotate_points_along_z(z["points"][None, :50, :], np.array([0.77]))[0], z["rotated"])

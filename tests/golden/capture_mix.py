@@ -1,7 +1,11 @@
 #!/usr/bin/env python
-"""Capture golden vectors from the REFERENCE's own mixing processors (build container only).
+"""Capture golden vectors from the REFERENCE's own data-path Python (build container only).
 
-    python tests/golden/capture_mix.py        # writes tests/golden/mix_*.npz
+    python tests/golden/capture_mix.py
+writes tests/golden/mix_*.npz (CutMix / PolarMix / LaserMix / MixUp), aug_world.npz (global flip / rotation / scaling),
+gt_sampling.npz (DataBaseSampler), collate_batch.npz, data_processor.npz (range mask + shuffle), decode_bbox.npz
+(decode_bbox_from_heatmap), consistency.npz (reverse_transform / get_consistency_loss), small_utils.npz
+(PointFeatureEncoder, box / angle helpers).
 
 The four processor files (inter_domain_point_{cutmix,polarmix,lasermix}.py, intra_domain_point_mixup.py)
 are loaded by path under a stub package named `pcdet` (they use absolute `pcdet.…` imports,

@@ -567,10 +567,15 @@ wgrad_reduce_kernel(const float* __restrict__ slab, int chunks, long long elems,
     dw[e] = s;
 }
 
-static void wgrad_plan(int n_out, int* chunks, int* rows_per_chunk) {
+// Row chunks per offset: every (chunk, offset) pair is a workgroup and a slab the reduce kernel reads back.  Measured on the
+// C3 / C5 levels: the >= 64-channel kernels (4 waves / SIMD resident) run best with at most 48 chunks (64x64 @ 389k rows 0.606 ->
+// 0.587 ms, @ 227k 0.373 -> 0.338 ms), the 32-channel ones (7 waves / SIMD) with up to 144 (32x32 @ 682k 0.418 -> 0.388 ms).
+static void wgrad_plan(int n_out, int cin, int cout, int* chunks, int* rows_per_chunk) {
+    static const int env_chunks = getenv("TODA_WG_CHUNKS") ? atoi(getenv("TODA_WG_CHUNKS")) : 0;
+    const int max_chunks = env_chunks > 0 ? env_chunks : ((tiles_pow2(cin) * tiles_pow2(cout) >= 16) ? 48 : 144);
     int ch = n_out / 2048;
     if (ch < 1) ch = 1;
-    if (ch > 96) ch = 96;
+    if (ch > max_chunks) ch = max_chunks;
     int rpc = (n_out + ch - 1) / ch;
     rpc = (rpc + 15) / 16 * 16;
     if (rpc < 16) rpc = 16;
@@ -838,7 +843,7 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
 
 extern "C" size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout) {
     int chunks, rpc;
-    wgrad_plan(n_out, &chunks, &rpc);
+    wgrad_plan(n_out, cin, cout, &chunks, &rpc);
     return align_up((size_t)chunks * k_vol * cin * cout * sizeof(float), 256);
 }
 
@@ -855,7 +860,7 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
         return TODA_OK;
     }
     int chunks, rpc;
-    wgrad_plan(n_out, &chunks, &rpc);
+    wgrad_plan(n_out, cin, cout, &chunks, &rpc);
     const size_t need = (size_t)chunks * elems * sizeof(float);
     if (ws_bytes < need) {
         set_error("wgrad: workspace %zu < required %zu", ws_bytes, need);

@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py — training samples/s of the TODA LiDAR-detection hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the env: this process IS a rank), or
+started plain, in which case this process is only a launcher: before anything touches the GPU it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (one fresh process per GPU, RCCL over xGMI),
+lets rank 0's JSON line through and exits with the child's status (reference: tools/scripts/dist_train.sh:18,
+tools/train.py:65-74,143, pcdet/utils/common_utils.py:161-176).
 
 A step = one pass of the hot path over one batch of synthetic clouds that are already resident in
 HBM: GPU voxelisation + MeanVFE -> VoxelBackBone8x (rulebooks + sparse convs) -> HeightCompression
@@ -178,7 +184,9 @@ def run_gpu(args, rank, world, device):
         # 23-31 MB of fp32 gradients: 8 MB buckets let the all-reduce of the dense part's gradients (ready first) run over
         # xGMI while the sparse backbone is still in backward; the default 25 MB would make it one bucket at the very end
         ddp_kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=8)
-        if os.environ.get("TODA_DDP_BCAST_BUFFERS", "0") == "0":
+        # broadcast_buffers stays at torch's default (True) as in the reference (tools/train.py:143): rank 0's BN running
+        # statistics are broadcast at every forward, so all ranks hold the buffers that get checkpointed
+        if os.environ.get("TODA_DDP_BCAST_BUFFERS", "1") == "0":
             ddp_kw["broadcast_buffers"] = False
         if os.environ.get("TODA_DDP_STATIC", "0") == "1":
             ddp_kw["static_graph"] = True
@@ -239,9 +247,12 @@ def run_gpu(args, rank, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for it in range(args.warmup, args.warmup + args.steps):
+    marks[0].record()
+    for k, it in enumerate(range(args.warmup, args.warmup + args.steps)):
         loss = step(it)
+        marks[k + 1].record()        # no sync: the median step time is read after the clock has stopped
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -254,8 +265,12 @@ def run_gpu(args, rank, world, device):
         elapsed = float(t.item())
     final_loss = float(loss.item())
     assert np.isfinite(final_loss), "training diverged"
+    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+    comm = None
+    if world > 1 and not fwd_only:
+        comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3)
     return {"elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
-            "dataset": dataset, "model": net}
+            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm}
 
 
 def pmc_traffic(d):
@@ -300,21 +315,26 @@ def roofline_from_timer(timer):
     return roof, rows
 
 
-def cpu_baseline(cfg, n_points=180000, mixed=False, n_scenes=5):
-    """The same train step on the host cores: CPU oracle for the sparse part (oracle/, "port"), torch
-    CPU for the dense part, on a BOUNDED sample: ONE full-size scene (bs 1), ONE train step (the C
-    port has no warm-up effects; ~20-40 s of CPU work)."""
+def cpu_baseline(cfg, workload, n_scenes=5):
+    """The SAME workload on the host cores: CPU oracle for the sparse part (oracle/, "port"), torch CPU for the dense
+    part, on a BOUNDED sample of it (a few full-size scenes at bs 1, one step each; ~10-30 s of CPU work): a full train
+    step for c3 / c5 / c5mix, the forward-only backbone pass for c2, the 2 fwd + 1 bwd consistency step for c5cl.
+    Point counts, ranges and model are the workload's own config."""
     from oracle.cpu_backend import oracle_backend
     from toda_amd.pcdet.models import model_fn_decorator
 
     def say(msg):
         print(f"[cpu_baseline] {msg}", file=sys.stderr, flush=True)
 
+    mixed, pair, fwd_only = workload.endswith("mix"), workload.endswith("cl"), workload == "c2"
     cfg = copy.deepcopy(cfg)
-    cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = n_points
     if "KINDS" not in cfg.DATA_CONFIG.SYNTHETIC and "KIND" not in cfg.DATA_CONFIG.SYNTHETIC:
         cfg.DATA_CONFIG.SYNTHETIC.KINDS = [cfg.DATA_CONFIG.SYNTHETIC.get("SOURCE_KIND", "waymo_toda")]
-    dataset = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    if pair:
+        from toda_amd.pcdet.datasets import SyntheticPairDataset
+        dataset = SyntheticPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    else:
+        dataset = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
     torch.manual_seed(1234)
     from oracle import oracle as O
 
@@ -345,28 +365,126 @@ def cpu_baseline(cfg, n_points=180000, mixed=False, n_scenes=5):
                                   dc.MIX_INC_METHOD)
         mix_s = time.perf_counter() - t0
         data = dataset.data_processor.forward({"points": mixed_scene["points"], "gt_boxes": mixed_scene["gt_boxes"], "use_lead_xyz": True})
-        batch = dataset.collate_batch([data])
+        batches = [dataset.collate_batch([data])]
         say(f"PolarMix of one scene pair on the host: {mix_s:.2f} s")
-        batches = [batch]
     else:
         batches = [dataset.collate_batch([dataset[i]]) for i in range(n_scenes)]
-    say(f"{len(batches)} scene(s) of {n_points} points on {cores} host threads ...")
+    npts = [int(len((b[0] if pair else b)["points"])) for b in batches]
+    say(f"{len(batches)} scene(s) of {npts} points on {cores} host threads ...")
+    if pair:
+        from toda_amd.pcdet.models import DistModel, model_fn_decorator_cl
+        cl_fn, cl_model = model_fn_decorator_cl(), DistModel(model)
     with oracle_backend():
         t0 = time.perf_counter()
-        for i, batch in enumerate(batches):        # one full train step per scene (bs 1): ~10 s of CPU work in total
-            optimizer.zero_grad()
-            ret = fn(model, dict(batch))
-            ret.loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
-            optimizer.step()
+        for i, batch in enumerate(batches):        # one step per scene (bs 1)
+            if fwd_only:
+                with torch.no_grad():
+                    b = dict(batch)
+                    from toda_amd.pcdet.models import load_data_to_gpu
+                    load_data_to_gpu(b)
+                    voxelize_on_gpu(b, dataset.voxel_cfg)      # ops.voxelize_batch is the oracle's inside oracle_backend()
+                    for m in (model.vfe, model.backbone_3d, model.map_to_bev_module):
+                        b = m(b)
+            else:
+                optimizer.zero_grad()
+                if pair:
+                    loss = cl_fn(cl_model, dict(batch[0]), dict(batch[1]), False).loss
+                else:
+                    loss = fn(model, dict(batch)).loss
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+                optimizer.step()
             say(f"step {i + 1}/{len(batches)} done after {time.perf_counter() - t0:.1f} s")
         dt = time.perf_counter() - t0 + mix_s
+    what = {"c2": "forward pass voxel features -> VoxelBackBone8x -> dense BEV (no gradients)",
+            "c5cl": "consistency step (2 forwards + 1 backward + optimizer)"}.get(workload, "full train step (fwd + bwd + clip + Adam)")
     return {"value": round(len(batches) / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{len(batches)} scene(s) of {n_points} points (bs 1 instead of 2), one full train step each = {dt:.1f} s in total; "
-                      f"sparse part = oracle/ C port (OpenMP, AVX2), dense part = torch CPU"}
+            "sample": f"{len(batches)} scene(s) of {sorted(set(npts))} points from this workload's own generator (bs 1), one {what} each = "
+                      f"{dt:.1f} s in total; sparse part = oracle/ C port (OpenMP, AVX2), dense part = torch CPU"}
 
 
-def main():
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a rank environment: this process never touches the GPU.  It starts one fresh process per GPU
+    through torch.distributed.run (the same command line the driver uses), lets their output through (rank 0 prints the
+    JSON line) and returns the launcher's exit status (non-zero when any rank failed)."""
+    import subprocess
+    dry = os.environ.get("TODA_BENCH_DRYRUN") == "1"
+    if not dry:
+        have = torch.cuda.device_count()      # counting devices does not initialise HIP
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible on this node", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """TODA_BENCH_DRYRUN=1: rendezvous + one all-reduce over gloo, no GPU work - exercises the launcher on a CPU-only box."""
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ones = torch.ones(1)
+    dist.all_reduce(ones)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "comm": {"ranks": int(ones.item()), "backend": "gloo"}}))
+    dist.destroy_process_group()
+    if os.environ.get("TODA_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+
+
+def comm_report(model, net, step, args, world, device, ms_per_step):
+    """Outside the timed region: how much of the gradient all-reduce the backward hides.  (i) the same steps with
+    the all-reduce switched off (DDP.no_sync) -> ms per step without communication; (ii) one flat all-reduce of the
+    gradient payload on an otherwise idle GPU.  exposed = ms_per_step - (i); hidden = (ii) - exposed."""
+    ones = torch.ones(1, device=device)
+    dist.all_reduce(ones)
+    n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    flat = torch.zeros(n_par, device=device)
+    for _ in range(3):
+        dist.all_reduce(flat)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        dist.all_reduce(flat)
+    torch.cuda.synchronize()
+    ar_ms = (time.perf_counter() - t0) / 10 * 1e3
+    k = min(args.steps, 10)
+    it0 = args.warmup + args.steps
+    with model.no_sync():
+        step(it0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for it in range(it0 + 1, it0 + 1 + k):
+            step(it)
+        torch.cuda.synchronize()
+        dist.barrier()
+        nosync_ms = (time.perf_counter() - t0) / k * 1e3
+    t = torch.tensor([ar_ms, nosync_ms], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ar_ms, nosync_ms = (float(v) for v in t.tolist())
+    exposed = max(ms_per_step - nosync_ms, 0.0)
+    return {"backend": "rccl", "ranks": int(ones.item()), "grad_bytes": 4 * n_par,
+            "allreduce_ms_standalone": round(ar_ms, 3), "ms_per_step_without_allreduce": round(nosync_ms, 3),
+            "allreduce_exposed_ms": round(exposed, 3), "allreduce_hidden_ms": round(max(ar_ms - exposed, 0.0), 3)}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -375,12 +493,18 @@ def main():
     ap.add_argument("--batches", type=int, default=2, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-gpu", type=int, default=None, help="override the workload's samples per GPU (exploration)")
-    ap.add_argument("--layers", action="store_true", help="also print the per-shape gather-GEMM table to stderr")
-    args = ap.parse_args()
+    ap.add_argument("--layers", action="store_true", help="also print the per-kernel roofline table to stderr")
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # plain `python bench.py --gpus N`: become the launcher
+        raise SystemExit(launch_ranks(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("TODA_BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -388,8 +512,7 @@ def main():
     if world > 1 or os.environ.get("TODA_FORCE_DDP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if os.environ.get("TODA_MIOPEN_FIND", "0") == "1":      # experiment knob: MIOpen find mode for the dense convs
         torch.backends.cudnn.benchmark = True
@@ -401,6 +524,7 @@ def main():
         if args.layers:
             for r in rows:
                 print(json.dumps(r), file=sys.stderr)
+        step_ms = res["step_ms"]
         line = {
             "metric": "LiDAR training samples/sec" if args.workload != "c2" else "LiDAR backbone forward samples/sec", "value": round(total_samples / res["elapsed"], 3),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -410,11 +534,16 @@ def main():
                        "points_per_cloud": {"c3": 180000, "c2": 60000}.get(args.workload, "180000/35000 alternating"),
                        "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4),
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)},
+            # per-step GPU time between events recorded at the step boundaries of rank 0 (no sync inside the region)
+            "ms_per_step_median": round(float(np.median(step_ms)), 3) if step_ms else None,
+            "ms_per_step_p10_p90": [round(float(np.percentile(step_ms, q)), 3) for q in (10, 90)] if step_ms else None,
             "roofline": roof,
         }
+        if res.get("comm"):
+            line["comm"] = res["comm"]
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(res["cfg"], mixed=args.workload.endswith("mix"))
-        print(json.dumps(line))
+            line["cpu_baseline"] = cpu_baseline(res["cfg"], args.workload)
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -1,0 +1,43 @@
+"""One rank of tests/test_gpu_ddp_rccl.py (started by torch.distributed.run, one process per GPU): the tiny CenterPoint
+model through the HIP path under DistributedDataParallel over RCCL; rank 0 stores loss + averaged gradients."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out = sys.argv[1]
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from test_ddp_gloo import _freeze_bn, _tiny_cfg
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import build_network, model_fn_decorator
+
+    cfg = _tiny_cfg()
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    torch.manual_seed(0)
+    model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).to(dev).train()
+    _freeze_bn(model)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=8)
+    batch = ds.collate_batch([ds[2 * rank], ds[2 * rank + 1]])      # DistributedSampler-style shard
+    ret = model_fn_decorator()(ddp, batch)
+    ret.loss.backward()
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    if rank == 0:
+        grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        torch.save({"loss": ret.loss.detach().cpu(), "grads": grads, "ranks": int(ones.item())}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

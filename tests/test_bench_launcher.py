@@ -1,0 +1,43 @@
+"""`python bench.py --gpus N` with N > 1 must start its own ranks (reference
+tools/scripts/dist_train.sh:18).  The launcher is exercised here without a GPU: TODA_BENCH_DRYRUN=1 makes the ranks
+rendezvous over gloo, all-reduce a one and print the JSON line instead of training."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *argv):
+    env = dict(os.environ, TODA_BENCH_DRYRUN="1", OMP_NUM_THREADS="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                          timeout=600)
+
+
+@pytest.mark.timeout(900)
+def test_plain_invocation_spawns_two_ranks_and_relays_one_line():
+    p = _run({}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["comm"]["ranks"] == 2        # both ranks took part in the all-reduce
+
+
+@pytest.mark.timeout(900)
+def test_failing_rank_gives_nonzero_exit():
+    p = _run({"TODA_BENCH_DRYRUN_FAIL_RANK": "1"}, "--gpus", "2")
+    assert p.returncode != 0
+
+
+def test_world_size_mismatch_is_an_error_not_an_assert():
+    env = dict(os.environ, TODA_BENCH_DRYRUN="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

@@ -177,3 +177,66 @@ print('ok')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_train_one_epoch_moves_train_percent_like_the_reference():
+    """reference tools/train_utils/train_utils.py:47-48: dataset.train_percent = (epoch * its + it) / (epochs * its)."""
+    from toda_amd.pcdet.config import AttrDict
+    from toda_amd.tools.train_utils.train_utils import train_one_epoch
+
+    class DS(torch.utils.data.Dataset):
+        train_percent = 0.0
+
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            return torch.zeros(1)
+
+    seen = []
+    lin = torch.nn.Linear(1, 1)
+    loader = torch.utils.data.DataLoader(DS(), batch_size=1)
+
+    def model_func(model, batch):
+        seen.append(loader.dataset.train_percent)
+        return model(batch).sum(), {}, {}
+
+    class Sched:
+        def step(self, it):
+            pass
+
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    it = 0
+    for epoch in range(2):
+        it = train_one_epoch(lin, opt, loader, model_func, Sched(), it, AttrDict(GRAD_NORM_CLIP=10), rank=1, tbar=None,
+                             total_it_each_epoch=4, dataloader_iter=iter(loader), cur_epoch=epoch, total_epoch=2)
+    assert seen == [k / 8 for k in range(8)]
+
+
+def test_polarmix_sector_schedule_follows_train_percent():
+    """ASC sectors widen with train_percent (reference inter_domain_point_polarmix.py:62-75)."""
+    from toda_amd.pcdet.datasets.processor import point_mix
+
+    w = []
+    for pct in (0.0, 0.5, 1.0):
+        sectors = point_mix.polarmix_sectors([np.pi / 4, np.pi / 2], pct, ["ASC"], np.random.RandomState(0))
+        w.append(sum(hi - lo for lo, hi in sectors))
+    assert w[0] < w[1] < w[2]
+
+
+def test_sync_batchnorm_is_never_taken_by_the_fused_row_path():
+    """--sync_bn (reference tools/train.py:117-118): a converted SparseBasicBlock must use the SyncBatchNorm modules, not the
+    per-rank fused BatchNorm1d row passes."""
+    from toda_amd import ops
+    from toda_amd.pcdet.models.backbones_3d.spconv_backbone import SparseBasicBlock
+    from functools import partial
+
+    block = SparseBasicBlock(16, 16, norm_fn=partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01), indice_key="res1")
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(block)
+    assert type(conv.bn1) is torch.nn.SyncBatchNorm
+
+    class FakeCuda:      # the predicate must say no before it looks at the tensor
+        is_cuda, dtype, shape = True, torch.float32, (1000, 16)
+
+    assert not ops.bn_rows_supported(FakeCuda(), conv.bn1)
+    assert ops.bn_rows_supported(FakeCuda(), torch.nn.BatchNorm1d(16, eps=1e-3, momentum=0.01))

@@ -41,6 +41,14 @@ __device__ __forceinline__ long long lin_index(int b, int z, int y, int x, const
     return (((long long)b * g.D + z) * g.H + y) * g.W + x;
 }
 
+// A coordinate row outside [0,B) x [0,D) x [0,H) x [0,W) (wrong batch_size, coordinates made for another grid, a
+// hand-built SparseConvTensor) must never become a bitmap address: such rows are ignored by every builder - they set
+// no bit, get no neighbours and are nobody's neighbour.
+__device__ __forceinline__ bool in_grid(const int4 c, const GridDims& g) {
+    return (unsigned)c.x < (unsigned)g.B && (unsigned)c.y < (unsigned)g.D && (unsigned)c.z < (unsigned)g.H &&
+           (unsigned)c.w < (unsigned)g.W;
+}
+
 __device__ __forceinline__ int gi_rank(const uint2* __restrict__ cells, long long lin) {
     const uint2 c = cells[lin >> 5];
     const unsigned bit = 1u << (lin & 31);
@@ -55,6 +63,7 @@ gi_mark_coords_kernel(const int4* __restrict__ idx, int n, const int32_t* __rest
     const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
     if (i >= n) return;
     const int4 c = idx[i];  // (b, z, y, x)
+    if (!in_grid(c, g)) return;
     const long long lin = lin_index(c.x, c.y, c.z, c.w, g);
     atomicOr(&cells[lin >> 5].x, 1u << (lin & 31));
 }
@@ -66,6 +75,7 @@ gi_rowof_kernel(const int4* __restrict__ idx, int n, const int32_t* __restrict__
     const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
     if (i >= n) return;
     const int4 c = idx[i];
+    if (!in_grid(c, g)) return;
     const int r = gi_rank(cells, lin_index(c.x, c.y, c.z, c.w, g));
     rowof[r] = i;
 }
@@ -93,6 +103,7 @@ gi_mark_conv_kernel(const int4* __restrict__ idx, int n, const int32_t* __restri
     const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
     if (i >= n) return;
     const int4 c = idx[i];
+    if ((unsigned)c.x >= (unsigned)cg.out.B) return;      // the spatial axes are clamped by out_coord
     for (int kz = 0; kz < cg.ks[0]; ++kz) {
         const int zo = out_coord(c.y, kz, cg.st[0], cg.pd[0], cg.out.D);
         if (zo < 0) continue;
@@ -161,13 +172,14 @@ rb_subm_kernel(const int4* __restrict__ idx, int n, GridDims g, int dz, int dy, 
     const bool live = o < n;
     int4 c = make_int4(0, 0, 0, 0);
     if (live) c = idx[o];
+    const bool inside = live && in_grid(c, g);
     uint2 cell[K];
     unsigned bit[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int kz = k / (KY * KX), ky = (k / KX) % KY, kx = k % KX;
         const int z = c.y + (kz - KZ / 2) * dz, y = c.z + (ky - KY / 2) * dy, x = c.w + (kx - KX / 2) * dx;
-        const bool ok = live && z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W;
+        const bool ok = inside && z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W;
         cell[k] = make_uint2(0u, 0u);
         bit[k] = 0u;
         if (ok) {
@@ -214,7 +226,7 @@ rb_subm_generic_kernel(const int4* __restrict__ idx, int n, GridDims g, int kz_n
                 if (live) {
                     const int z = c.y + (kz - kz_n / 2) * dz, y = c.z + (ky - ky_n / 2) * dy,
                               x = c.w + (kx - kx_n / 2) * dx;
-                    if (z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) {
+                    if (in_grid(c, g) && z >= 0 && z < g.D && y >= 0 && y < g.H && x >= 0 && x < g.W) {
                         r = gi_rank(cells, lin_index(c.x, z, y, x, g));
                         if (r >= 0 && rowof) r = rowof[r];
                     }
@@ -253,7 +265,7 @@ rb_conv_kernel(const int4* __restrict__ idx, int n_in, ConvGeom cg, const uint2*
         const int kz = k / (KY * KX), ky = (k / KX) % KY, kx = k % KX;
         cell[k] = make_uint2(0u, 0u);
         bit[k] = 0u;
-        if (live && zo[kz] >= 0 && yo[ky] >= 0 && xo[kx] >= 0) {
+        if (live && (unsigned)c.x < (unsigned)cg.out.B && zo[kz] >= 0 && yo[ky] >= 0 && xo[kx] >= 0) {
             const long long lin = lin_index(c.x, zo[kz], yo[ky], xo[kx], cg.out);
             cell[k] = cells[lin >> 5];
             bit[k] = 1u << (lin & 31);
@@ -290,7 +302,7 @@ rb_conv_generic_kernel(const int4* __restrict__ idx, int n_in, ConvGeom cg, cons
                 const int xo = out_coord(c.w, kx, cg.st[2], cg.pd[2], cg.out.W);
                 int o = -1;
                 if (live) {
-                    if (zo >= 0 && yo >= 0 && xo >= 0) {
+                    if ((unsigned)c.x < (unsigned)cg.out.B && zo >= 0 && yo >= 0 && xo >= 0) {
                         o = gi_rank(cells, lin_index(c.x, zo, yo, xo, cg.out));
                         if (o >= n_out) o = -1;
                         if (o >= 0) o2i[(size_t)k * n_out + o] = i;

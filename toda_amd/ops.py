@@ -536,8 +536,10 @@ def bn_rows(x, bn, relu, residual=None):
 
 
 def bn_rows_supported(x, bn):
+    """The fused row passes implement nn.BatchNorm1d with per-rank statistics and nothing else: a SyncBatchNorm
+    (tools/train.py --sync_bn, reference tools/train.py:117-118) or any other norm class takes its own module path."""
     c = x.shape[1]
-    return (x.is_cuda and x.dtype == torch.float32 and 4 <= c <= 128 and 256 % c == 0 and bn.affine and bn.momentum is not None
+    return (type(bn) is torch.nn.BatchNorm1d and x.is_cuda and x.dtype == torch.float32 and 4 <= c <= 128 and 256 % c == 0 and bn.affine and bn.momentum is not None
             and x.shape[0] > 1)
 
 

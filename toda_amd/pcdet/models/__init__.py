@@ -127,8 +127,10 @@ def filter_boxes_centerpoint(batch_dict, model):
     limit = torch.tensor(post.POST_CENTER_LIMIT_RANGE, dtype=torch.float32, device=ref.device)
     out = [{"pred_boxes": [], "pred_scores": []} for _ in range(batch_dict["batch_size"])]
     for pred in batch_dict["pred_dicts"]:
-        hm = pred["hm"]
-        hm = hm if (hm.min() >= 0 and hm.max() <= 1) else hm.sigmoid()  # get_loss already applied the sigmoid
+        # As the reference (:328): .sigmoid() of whatever pred_dict holds.  In the training step get_loss has already replaced
+        # pred["hm"] by its clamped sigmoid in place (center_head.py:233), so the scores here are sigmoid(sigmoid(logit)) in
+        # 0.5 .. 0.73 and every top-K box passes SCORE_THRESH - reproduced as is (no host-side probing of the values).
+        hm = pred["hm"].sigmoid()
         decoded = centernet_utils.decode_bbox_from_heatmap(
             heatmap=hm, rot_cos=pred["rot"][:, 0:1], rot_sin=pred["rot"][:, 1:2], center=pred["center"],
             center_z=pred["center_z"], dim=pred["dim"].exp(), vel=None, point_cloud_range=head.point_cloud_range,

@@ -64,7 +64,7 @@ def main(argv=None):
     wrapped = DistModel(model)
     if dist_train:
         wrapped = nn.parallel.DistributedDataParallel(wrapped, device_ids=[cfg.LOCAL_RANK % torch.cuda.device_count()],
-                                                    broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=8)  # per-rank BN running stats (only rank 0's are saved); saves one coalesced broadcast per step
+                                                    gradient_as_bucket_view=True, bucket_cap_mb=8)  # broadcast_buffers = torch default (True), as the reference
     scheduler, _ = build_scheduler(optimizer, len(loader), epochs, -1, cfg.OPTIMIZATION)
     fn = model_fn_decorator_cl()
     it = 0

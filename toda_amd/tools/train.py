@@ -105,7 +105,7 @@ def main(argv=None):
     model.train()
     if dist_train:
         model = nn.parallel.DistributedDataParallel(model, device_ids=[cfg.LOCAL_RANK % torch.cuda.device_count()],
-                                                    broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=8)  # per-rank BN running stats (only rank 0's are saved); saves one coalesced broadcast per step
+                                                    gradient_as_bucket_view=True, bucket_cap_mb=8)  # broadcast_buffers = default True as the reference (tools/train.py:143): rank 0's BN running stats reach every rank each forward
     logger.info(model)
     lr_scheduler, lr_warmup_scheduler = build_scheduler(optimizer, total_iters_each_epoch=len(train_loader),
                                                         total_epochs=args.epochs, last_epoch=last_epoch,

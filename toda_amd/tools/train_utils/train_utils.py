@@ -23,7 +23,8 @@ def _to_float(v):
 
 
 def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, accumulated_iter, optim_cfg, rank, tbar,
-                    total_it_each_epoch, dataloader_iter, tb_log=None, leave_pbar=False, log_interval=10, logger=None):
+                    total_it_each_epoch, dataloader_iter, tb_log=None, leave_pbar=False, cur_epoch=0, total_epoch=0,
+                    log_interval=10, logger=None):
     if total_it_each_epoch == len(train_loader):
         dataloader_iter = iter(train_loader)
     data_time, forward_time, batch_time = (common_utils.AverageMeter() for _ in range(3))
@@ -42,6 +43,8 @@ def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, ac
             cur_lr = optimizer.param_groups[0]["lr"]
         model.train()
         optimizer.zero_grad()
+        if total_epoch:     # reference :47-48: progress in [0, 1) drives the PolarMix ASC / DESC / SIGMOID sector schedules
+            train_loader.dataset.train_percent = (cur_epoch * total_it_each_epoch + cur_it) / (total_epoch * total_it_each_epoch)
         loss, tb_dict, disp = model_func(model, batch)
         t_fwd = time.time() - end
         loss.backward()
@@ -89,7 +92,8 @@ def train_model(model, optimizer, train_loader, model_func, lr_scheduler, optim_
         accumulated_iter = train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler=sched,
                                            accumulated_iter=accumulated_iter, optim_cfg=optim_cfg, rank=rank, tbar=None,
                                            tb_log=tb_log, total_it_each_epoch=total_it_each_epoch,
-                                           dataloader_iter=dataloader_iter, logger=logger)
+                                           dataloader_iter=dataloader_iter, cur_epoch=cur_epoch, total_epoch=total_epochs,
+                                           logger=logger)
         trained_epoch = cur_epoch + 1
         if trained_epoch % ckpt_save_interval == 0 and rank == 0 and ckpt_save_dir is not None:
             existing = sorted(glob.glob(os.path.join(str(ckpt_save_dir), "checkpoint_epoch_*.pth")), key=os.path.getmtime)

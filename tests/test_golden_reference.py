@@ -61,22 +61,29 @@ BEV_CFG = dict(LAYER_NUMS=[1, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[8, 16], UPS
                NUM_UPSAMPLE_FILTERS=[16, 16])
 
 
-def test_bev_backbone_matches_reference():
+def check_bev_backbone(device, tol=1.0):
+    """BaseBEVBackbone forward / input-grad / weight-grads / running statistics vs the reference's module (tol scales the
+    tolerances: 1 on the CPU; the GPU twin allows the library convolutions' different summation order)."""
     from toda_amd.pcdet.models.backbones_2d import BaseBEVBackbone
 
     g = load("bev_backbone")
     m = BaseBEVBackbone(AttrDict(BEV_CFG), 12).train()
     load_weights(m, g)
-    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    m = m.to(device)
+    x = torch.from_numpy(g["x"]).to(device).requires_grad_(True)
     y = m({"spatial_features": x})["spatial_features_2d"]
-    np.testing.assert_allclose(y.detach().numpy(), g["y"], rtol=1e-5, atol=1e-5)
-    y.backward(torch.from_numpy(g["gy"]))
-    np.testing.assert_allclose(x.grad.numpy(), g["gx"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["y"], rtol=1e-5 * tol, atol=1e-5 * tol)
+    y.backward(torch.from_numpy(g["gy"]).to(device))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["gx"], rtol=1e-4 * tol, atol=1e-5 * tol)
     for n, p in m.named_parameters():
-        np.testing.assert_allclose(p.grad.numpy(), g["g." + n], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g["g." + n], rtol=1e-4 * tol, atol=1e-4 * tol)
     for k, v in m.state_dict().items():
         if "running" in k:
-            np.testing.assert_allclose(v.numpy(), g["after." + k], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(v.cpu().numpy(), g["after." + k], rtol=1e-5 * tol, atol=1e-6 * tol)
+
+
+def test_bev_backbone_matches_reference():
+    check_bev_backbone("cpu")
 
 
 HEAD_CFG = dict(
@@ -158,17 +165,24 @@ def test_onecycle_and_decoupled_adam_match_reference():
             np.testing.assert_allclose(v.numpy(), g[f"s{it}.{k}"], rtol=1e-5, atol=1e-6, err_msg=f"step {it} {k}")
 
 
-def test_anchor_head_losses_match_reference():
+def check_anchor_losses(device):
     from toda_amd.pcdet.utils import loss_utils as lu
 
     g = load("anchor_losses")
-    T = torch.from_numpy
+
+    def T(a):
+        return torch.from_numpy(a).to(device)
+
     focal = lu.SigmoidFocalClassificationLoss(alpha=0.25, gamma=2.0)(T(g["logits"]), T(g["onehot"]), T(g["w"]))
-    np.testing.assert_allclose(focal.numpy(), g["focal"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(focal.cpu().numpy(), g["focal"], rtol=1e-5, atol=1e-7)
     sl1 = lu.WeightedSmoothL1Loss(code_weights=[1, 1, 1, 1, 1, 1, 0.5])(T(g["a"]), T(g["b"]), T(g["w"]))
-    np.testing.assert_allclose(sl1.numpy(), g["sl1"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(sl1.cpu().numpy(), g["sl1"], rtol=1e-5, atol=1e-7)
     ce = lu.WeightedCrossEntropyLoss()(T(g["d"]), T(g["dt"]), T(g["w"]))
-    np.testing.assert_allclose(ce.numpy(), g["ce"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ce.cpu().numpy(), g["ce"], rtol=1e-5, atol=1e-7)
+
+
+def test_anchor_head_losses_match_reference():
+    check_anchor_losses("cpu")
 
 
 C1_VOXEL = [0.16, 0.16, 4]
@@ -190,13 +204,17 @@ C1_HEAD = dict(
 )
 
 
-def test_c1_pointpillar_chain_matches_reference():
-    """BASELINE config 1 (CPU plumbing): PillarVFE -> PointPillarScatter -> BaseBEVBackbone ->
-    AnchorHeadSingle incl. anchors, target assignment, the three losses and backward."""
+def check_c1_pointpillar_chain(device, tol=1.0):
+    """BASELINE config 1: PillarVFE -> PointPillarScatter -> BaseBEVBackbone -> AnchorHeadSingle incl. anchors, target
+    assignment, the three losses and backward, against the vectors captured from the reference's own modules.  On the
+    CPU this is the "plumbing" configuration; on the GPU the same modules run with the HIP pillar scatter."""
     from toda_amd.pcdet.models.backbones_2d import BaseBEVBackbone
     from toda_amd.pcdet.models.backbones_2d.map_to_bev import PointPillarScatter
     from toda_amd.pcdet.models.backbones_3d.vfe import PillarVFE
     from toda_amd.pcdet.models.dense_heads import AnchorHeadSingle
+
+    def N(t):
+        return t.detach().cpu().numpy()
 
     g = load("c1_pointpillar_chain")
     grid = np.array([48, 48, 1])
@@ -208,31 +226,38 @@ def test_c1_pointpillar_chain_matches_reference():
     load_weights(vfe, g, "vfe.")
     load_weights(bev, g, "bev.")
     load_weights(head, g, "head.")
-    np.testing.assert_allclose(torch.cat(head.anchors, dim=-3).numpy(), g["anchors"], rtol=0, atol=1e-6)
-    voxels = torch.from_numpy(g["voxels"]).requires_grad_(True)
-    d = {"voxels": voxels, "voxel_num_points": torch.from_numpy(g["num"]), "voxel_coords": torch.from_numpy(g["coords"]),
-         "gt_boxes": torch.from_numpy(g["gt"].copy()), "batch_size": 2}
+    vfe, scatter, bev, head = vfe.to(device), scatter.to(device), bev.to(device), head.to(device)
+    if device != "cpu":
+        head.anchors = [a.to(device) for a in head.anchors]
+    np.testing.assert_allclose(N(torch.cat(head.anchors, dim=-3)), g["anchors"], rtol=0, atol=1e-6)
+    voxels = torch.from_numpy(g["voxels"]).to(device).requires_grad_(True)
+    d = {"voxels": voxels, "voxel_num_points": torch.from_numpy(g["num"]).to(device),
+         "voxel_coords": torch.from_numpy(g["coords"]).to(device), "gt_boxes": torch.from_numpy(g["gt"].copy()).to(device),
+         "batch_size": 2}
     d = vfe(d)
-    np.testing.assert_allclose(d["pillar_features"].detach().numpy(), g["pillar_features"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(N(d["pillar_features"]), g["pillar_features"], rtol=1e-5 * tol, atol=1e-6 * tol)
     d = scatter(d)
-    np.testing.assert_allclose(d["spatial_features"].detach().sum(dim=(2, 3)).numpy(), g["spatial_features_sum"], rtol=1e-4,
-                               atol=1e-4)
+    np.testing.assert_allclose(N(d["spatial_features"].sum(dim=(2, 3))), g["spatial_features_sum"], rtol=1e-4, atol=1e-4)
     d = head(bev(d))
     fr = head.forward_ret_dict
-    np.testing.assert_allclose(fr["cls_preds"].detach().numpy(), g["cls_preds"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(fr["box_preds"].detach().numpy(), g["box_preds"], rtol=1e-4, atol=1e-5)
-    np.testing.assert_allclose(fr["dir_cls_preds"].detach().numpy(), g["dir_preds"], rtol=1e-4, atol=1e-5)
-    assert np.array_equal(fr["box_cls_labels"].numpy(), g["box_cls_labels"])
-    np.testing.assert_allclose(fr["box_reg_targets"].numpy(), g["box_reg_targets"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(fr["reg_weights"].numpy(), g["reg_weights"], rtol=0, atol=0)
+    np.testing.assert_allclose(N(fr["cls_preds"]), g["cls_preds"], rtol=1e-4 * tol, atol=1e-5 * tol)
+    np.testing.assert_allclose(N(fr["box_preds"]), g["box_preds"], rtol=1e-4 * tol, atol=1e-5 * tol)
+    np.testing.assert_allclose(N(fr["dir_cls_preds"]), g["dir_preds"], rtol=1e-4 * tol, atol=1e-5 * tol)
+    assert np.array_equal(N(fr["box_cls_labels"]), g["box_cls_labels"])
+    np.testing.assert_allclose(N(fr["box_reg_targets"]), g["box_reg_targets"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(N(fr["reg_weights"]), g["reg_weights"], rtol=0, atol=0)
     loss, tb = head.get_loss()
     for mine, ref in ((loss, "loss"), (tb["rpn_loss_cls"], "loss_cls"), (tb["rpn_loss_loc"], "loss_loc"),
                       (tb["rpn_loss_dir"], "loss_dir")):
-        assert abs(float(mine) - float(g[ref])) < 1e-4 * max(1.0, abs(float(g[ref]))), ref
+        assert abs(float(mine) - float(g[ref])) < 1e-4 * tol * max(1.0, abs(float(g[ref]))), ref
     loss.backward()
-    np.testing.assert_allclose(voxels.grad.numpy(), g["gvoxels"], rtol=1e-3, atol=1e-6)
-    np.testing.assert_allclose(head.conv_cls.weight.grad.numpy(), g["g_conv_cls"], rtol=1e-3, atol=1e-5)
-    np.testing.assert_allclose(vfe.pfn_layers[0].linear.weight.grad.numpy(), g["g_pfn"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(N(voxels.grad), g["gvoxels"], rtol=1e-3 * tol, atol=1e-6 * tol)
+    np.testing.assert_allclose(N(head.conv_cls.weight.grad), g["g_conv_cls"], rtol=1e-3 * tol, atol=1e-5 * tol)
+    np.testing.assert_allclose(N(vfe.pfn_layers[0].linear.weight.grad), g["g_pfn"], rtol=1e-3 * tol, atol=1e-5 * tol)
+
+
+def test_c1_pointpillar_chain_matches_reference():
+    check_c1_pointpillar_chain("cpu")
 
 
 def test_collate_batch_matches_reference():

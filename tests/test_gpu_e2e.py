@@ -139,3 +139,64 @@ def test_batch_with_a_tiny_or_empty_sample_trains(n_second):
     ret, _, _ = model(batch)
     ret["loss"].backward()
     assert torch.isfinite(ret["loss"]) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name", ["centerpoint_voxel_waymo", "toda_stage1_centerpoint_res"])
+def test_full_size_detector_matches_oracle_backend(name):
+    """BASELINE configs 3 and 5 at their FULL size (180k-pt Waymo-shape clouds / mixed 180k + 35k, bs 2, the real grids
+    and voxel caps): same weights through the HIP path and through the CPU oracle backend, BatchNorm on its running
+    statistics.  Loss and every tb_dict entry <= 1e-3, the stage-4 sparse features (as the dense BEV map, which is
+    independent of the row order of generated index sets) <= 1e-3 relative, gradients <= 2e-3 (north star: 1e-3 fp32 for
+    features / losses)."""
+    import os
+    from oracle.cpu_backend import oracle_backend
+    from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import build_network, model_fn_decorator
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(root, CFG.format(name)), cfg)
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    torch.manual_seed(0)
+    cpu_model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).train()
+    # running statistics that are not the identity, so the eval-mode BN really scales and shifts
+    g = torch.Generator().manual_seed(1)
+    for m in cpu_model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.copy_(0.05 * torch.randn(m.running_mean.shape, generator=g))
+            m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+    _freeze_bn(cpu_model)
+    gpu_model = copy.deepcopy(cpu_model).cuda()
+    batch = ds.collate_batch([ds[0], ds[1]])
+    assert batch["points"].shape[0] > 150_000
+    fn = model_fn_decorator()
+    feats = {}
+
+    def grab(tag):
+        def hook(mod, args, out):
+            feats[tag] = out["spatial_features"].detach().cpu()
+        return hook
+
+    cpu_model.map_to_bev_module.register_forward_hook(grab("cpu"))
+    gpu_model.map_to_bev_module.register_forward_hook(grab("gpu"))
+    with oracle_backend():
+        ref = fn(cpu_model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
+        ref.loss.backward()
+    out = fn(gpu_model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
+    out.loss.backward()
+    assert abs(float(out.loss) - float(ref.loss)) <= 1e-3 * max(1.0, abs(float(ref.loss)))
+    for key in ref.tb_dict:
+        assert abs(float(out.tb_dict[key]) - float(ref.tb_dict[key])) <= 1e-3 * max(1.0, abs(float(ref.tb_dict[key]))), key
+    a, b = feats["cpu"], feats["gpu"]
+    assert a.shape == b.shape
+    rel = float((a - b).norm() / a.norm())
+    worst = float((a - b).abs().max() / a.abs().max())
+    assert rel < 1e-3 and worst < 1e-3, (rel, worst)
+    grads = [(n, p.grad, q.grad.cpu()) for (n, p), q in zip(cpu_model.named_parameters(), gpu_model.parameters()) if p.grad is not None]
+    g_all = torch.cat([p.flatten() for _, p, _ in grads])
+    d_all = torch.cat([(q - p).flatten() for _, p, q in grads])
+    global_err = float(d_all.norm() / g_all.norm())
+    assert global_err < 2e-3, global_err
+    print(f"{name}: loss {float(out.loss):.5f} vs {float(ref.loss):.5f}, BEV features rel {rel:.2e} / max {worst:.2e}, grads {global_err:.2e}")

@@ -64,3 +64,26 @@ def test_center_head_full_on_gpu_matches_reference():
     assert abs(float(loss) - float(g["loss"])) < 1e-3 * max(1, float(g["loss"]))
     loss.backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), g["gx"], rtol=2e-3, atol=2e-5)
+
+
+def test_bev_backbone_on_gpu_matches_reference():
+    """a13: BaseBEVBackbone on the device (forward, input grad, every weight grad, BN running statistics) against the
+    reference module's vectors (reference base_bev_backbone.py:81-112)."""
+    from tests.test_golden_reference import check_bev_backbone
+
+    check_bev_backbone("cuda", tol=10.0)
+
+
+def test_c1_pointpillar_chain_on_gpu_matches_reference():
+    """a6', a12', a17: PillarVFE -> HIP pillar scatter -> BEV neck -> AnchorHeadSingle (anchors, AxisAlignedTargetAssigner,
+    cls / loc / dir losses, backward) on the device against the reference chain's vectors (pillar_vfe.py:94-123,
+    anchor_head_single.py:41-75, anchor_head_template.py:101-223, axis_aligned_target_assigner.py:36-210)."""
+    from tests.test_golden_reference import check_c1_pointpillar_chain
+
+    check_c1_pointpillar_chain("cuda", tol=10.0)
+
+
+def test_anchor_head_losses_on_gpu_match_reference():
+    from tests.test_golden_reference import check_anchor_losses
+
+    check_anchor_losses("cuda")

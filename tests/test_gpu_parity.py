@@ -110,6 +110,36 @@ def test_rulebook_subm_bit_exact(shape, batch, npb, ks, dil):
     assert np.array_equal(rb.pair_cnt.cpu().numpy(), cnt0)
 
 
+def test_rulebooks_ignore_rows_outside_the_lattice():
+    """Coordinates outside [0, batch) x shape (wrong batch_size, indices made for another grid, a hand-built SparseConvTensor)
+    must not become bitmap addresses: such rows set no bit, get no neighbours and are nobody's neighbour, and the
+    tables of every other row are exactly those of the clean set."""
+    from toda_amd import ops
+
+    shape, batch = [9, 40, 36], 2
+    idx, _ = H.clustered_sparse(batch, shape, 800, 1, seed=11)
+    bad = np.array([[2, 1, 1, 1], [-1, 0, 0, 0], [0, 9, 3, 3], [1, 2, 40, 5], [0, 3, 4, -7], [7, 100000, 100000, 100000]], np.int32)
+    pos = [0, 5, 100, 200, 300, len(idx)]
+    mixed = np.insert(idx, pos, bad, axis=0)
+    keep = np.ones(len(mixed), bool)
+    bad_rows = np.array(pos) + np.arange(len(pos))
+    keep[bad_rows] = False
+    remap = np.full(len(mixed) + 1, -1, np.int64)
+    remap[:-1][keep] = np.arange(len(idx))
+
+    nbr0, cnt0 = O.rulebook_subm(idx, batch, shape)
+    rb, _ = ops.build_subm_rulebook(dev(mixed), batch, shape)
+    nbr1 = rb.nbr_fwd.cpu().numpy()
+    assert (nbr1[:, bad_rows] == -1).all()
+    assert np.array_equal(remap[nbr1[:, keep]], nbr0) and np.array_equal(rb.pair_cnt.cpu().numpy(), cnt0)
+
+    io0, sho0, o2i0, i2o0, cnt0 = O.rulebook_conv(idx, batch, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    only_batch_bad = np.insert(idx, [3, 50], np.array([[2, 1, 1, 1], [-3, 2, 2, 2]], np.int32), axis=0)
+    io1, sho1, rb2, _ = ops.build_conv_rulebook(dev(only_batch_bad), batch, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    assert np.array_equal(io1.cpu().numpy(), io0) and np.array_equal(rb2.pair_cnt.cpu().numpy(), cnt0)
+    assert (rb2.nbr_bwd.cpu().numpy()[:, [3, 51]] == -1).all()
+
+
 CONV_GEOMS = [
     ((3, 3, 3), (2, 2, 2), (1, 1, 1)),
     ((3, 3, 3), (2, 2, 2), (0, 1, 1)),

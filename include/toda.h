@@ -292,6 +292,27 @@ int toda_points_world_transform(const float* src, int n, const int32_t* n_dev, i
                                 void* stream);
 
 /* ------------------------------------------------------------------------
+ * Dense 3x3 / stride 1 / pad 1 fp32 convolution of the BEV neck and the dense heads (NCHW), replacing
+ * torch.nn.Conv2d -> cuDNN / MIOpen at pcdet/models/backbones_2d/base_bev_backbone.py:37-58,81-112 and
+ * pcdet/models/dense_heads/center_head.py:20-28,73-80 together with autograd's backward of those layers
+ * (tools/train_utils/train_utils.py:55).  Fused Winograd F(4x4,3x3) on the fp32 matrix cores; nothing of the
+ * Winograd domain is written to memory.  w is torch's [Cout][Cin][3][3].
+ *   toda_conv3x3_supported        1 when (batch, cin, cout, H, W) can run here in all three directions
+ *                                 (channels multiples of 32, W even, tensors below 4 GiB), else 0
+ *   toda_conv3x3_transform_weight u = G w G^T in the kernel's operand order; mode 0: forward,
+ *                                 mode 1: data gradient (filters rotated by 180 degrees, channel roles swapped)
+ *   toda_conv3x3_fwd              y[B][cout][H][W] = conv(x[B][cin][H][W]) (+ bias[cout], nullable).  With the
+ *                                 mode-1 operand and (cin, cout) = (Cout, Cin) of the layer it computes dX from dY
+ *   toda_conv3x3_wgrad            dw[Cout][Cin][3][3] from x and dy (workspace: per-split partial sums, folded
+ *                                 in fixed order - deterministic, no float atomics)
+ * ---------------------------------------------------------------------- */
+int toda_conv3x3_supported(int batch, int cin, int cout, int H, int W);
+size_t toda_conv3x3_weight_floats(int cout, int cin);
+int toda_conv3x3_transform_weight(const float* w, int cout, int cin, int mode, float* u, void* stream);
+int toda_conv3x3_fwd(const float* x, const float* u, const float* bias, int batch, int cin, int cout, int H,
+                     int W, float* y, void* stream);
+
+/* ------------------------------------------------------------------------
  * Instrumentation (no counterpart in the reference): per-launch durations of the gather-GEMM kernels, taken
  * from start / stop events stamped on the kernel dispatch itself (hipExtLaunchKernelGGL), i.e. the number
  * rocprofv3 --kernel-trace reports.  toda_timing_begin arms up to `capacity` launches of

@@ -1,0 +1,80 @@
+"""Dense 3x3 convolution (Winograd F(4x4,3x3) on the fp32 matrix cores, toda_amd/csrc/conv2d.hip) against a plain PyTorch
+reference of the same op: torch.nn.functional.conv2d in float64 on the CPU (the reference's layers are torch.nn.Conv2d,
+base_bev_backbone.py:37-58, center_head.py:20-28,73-80).  Tolerance: 2e-5 of the output scale (north star 1e-3 fp32)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (batch, cin, cout, H, W): full tiles, partial tiles in x / y (W = 4k + 2), ragged last tile block, bias, neck / head channel pairs
+SHAPES = [
+    (1, 32, 32, 8, 8),
+    (2, 32, 64, 12, 16),
+    (2, 64, 32, 22, 26),
+    (1, 128, 128, 47, 46),
+    (3, 256, 128, 10, 94),
+    (2, 512, 64, 20, 20),
+    (1, 64, 320, 9, 30),
+]
+
+
+def _ref(x, w, b):
+    return F.conv2d(x.double().cpu(), w.double().cpu(), None if b is None else b.double().cpu(), padding=1)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_conv3x3_forward_matches_fp64_reference(shape, with_bias):
+    from toda_amd import ops
+
+    b, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(b * 1000 + cin + cout + h)
+    x = torch.relu(torch.randn((b, cin, h, w_), generator=g)).cuda()
+    w = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda()
+    bias = torch.randn((cout,), generator=g).cuda() if with_bias else None
+    y = ops.conv3x3(x, w, bias)
+    ref = _ref(x, w, bias)
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert y.shape == ref.shape and err < 2e-5, err
+
+
+@pytest.mark.parametrize("shape", SHAPES[1:5])
+def test_conv3x3_backward_matches_fp64_autograd(shape):
+    from toda_amd import ops
+
+    b, cin, cout, h, w_ = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((b, cin, h, w_), generator=g).cuda().requires_grad_(True)
+    w = (torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda().requires_grad_(True)
+    bias = torch.randn((cout,), generator=g).cuda().requires_grad_(True)
+    gy = torch.randn((b, cout, h, w_), generator=g).cuda()
+    ops.conv3x3(x, w, bias).backward(gy)
+    xd, wd, bd = (t.detach().double().cpu().requires_grad_(True) for t in (x, w, bias))
+    F.conv2d(xd, wd, bd, padding=1).backward(gy.double().cpu())
+    for name, got, ref in (("dx", x.grad, xd.grad), ("dw", w.grad, wd.grad), ("db", bias.grad, bd.grad)):
+        err = float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < 5e-5, (name, err)
+
+
+def test_module_routing_keeps_unsupported_layers_on_torch():
+    """run_dense_sequential: 3x3 / stride-1 layers with channels % 32 == 0 take the HIP kernel, the rest (stride 2, 1x1,
+    tiny head outputs) stay on torch; results equal torch's within fp32 rounding."""
+    from toda_amd import ops
+
+    torch.manual_seed(0)
+    seq = torch.nn.Sequential(torch.nn.ZeroPad2d(1), torch.nn.Conv2d(32, 64, 3, stride=1, padding=0, bias=False), torch.nn.BatchNorm2d(64),
+                              torch.nn.ReLU(), torch.nn.Conv2d(64, 64, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.ZeroPad2d(1), torch.nn.Conv2d(64, 32, 3, stride=2, padding=0), torch.nn.Conv2d(32, 3, 3, padding=1)).cuda()
+    x = torch.randn(2, 32, 20, 24, device="cuda")
+    calls = []
+    orig = ops.conv3x3
+    ops.conv3x3 = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        y = ops.run_dense_sequential(seq, x)
+    finally:
+        ops.conv3x3 = orig
+    assert len(calls) == 2
+    ref = seq(x)
+    assert float((y - ref).abs().max()) < 1e-4 * float(ref.abs().max())

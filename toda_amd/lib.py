@@ -60,6 +60,10 @@ SIGNATURES = {
     "toda_rows_select_append": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "toda_points_rotate_z": (_i, [_vp, _i, _vp, _i, _dbl, _dbl, _vp, _vp]),
     "toda_points_world_transform": (_i, [_vp, _i, _vp, _i, _i, _i, _i, C.c_float, C.c_float, _i, C.c_float, _vp, _vp]),
+    "toda_conv3x3_supported": (_i, [_i, _i, _i, _i, _i]),
+    "toda_conv3x3_weight_floats": (_sz, [_i, _i]),
+    "toda_conv3x3_transform_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "toda_conv3x3_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "toda_timing_begin": (_i, [_i]),
     "toda_timing_end": (_i, [_vp, _i, _vp]),
     "toda_center_assign": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _dbl, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -615,6 +615,13 @@ def run_dense_sequential(seq, x):
         m = mods[i]
         if isinstance(m, torch.nn.Sequential):
             x = run_dense_sequential(m, x)
+        elif (type(m) is torch.nn.ZeroPad2d and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < len(mods) and type(mods[i + 1]) is torch.nn.Conv2d
+              and mods[i + 1].padding == (0, 0) and conv3x3_supported(x, mods[i + 1])):
+            x = conv3x3(x, mods[i + 1].weight, mods[i + 1].bias)      # ZeroPad2d(1) + Conv2d(3x3, padding 0) = one padded convolution
+            i += 2
+            continue
+        elif type(m) is torch.nn.Conv2d and m.padding == (1, 1) and conv3x3_supported(x, m):
+            x = conv3x3(x, m.weight, m.bias)
         elif type(m) is torch.nn.BatchNorm2d and bn_planes_supported(x, m):
             relu = i + 1 < len(mods) and type(mods[i + 1]) is torch.nn.ReLU
             x = bn_planes(x, m, relu)
@@ -624,6 +631,88 @@ def run_dense_sequential(seq, x):
             x = m(x)
         i += 1
     return x
+
+
+# ------------------------------------------------------------------ dense 3x3 convolution (BEV neck, heads)
+# TODA_DENSE_CONV=miopen sends every Conv2d back to torch / MIOpen (A/B knob and fallback for unsupported shapes)
+DENSE_CONV = _os.environ.get("TODA_DENSE_CONV", "winograd")
+_WINO_CACHE = {}
+
+
+def conv3x3_supported(x, conv):
+    """nn.Conv2d modules the Winograd F(4x4,3x3) kernels take: 3x3, stride 1, dilation 1, groups 1, padding 1 (or padding 0
+    behind an explicit ZeroPad2d(1), which the caller folds in), fp32 NCHW on the GPU, channels multiples of 32, even W."""
+    if DENSE_CONV != "winograd" or type(conv) is not torch.nn.Conv2d or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return False
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1:
+        return False
+    if conv.padding_mode != "zeros" or conv.in_channels != x.shape[1]:
+        return False
+    b, c, h, w = x.shape
+    return bool(L.load().toda_conv3x3_supported(b, conv.in_channels, conv.out_channels, h, w))
+
+
+def conv3x3_transform_weight(weight, mode):
+    """[Cout, Cin, 3, 3] -> G w G^T in the kernel's operand order (mode 0 forward, 1 data gradient)."""
+    lib = L.load()
+    cout, cin = weight.shape[0], weight.shape[1]
+    u = torch.empty((lib.toda_conv3x3_weight_floats(cout, cin),), dtype=torch.float32, device=weight.device)
+    L.check(lib.toda_conv3x3_transform_weight(L.ptr(weight.contiguous()), cout, cin, int(mode), L.ptr(u), L.stream()),
+            "toda_conv3x3_transform_weight")
+    return u
+
+
+def conv3x3_run(x, u, bias, cout):
+    lib = L.load()
+    b, cin, h, w = x.shape
+    y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
+    L.check(lib.toda_conv3x3_fwd(L.ptr(x), L.ptr(u), L.ptr(bias), b, cin, cout, h, w, L.ptr(y), L.stream()), "toda_conv3x3_fwd")
+    return y
+
+
+class _Conv3x3(torch.autograd.Function):
+    """y = conv2d(x, weight, bias, stride 1, padding 1).  Backward: dX = the same kernel on the rotated / transposed filters,
+    dW = the Winograd-domain wgrad kernel, dB = sum of dY."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        y = conv3x3_run(x, conv3x3_transform_weight(weight, 0), bias, weight.shape[0])
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = conv3x3_run(gy, conv3x3_transform_weight(weight, 1), None, weight.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw = conv3x3_wgrad(x, gy, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb
+
+
+def conv3x3_wgrad(x, gy, wshape):
+    lib = L.load()
+    if not hasattr(lib, "toda_conv3x3_wgrad"):
+        return torch.ops.aten.convolution_backward(gy, x, torch.empty(wshape, device=x.device), None, (1, 1), (1, 1), (1, 1), False,
+                                                   (0, 0), 1, (False, True, False))[1]
+    b, cin, h, w = x.shape
+    cout = gy.shape[1]
+    dw = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
+    ws_bytes = lib.toda_conv3x3_wgrad_workspace_bytes(b, cin, cout, h, w)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=x.device)
+    L.check(lib.toda_conv3x3_wgrad(L.ptr(x), L.ptr(gy), b, cin, cout, h, w, L.ptr(dw), L.ptr(ws), ws_bytes, L.stream()),
+            "toda_conv3x3_wgrad")
+    return dw
+
+
+def conv3x3(x, weight, bias=None):
+    return _Conv3x3.apply(x, weight, bias)
 
 
 # --------------------------------------------------------------- CenterHead target assign

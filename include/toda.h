@@ -302,15 +302,18 @@ int toda_points_world_transform(const float* src, int n, const int32_t* n_dev, i
  *   toda_conv3x3_transform_weight u = G w G^T in the kernel's operand order; mode 0: forward,
  *                                 mode 1: data gradient (filters rotated by 180 degrees, channel roles swapped)
  *   toda_conv3x3_fwd              y[B][cout][H][W] = conv(x[B][cin][H][W]) (+ bias[cout], nullable).  With the
- *                                 mode-1 operand and (cin, cout) = (Cout, Cin) of the layer it computes dX from dY
+ *                                 mode-1 operand and (cin, cout) = (Cout, Cin) of the layer it computes dX from dY.
+ *                                 ws: toda_conv3x3_workspace_bytes() bytes used by one call at a time (hand-off
+ *                                 flags, zeroed by the call itself, + partial-sum slabs of the stream-K work split)
  *   toda_conv3x3_wgrad            dw[Cout][Cin][3][3] from x and dy (workspace: per-split partial sums, folded
  *                                 in fixed order - deterministic, no float atomics)
  * ---------------------------------------------------------------------- */
 int toda_conv3x3_supported(int batch, int cin, int cout, int H, int W);
 size_t toda_conv3x3_weight_floats(int cout, int cin);
 int toda_conv3x3_transform_weight(const float* w, int cout, int cin, int mode, float* u, void* stream);
+size_t toda_conv3x3_workspace_bytes(void);
 int toda_conv3x3_fwd(const float* x, const float* u, const float* bias, int batch, int cin, int cout, int H,
-                     int W, float* y, void* stream);
+                     int W, float* y, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Instrumentation (no counterpart in the reference): per-launch durations of the gather-GEMM kernels, taken

@@ -25,6 +25,7 @@
 // Replaces torch.nn.Conv2d -> MIOpen for: pcdet/models/backbones_2d/base_bev_backbone.py:37-58,81-112 and
 // pcdet/models/dense_heads/center_head.py:20-28,73-80 (reference paths).
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -32,6 +33,7 @@ namespace toda {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 
 constexpr int WN_BLOCK = 256;     // 4 waves: (wt, wc) = 2 tile groups x 2 channel groups
 constexpr int WN_TILES = 32;      // tiles per workgroup
@@ -139,64 +141,140 @@ __device__ __forceinline__ int wn_work_id() {
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
 }
 
-// 6x6 input patch of (tile, channel): rows y0-1 .. y0+4, columns x0-1 .. x0+4; everything outside the image is the
-// zero padding and comes back as a hardware zero from an out-of-range buffer offset (no branch around a load).
-struct PatchAddr {
-    int off0;            // float index of (row y0-1, col x0-1) in this thread's channel plane of chunk 0
-    unsigned rowmask;    // bit r: input row y0-1+r inside the image (and the tile exists)
-    unsigned colmask;    // bit 0: col x0-1; bit 1: cols x0, x0+1; bit 2: cols x0+2, x0+3; bit 3: col x0+4
+// 6x6 input patch of (tile, channel): rows y0-1 .. y0+4, columns x0-1 .. x0+4.  The vector-memory path charges per LANE
+// ADDRESS (~16 cycles per wave-instruction whatever its width: 24 narrow loads per patch made the loads, not the matrix
+// pipe, the pace-setter), so a lane fetches only the four columns it owns, x0 .. x0+3, as ONE 16-byte load per row; the
+// halo columns x0-1 and x0+4 are the neighbouring tiles' columns 3 and 0 and arrive by DPP from lanes t-1 / t+1 of the
+// 16-tile group (tiles of a group are consecutive in x; where the sequence wraps to the next image row the halo is the
+// zero padding anyway).  Only lanes 0 and 15 of a group fetch their outer halo element themselves (one more load with 2
+// useful lanes per group).  Rows outside the image / tiles past the end come back as hardware zeros from an out-of-range
+// buffer offset; the channel chunk advances through the scalar offset of the load.
+struct PatchOff {
+    unsigned offc[6];    // byte offset of (row, x0) or out of range
+    unsigned offe[6];    // lane 0 of a group: (row, x0-1); lane 15: (row, x0+4); other lanes / outside the image: out of range
+    bool left, right;    // halo column x0-1 / x0+4 inside the image (or fetched by this lane itself)
+    bool tail;           // W % 4 == 2 and last tile of an image row: columns x0+2, x0+3 are padding
 };
 
-__device__ __forceinline__ PatchAddr wn_patch_addr(int tile, int chan, int C, const WinoGeom& g) {
-    PatchAddr p;
+__device__ __forceinline__ PatchOff wn_patch_off(int tile, int t, int chan, int C, const WinoGeom& g) {
+    PatchOff p;
     const bool exists = tile < g.n_tiles;
     const int tl = exists ? tile : 0;
     const int b = tl / g.tiles_img, rem = tl - b * g.tiles_img;
     const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
     const int y0 = 4 * ty, x0 = 4 * tx;
-    p.off0 = ((b * C + chan) * g.H + (y0 - 1)) * g.W + (x0 - 1);
-    p.rowmask = 0u;
+    const int base = ((b * C + chan) * g.H + (y0 - 1)) * g.W + x0;
+    const bool has_l = x0 > 0, has_r = x0 + 4 < g.W;
+    p.left = has_l || t == 0;
+    p.right = has_r || t == 15;
+    p.tail = x0 + 3 >= g.W;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        const int y = y0 - 1 + r;
-        if (exists && y >= 0 && y < g.H) p.rowmask |= 1u << r;
+        const int yy = y0 - 1 + r;
+        const bool rv = exists && yy >= 0 && yy < g.H;
+        const int row = base + r * g.W;
+        p.offc[r] = rv ? (unsigned)row * 4u : WN_OOB;
+        p.offe[r] = (rv && t == 0 && has_l) ? (unsigned)(row - 1) * 4u : (rv && t == 15 && has_r) ? (unsigned)(row + 4) * 4u : WN_OOB;
     }
-    p.colmask = (x0 > 0 ? 1u : 0u) | 2u | (x0 + 3 < g.W ? 4u : 0u) | (x0 + 4 < g.W ? 8u : 0u);
     return p;
 }
 
-__device__ __forceinline__ void wn_load_patch(__amdgpu_buffer_rsrc_t rsrc, const PatchAddr& p, int W, unsigned soff,
-                                              float (&d)[6][6]) {
+// Patch as the transform wants it: column pairs (1,2), (3,4) and (0,5) as 2-wide vectors (v_pk_* math in the column pass)
+struct Patch {
+    f32x2 p[6], q[6], e[6];     // (d[r][1], d[r][2]), (d[r][3], d[r][4]), (d[r][0], d[r][5])
+};
+
+__device__ __forceinline__ float wn_dpp_from_prev(float own, float v) {   // lane t <- lane t-1 of its 16-lane row; lane 0 keeps own
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own), __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wn_dpp_from_next(float own, float v) {   // lane t <- lane t+1; lane 15 keeps own
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, own), __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ void wn_load_patch(__amdgpu_buffer_rsrc_t rsrc, const PatchOff& o, unsigned soff, Patch& d) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        const bool rv = (p.rowmask >> r) & 1u;
-        const unsigned o = (unsigned)(p.off0 + r * W) * 4u;
-        d[r][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (rv && (p.colmask & 1u)) ? o : WN_OOB, soff, 0));
-        const f32x2 m = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, rv ? o + 4u : WN_OOB, soff, 0));
-        const f32x2 n = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (rv && (p.colmask & 4u)) ? o + 12u : WN_OOB, soff, 0));
-        d[r][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (rv && (p.colmask & 8u)) ? o + 20u : WN_OOB, soff, 0));
-        d[r][1] = m[0];
-        d[r][2] = m[1];
-        d[r][3] = n[0];
-        d[r][4] = n[1];
+        const f32x4 c = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.offc[r], soff, 0));
+        const float e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o.offe[r], soff, 0));
+        const float l = wn_dpp_from_prev(e, c[3]), rr = wn_dpp_from_next(e, c[0]);
+        d.p[r] = f32x2{c[0], c[1]};
+        d.q[r] = f32x2{o.tail ? 0.0f : c[2], o.tail ? 0.0f : c[3]};
+        d.e[r] = f32x2{o.left ? l : 0.0f, o.right ? rr : 0.0f};
     }
 }
 
-// d (6x6) -> B^T d B, written to the A image of the thread's (group, tile t, channel c)
-__device__ __forceinline__ void wn_input_transform_store(const float (&d)[6][6], float* __restrict__ dst) {
-    float t[6][6];
-#pragma unroll
-    for (int x = 0; x < 6; ++x) wn_bt(d[0][x], d[1][x], d[2][x], d[3][x], d[4][x], d[5][x], t[0][x], t[1][x], t[2][x], t[3][x], t[4][x], t[5][x]);
+__device__ __forceinline__ f32x2 wn_fma2(float c, f32x2 a, f32x2 b) {
+    return __builtin_elementwise_fma(f32x2{c, c}, a, b);
+}
+
+// B^T on two independent columns at once
+__device__ __forceinline__ void wn_bt2(const f32x2 (&d)[6], f32x2 (&v)[6]) {
+    const f32x2 a = d[3] - d[1], b = d[4] - d[2];
+    v[0] = wn_fma2(1.5f, a, wn_fma2(-2.0f, d[2], d[0] + d[4]));
+    v[1] = wn_fma2(-2.5f, d[2], wn_fma2(0.5f, d[3], d[1] + d[4]));
+    v[2] = wn_fma2(2.5f, d[3], wn_fma2(0.5f, d[2], d[4] - d[1]));
+    v[3] = wn_fma2(2.0f, a, b);
+    v[4] = wn_fma2(-0.5f, a, b);
+    v[5] = wn_fma2(1.5f, b, wn_fma2(-2.0f, d[3], d[1] + d[5]));
+}
+
+// patch -> B^T d B, written to the A image slot of the thread's (group, tile row m, channel c)
+__device__ __forceinline__ void wn_input_transform_store(const Patch& d, float* __restrict__ dst) {
+    f32x2 tp[6], tq[6], te[6];      // column pass: t[i][1..2], t[i][3..4], t[i][0 | 5]
+    wn_bt2(d.p, tp);
+    wn_bt2(d.q, tq);
+    wn_bt2(d.e, te);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         float v0, v1, v2, v3, v4, v5;
-        wn_bt(t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5], v0, v1, v2, v3, v4, v5);
+        wn_bt(te[i][0], tp[i][0], tp[i][1], tq[i][0], tq[i][1], te[i][1], v0, v1, v2, v3, v4, v5);
         dst[(i * 6 + 0) * WN_IMG] = v0;
         dst[(i * 6 + 1) * WN_IMG] = v1;
         dst[(i * 6 + 2) * WN_IMG] = v2;
         dst[(i * 6 + 3) * WN_IMG] = v3;
         dst[(i * 6 + 4) * WN_IMG] = v4;
         dst[(i * 6 + 5) * WN_IMG] = v5;
+    }
+}
+
+// MFMA row m of a 16-tile group holds tile perm(m) = 4 (m & 3) + (m >> 2) of the group (an involution).  In the
+// accumulator lane quad q, register r is row 4 q + r = tile 4 r + q: for a fixed register the four lane quads hold four
+// CONSECUTIVE tiles, so one store instruction writes 64 contiguous bytes per channel and image row.
+__device__ __forceinline__ int wn_row_of_tile(int t) { return 4 * (t & 3) + (t >> 2); }
+
+// Output transform + store of one wave's 16 tiles x 16 channels: lane = (channel n = lane & 15, quad q = lane >> 4),
+// accumulator register r = tile 4 r + q of the group (wn_row_of_tile).
+__device__ __forceinline__ void wn_epilogue(const f32x4 (&acc)[WN_FREQ], float* __restrict__ y, const float* __restrict__ bias,
+                                            int tile_base, int co, const WinoGeom& g, int lane) {
+    const float bv = bias ? bias[co] : 0.0f;
+    const bool vec4 = (g.W & 3) == 0;      // image rows 16-byte aligned: one 16-byte store per tile row
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tile = tile_base + 4 * r + (lane >> 4);
+        if (tile >= g.n_tiles) continue;
+        const int b = tile / g.tiles_img, rem = tile - b * g.tiles_img;
+        const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+        float tmp[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            wn_at(acc[0 * 6 + j][r], acc[1 * 6 + j][r], acc[2 * 6 + j][r], acc[3 * 6 + j][r], acc[4 * 6 + j][r], acc[5 * 6 + j][r],
+                  tmp[0][j], tmp[1][j], tmp[2][j], tmp[3][j]);
+        float* const row0 = y + (((size_t)b * g.Cout + co) * g.H + 4 * ty) * g.W + 4 * tx;
+        const bool right = 4 * tx + 3 < g.W;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float o0, o1, o2, o3;
+            wn_at(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o0, o1, o2, o3);
+            if (4 * ty + i < g.H) {
+                float* p = row0 + (size_t)i * g.W;
+                if (vec4) {
+                    *reinterpret_cast<f32x4*>(p) = f32x4{o0 + bv, o1 + bv, o2 + bv, o3 + bv};
+                } else {
+                    *reinterpret_cast<f32x2*>(p) = f32x2{o0 + bv, o1 + bv};
+                    if (right) *reinterpret_cast<f32x2*>(p + 2) = f32x2{o2 + bv, o3 + bv};
+                }
+            }
+        }
     }
 }
 
@@ -216,9 +294,9 @@ wino_fwd_kernel(const float* __restrict__ x, const float* __restrict__ u, const 
 
     // ---- transform role: thread = (tile group, tile t, channel c of the chunk)
     const int t_t = tid & 15, t_c = (tid >> 4) & 7, t_grp = tid >> 7;
-    const PatchAddr pa = wn_patch_addr(tile0 + t_grp * 16 + t_t, t_c, g.Cin, g);
+    const PatchOff pa = wn_patch_off(tile0 + t_grp * 16 + t_t, t_t, t_c, g.Cin, g);
     const __amdgpu_buffer_rsrc_t xr = wn_rsrc(x, (unsigned)((size_t)g.B * g.Cin * g.H * g.W * 4u));
-    float* const a_dst = ldsA + t_grp * 128 + ((t_c >> 1) * 16 + t_t) * 2 + (t_c & 1);
+    float* const a_dst = ldsA + t_grp * 128 + ((t_c >> 1) * 16 + wn_row_of_tile(t_t)) * 2 + (t_c & 1);
     const unsigned chunk_bytes = (unsigned)(WN_KC * g.H * g.W) * 4u;
 
     // ---- matrix role: wave = (wt, wc)
@@ -231,8 +309,8 @@ wino_fwd_kernel(const float* __restrict__ x, const float* __restrict__ u, const 
 #pragma unroll
     for (int f = 0; f < WN_FREQ; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float d[6][6];
-    wn_load_patch(xr, pa, g.W, 0u, d);
+    Patch d;
+    wn_load_patch(xr, pa, 0u, d);
     for (int chunk = 0; chunk < g.n_chunks; ++chunk) {
         // transformed filters of this chunk: 36 KiB straight into the B image (lane-linear, 16 B per lane)
         const float* usrc = u_blk + (size_t)chunk * (WN_FREQ * WN_IMG);
@@ -241,7 +319,7 @@ wino_fwd_kernel(const float* __restrict__ x, const float* __restrict__ u, const 
             __builtin_amdgcn_global_load_lds(usrc + it * (WN_BLOCK * 4), ldsB + it * (WN_BLOCK * 4) + wave * 256, 16, 0, 0);
         wn_input_transform_store(d, a_dst);
         __syncthreads();
-        if (chunk + 1 < g.n_chunks) wn_load_patch(xr, pa, g.W, (unsigned)(chunk + 1) * chunk_bytes, d);   // in flight under the MFMAs
+        if (chunk + 1 < g.n_chunks) wn_load_patch(xr, pa, (unsigned)(chunk + 1) * chunk_bytes, d);   // in flight under the MFMAs
 #pragma unroll
         for (int f = 0; f < WN_FREQ; f += 2) {
             const f32x2 a0 = a_frag[f * 128], b0 = b_frag[f * 128];
@@ -254,31 +332,250 @@ wino_fwd_kernel(const float* __restrict__ x, const float* __restrict__ u, const 
         __syncthreads();
     }
 
-    // ---- epilogue: lane = (channel n = lane & 15, tile quad q = lane >> 4); register r = tile 4 q + r of the wave's 16
-    const int co = cb * WN_COUT + wc * 16 + (lane & 15);
-    const float bv = bias ? bias[co] : 0.0f;
+    wn_epilogue(acc, y, bias, tile0 + wt * 16, cb * WN_COUT + wc * 16 + (lane & 15), g, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-specialised persistent variant (the default): 512-thread workgroups, one per CU.
+//   waves 0-3 (one per SIMD)  CONSUMERS: own the 36 x f32x4 accumulators of (16 tiles x 16 channels), read the A / B
+//                             fragments of the current chunk from LDS a few frequencies ahead of the MFMAs, run the output
+//                             transform at the end of a unit.  They issue no global loads and almost no VALU work.
+//   waves 4-7 (one per SIMD)  PRODUCERS: fetch the 6x6 patches two chunks ahead (registers), transform chunk q+1 and write
+//                             its A image, and start the 36 KiB LDS-DMA of its transformed filters, all while the consumers
+//                             multiply chunk q.  Double-buffered A and B images (144 KiB), ONE barrier per chunk.
+// With every wave doing both jobs (wino_fwd_kernel) the 144 accumulator registers, the prefetched patch and the transform
+// temporaries do not fit 256 VGPRs: no room to read fragments ahead, each MFMA group waits for its own LDS round trip.
+//
+// Work split ("stream-K"): the job is the sequence of (unit, chunk) steps, unit = (tile block, channel block) in that
+// order; workgroup w of G takes steps [w S / G, (w + 1) S / G) - every CU multiplies the same number of chunks (+-1) although
+// the unit count (556 or 288 for the neck layers) is no multiple of the 256 CUs.  A unit cut by a range boundary is finished
+// by the workgroup that holds its chunk 0 (the OWNER): the other workgroups on it (their ranges START inside the unit, so it is
+// the first thing they do) write their output-transformed partial sums to a per-workgroup slab and raise a per-wave flag
+// (agent-scope release); the owner, which reaches that unit at the END of its range, acquires the flags and adds the slabs in
+// workgroup order before its single store of y.  Fixed summation order: deterministic.  The slab bytes are stored
+// write-through (sc1) and each writing wave drains them before its flag store; the flag block is zeroed by a memset node in
+// front of every launch (cdna_hip_programming.md Guideline 16).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WS_BLOCK = 512;
+constexpr size_t WS_FLAG_BYTES = 4096;   // WS_MAX_GRID x 4 ints, at the start of the workspace
+constexpr int WS_MAX_GRID = 256;    // workgroups (= slabs) at most: one per CU of an MI355X
+
+struct WinoCursor {
+    int unit, chunk;
+};
+constexpr int WS_SLAB_FLOATS = WN_COUT * WN_TILES * 16;      // one unit's outputs: [wave][channel n][row i][quad tile][4]
+
+__device__ __forceinline__ long long ws_range_lo(int w, int G, long long S) { return (long long)w * S / G; }
+
+// Output transform of one wave's 16 tiles x 16 channels with the three endings of a stream-K segment:
+//   slab_out != null            contributor: partial sums -> slab (no bias), then publish
+//   else                        add the n_in contributor slabs slab_in + k * stride (k = 0 .. n_in - 1, in order), bias, store y
+// Slab element of (lane n, quad q, register r, row i): ((n * 4 + i) * 4 + r) * 16 + q * 4 .. +3 inside the wave's quarter:
+// the four quads of a store instruction write 64 contiguous bytes.
+__device__ __forceinline__ void ws_epilogue(const f32x4 (&acc)[WN_FREQ], float* __restrict__ y, const float* __restrict__ bias,
+                                            int tile_base, int co, const WinoGeom& g, int lane, float* __restrict__ slab_out,
+                                            const float* __restrict__ slab_in, int n_in, size_t slab_stride) {
+    const float bv = (bias && !slab_out) ? bias[co] : 0.0f;
+    const bool vec4 = (g.W & 3) == 0;
+    const int n = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int tile = tile0 + wt * 16 + (lane >> 4) * 4 + r;
-        if (tile >= g.n_tiles) continue;
-        const int b = tile / g.tiles_img, rem = tile - b * g.tiles_img;
-        const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+        const int tile = tile_base + 4 * r + q;
         float tmp[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
             wn_at(acc[0 * 6 + j][r], acc[1 * 6 + j][r], acc[2 * 6 + j][r], acc[3 * 6 + j][r], acc[4 * 6 + j][r], acc[5 * 6 + j][r],
                   tmp[0][j], tmp[1][j], tmp[2][j], tmp[3][j]);
-        float* const row0 = y + (((size_t)b * g.Cout + co) * g.H + 4 * ty) * g.W + 4 * tx;
-        const bool right = 4 * tx + 3 < g.W;
+        f32x4 o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float o0, o1, o2, o3;
             wn_at(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], o0, o1, o2, o3);
+            o[i] = f32x4{o0, o1, o2, o3};
+        }
+        if (slab_out) {
+            // write-through (sc1) stores: the bytes leave this XCD's L2 without an L2-wide release fence (a buffer_wbl2 per
+            // publishing wave wrote back every dirty line of the XCD - the other workgroups' output rows included)
+            const __amdgpu_buffer_rsrc_t sr = wn_rsrc(slab_out, (unsigned)(WS_SLAB_FLOATS / 4) * 4u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, o[i]), sr, (unsigned)(((n * 4 + i) * 4 + r) * 16 + q * 4) * 4u, 0, 16);
+            continue;
+        }
+        for (int k = 0; k < n_in; ++k) {
+            const float* sl = slab_in + (size_t)k * slab_stride;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] += *reinterpret_cast<const f32x4*>(sl + ((n * 4 + i) * 4 + r) * 16 + q * 4);
+        }
+        if (tile >= g.n_tiles) continue;
+        const int b = tile / g.tiles_img, rem = tile - b * g.tiles_img;
+        const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+        float* const row0 = y + (((size_t)b * g.Cout + co) * g.H + 4 * ty) * g.W + 4 * tx;
+        const bool right = 4 * tx + 3 < g.W;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             if (4 * ty + i < g.H) {
                 float* p = row0 + (size_t)i * g.W;
-                *reinterpret_cast<f32x2*>(p) = f32x2{o0 + bv, o1 + bv};
-                if (right) *reinterpret_cast<f32x2*>(p + 2) = f32x2{o2 + bv, o3 + bv};
+                const f32x4 v = o[i] + f32x4{bv, bv, bv, bv};
+                if (vec4) {
+                    *reinterpret_cast<f32x4*>(p) = v;
+                } else {
+                    *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+                    if (right) *reinterpret_cast<f32x2*>(p + 2) = f32x2{v[2], v[3]};
+                }
             }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(WS_BLOCK, 2)
+wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
+                   float* __restrict__ y, const WinoGeom g, const int n_units, float* __restrict__ slabs,
+                   int* __restrict__ flags, const int ablate) {
+    __shared__ float lds[4 * WN_FREQ * WN_IMG];   // A0 | A1 | B0 | B1
+    constexpr int IMG = WN_FREQ * WN_IMG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    const int w = wn_work_id();
+    const long long S = (long long)n_units * g.n_chunks;
+    const long long lo = ws_range_lo(w, G, S), hi = ws_range_lo(w + 1, G, S);
+    const int total = (int)(hi - lo);               // chunks this workgroup multiplies = barriers every wave passes
+    if (total == 0) return;
+
+    if (wave < 4) {
+        // ------------------------------------------------------------------ consumers
+        const int wt = wave >> 1, wc = wave & 1;
+        const f32x2* const a_frag = reinterpret_cast<const f32x2*>(lds) + wt * 64 + lane;
+        const f32x2* const b_frag = reinterpret_cast<const f32x2*>(lds + 2 * IMG) + wc * 64 + lane;
+        int q = 0;
+        long long s = lo;
+        while (s < hi) {
+            const int unit = (int)(s / g.n_chunks);
+            const int c_begin = (int)(s - (long long)unit * g.n_chunks);
+            const int c_end = (hi - s < g.n_chunks - c_begin) ? c_begin + (int)(hi - s) : g.n_chunks;
+            const int tb = unit / g.n_cout_blocks, cb = unit - tb * g.n_cout_blocks;
+            f32x4 acc[WN_FREQ];
+#pragma unroll
+            for (int f = 0; f < WN_FREQ; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int chunk = c_begin; chunk < c_end; ++chunk, ++q) {
+                __syncthreads();                                  // images of chunk q complete, images of q - 1 free
+                const f32x2* const ap = a_frag + (q & 1) * (IMG / 2);
+                const f32x2* const bp = b_frag + (q & 1) * (IMG / 2);
+                if (ablate & 8) continue;
+                constexpr int AHEAD = 4;                          // frequencies whose fragments are in flight
+                f32x2 fa[WN_FREQ], fb[WN_FREQ];
+#pragma unroll
+                for (int f = 0; f < AHEAD; ++f) {
+                    fa[f] = ap[f * 128];
+                    fb[f] = bp[f * 128];
+                }
+#pragma unroll
+                for (int f = 0; f < WN_FREQ; f += 2) {
+                    if (f + AHEAD < WN_FREQ) {
+                        fa[f + AHEAD] = ap[(f + AHEAD) * 128];
+                        fb[f + AHEAD] = bp[(f + AHEAD) * 128];
+                        fa[f + AHEAD + 1] = ap[(f + AHEAD + 1) * 128];
+                        fb[f + AHEAD + 1] = bp[(f + AHEAD + 1) * 128];
+                    }
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][0], fb[f][0], acc[f], 0, 0, 0);
+                    acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][0], fb[f + 1][0], acc[f + 1], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][1], fb[f][1], acc[f], 0, 0, 0);
+                    acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][1], fb[f + 1][1], acc[f + 1], 0, 0, 0);
+                }
+            }
+            s += c_end - c_begin;
+            const int tile_base = tb * WN_TILES + wt * 16, co = cb * WN_COUT + wc * 16 + (lane & 15);
+            if (ablate & 16) {
+                if (acc[0][0] + acc[35][3] + acc[17][1] == 12345.f) y[0] = 1.f;
+            } else if (c_begin > 0) {
+                // contributor: this range starts inside the unit - partial sums to this workgroup's slab, then publish
+                float* const mine = slabs + (size_t)w * WS_SLAB_FLOATS + wave * (WS_SLAB_FLOATS / 4);
+                ws_epilogue(acc, y, bias, tile_base, co, g, lane, mine, nullptr, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores have left
+                if (lane == 0) __hip_atomic_store(flags + w * 4 + wave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // owner (or sole worker) of the unit: wait for the workgroups w+1.. whose ranges start inside it
+                int n_in = 0;
+                if (c_end < g.n_chunks) {
+                    const long long unit_end = (long long)(unit + 1) * g.n_chunks;
+                    for (int w2 = w + 1; w2 < G && ws_range_lo(w2, G, S) < unit_end; ++w2) {
+                        if (ws_range_lo(w2 + 1, G, S) == ws_range_lo(w2, G, S)) continue;      // empty range: no slab
+                        int* const fl = flags + w2 * 4 + wave;
+                        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                        ++n_in;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                ws_epilogue(acc, y, bias, tile_base, co, g, lane, nullptr,
+                            slabs + (size_t)(w + 1) * WS_SLAB_FLOATS + wave * (WS_SLAB_FLOATS / 4), n_in, WS_SLAB_FLOATS);
+
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ producers
+        const int pt = tid - 256;
+        const int t_t = pt & 15, t_c = (pt >> 4) & 7, t_grp = pt >> 7;
+        const int a_off = t_grp * 128 + ((t_c >> 1) * 16 + wn_row_of_tile(t_t)) * 2 + (t_c & 1);
+        const __amdgpu_buffer_rsrc_t xr = wn_rsrc(x, (unsigned)((size_t)g.B * g.Cin * g.H * g.W * 4u));
+        const unsigned chunk_bytes = (unsigned)(WN_KC * g.H * g.W) * 4u;
+        const int pwave = wave - 4;
+
+        auto patch_of = [&](int unit) {
+            const int tb = unit / g.n_cout_blocks;
+            return wn_patch_off(tb * WN_TILES + t_grp * 16 + t_t, t_t, t_c, g.Cin, g);
+        };
+        auto produce = [&](const Patch& d, int unit, int chunk, int buf) {
+            const int cb = unit % g.n_cout_blocks;
+            const float* usrc = u + ((size_t)cb * g.n_chunks + chunk) * IMG + pt * 4;
+            float* const bdst = lds + (2 + buf) * IMG + pwave * 256;
+            if (!(ablate & 2)) {
+#pragma unroll
+                for (int it = 0; it < IMG / 1024; ++it) __builtin_amdgcn_global_load_lds(usrc + it * 1024, bdst + it * 1024, 16, 0, 0);
+            }
+            if (!(ablate & 4)) wn_input_transform_store(d, lds + buf * IMG + a_off);
+            else lds[buf * IMG + a_off] = d.p[0][0] + d.e[5][1] + d.q[2][0];
+        };
+
+        // chunk stream of this workgroup: step lo + q -> (unit, chunk); units are consecutive
+        const int unit0 = (int)(lo / g.n_chunks), chunk0 = (int)(lo - (long long)unit0 * g.n_chunks);
+        WinoCursor ld{unit0, chunk0};       // next chunk to fetch
+        PatchOff pa = patch_of(unit0);
+        auto fetch = [&](Patch& d, int q_fetch) {
+            if (q_fetch < total) {
+                if (!(ablate & 1)) wn_load_patch(xr, pa, (unsigned)ld.chunk * chunk_bytes, d);
+                if (++ld.chunk == g.n_chunks) {
+                    ld.chunk = 0;
+                    ld.unit += 1;
+                    if (q_fetch + 1 < total && ld.unit % g.n_cout_blocks == 0) pa = patch_of(ld.unit);   // next tile block
+                }
+            }
+        };
+        WinoCursor pr{unit0, chunk0};       // next chunk to transform
+        auto step = [&](const Patch& d, int q_prod) {
+            produce(d, pr.unit, pr.chunk, q_prod & 1);
+            if (++pr.chunk == g.n_chunks) {
+                pr.chunk = 0;
+                pr.unit += 1;
+            }
+        };
+        Patch d0, d1;
+        fetch(d0, 0);
+        fetch(d1, 1);
+        step(d0, 0);                    // chunk 0 -> images 0
+        // loop body unrolled by two so that the patch registers alternate without copies
+        int q = 0;
+        while (true) {
+            __syncthreads();            // barrier q
+            if (q + 1 >= total) break;
+            fetch(d0, q + 2);
+            step(d1, q + 1);
+            ++q;
+            __syncthreads();            // barrier q
+            if (q + 1 >= total) break;
+            fetch(d1, q + 2);
+            step(d0, q + 1);
+            ++q;
         }
     }
 }
@@ -325,14 +622,46 @@ extern "C" int toda_conv3x3_transform_weight(const float* w, int cout, int cin, 
     return TODA_OK;
 }
 
+extern "C" size_t toda_conv3x3_workspace_bytes(void) {
+    // 4 flags per workgroup, then 256 per-workgroup slabs of one unit's partial outputs (64 KiB each); see wino_fwd_ws_kernel
+    return WS_FLAG_BYTES + (size_t)WS_MAX_GRID * WS_SLAB_FLOATS * sizeof(float);
+}
+
 extern "C" int toda_conv3x3_fwd(const float* x, const float* u, const float* bias, int batch, int cin, int cout, int H, int W,
-                                float* y, void* stream) {
+                                float* y, void* ws, size_t ws_bytes, void* stream) {
     TODA_CHECK_ARG(x && u && y, "conv3x3_fwd: null pointer");
     WinoGeom g;
     int rc = wino_geom("conv3x3_fwd", batch, cin, cout, H, W, &g);
     if (rc) return rc;
-    hipLaunchKernelGGL(wino_fwd_kernel, dim3(g.n_tile_blocks * g.n_cout_blocks), dim3(WN_BLOCK), 0, (hipStream_t)stream, x, u,
-                       bias, y, g);
+    static const int variant = getenv("TODA_WINO_VARIANT") ? atoi(getenv("TODA_WINO_VARIANT")) : 1;
+    const int n_units = g.n_tile_blocks * g.n_cout_blocks;
+    if (variant == 0) {
+        hipLaunchKernelGGL(wino_fwd_kernel, dim3(n_units), dim3(WN_BLOCK), 0, (hipStream_t)stream, x, u, bias, y, g);
+    } else {
+        TODA_CHECK_ARG(ws != nullptr, "conv3x3_fwd: workspace missing");
+        if (ws_bytes < toda_conv3x3_workspace_bytes()) {
+            toda::set_error("conv3x3_fwd: workspace too small (%zu < %zu bytes)", ws_bytes, toda_conv3x3_workspace_bytes());
+            return TODA_EWORKSPACE;
+        }
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            TODA_HIP(hipGetDevice(&dev));
+            TODA_HIP(hipGetDeviceProperties(&prop, dev));
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            if (n_cu > WS_MAX_GRID) n_cu = WS_MAX_GRID;
+        }
+        // one 144-KiB workgroup per CU; never more workgroups than chunk steps
+        const long long steps = (long long)n_units * g.n_chunks;
+        const int grid = steps < n_cu ? (int)steps : n_cu;
+        int* flags = (int*)ws;                                  // 4 words per workgroup, zeroed in front of every launch
+        float* slabs = (float*)((char*)ws + WS_FLAG_BYTES);
+        TODA_HIP(hipMemsetAsync(flags, 0, WS_FLAG_BYTES, (hipStream_t)stream));
+        static const int ablate = getenv("TODA_WINO_ABLATE") ? atoi(getenv("TODA_WINO_ABLATE")) : 0;
+        hipLaunchKernelGGL(wino_fwd_ws_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, u, bias, y, g, n_units, slabs, flags,
+                           ablate);
+    }
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

@@ -662,11 +662,22 @@ def conv3x3_transform_weight(weight, mode):
     return u
 
 
+def _conv3x3_workspace(device):
+    """Per (device, stream) scratch of the stream-K work split: zeroed once, the kernel leaves its flags zero."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WINO_CACHE.get(key)
+    if ws is None:
+        ws = _WINO_CACHE[key] = torch.zeros((L.load().toda_conv3x3_workspace_bytes(),), dtype=torch.uint8, device=device)
+    return ws
+
+
 def conv3x3_run(x, u, bias, cout):
     lib = L.load()
     b, cin, h, w = x.shape
     y = torch.empty((b, cout, h, w), dtype=torch.float32, device=x.device)
-    L.check(lib.toda_conv3x3_fwd(L.ptr(x), L.ptr(u), L.ptr(bias), b, cin, cout, h, w, L.ptr(y), L.stream()), "toda_conv3x3_fwd")
+    ws = _conv3x3_workspace(x.device)
+    L.check(lib.toda_conv3x3_fwd(L.ptr(x), L.ptr(u), L.ptr(bias), b, cin, cout, h, w, L.ptr(y), L.ptr(ws), ws.numel(), L.stream()),
+            "toda_conv3x3_fwd")
     return y
 
 

@@ -312,6 +312,9 @@ int toda_conv3x3_supported(int batch, int cin, int cout, int H, int W);
 size_t toda_conv3x3_weight_floats(int cout, int cin);
 int toda_conv3x3_transform_weight(const float* w, int cout, int cin, int mode, float* u, void* stream);
 size_t toda_conv3x3_workspace_bytes(void);
+size_t toda_conv3x3_wgrad_workspace_bytes(int batch, int cin, int cout, int H, int W);
+int toda_conv3x3_wgrad(const float* x, const float* dy, int batch, int cin, int cout, int H, int W, float* dw,
+                       void* ws, size_t ws_bytes, void* stream);
 int toda_conv3x3_fwd(const float* x, const float* u, const float* bias, int batch, int cin, int cout, int H,
                      int W, float* y, void* ws, size_t ws_bytes, void* stream);
 

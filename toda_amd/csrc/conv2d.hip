@@ -580,6 +580,289 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient in the Winograd domain: dU[f][ci][co] = sum over tiles V[f][tile][ci] * dM[f][tile][co],
+// V = B^T x B (the forward's input transform), dM = A dY A^T (the transpose of the output transform), then
+// dw[co][ci] = G^T dU G.  Same machine as the forward kernel - the contraction index is the TILE instead of the input
+// channel: a chunk is 8 consecutive tiles, the A image holds V (rows = 32 input channels), the B image dM (columns = 32 output
+// channels), 36 frequencies x 2 MFMA k-steps per chunk and consumer wave.  Producers: waves 4-5 transform x (one thread =
+// one channel x two neighbouring tiles: both patches of an image row from two 16-byte loads and two halo loads), waves 6-7
+// transform dY; a thread's two tiles are the two k-slots of one 8-byte LDS store.
+// Stream-K over (unit = (ci block, co block), chunk): every segment's 36 x 32 x 32 partial sums go to slab (w + unit);
+// wino_wgrad_finish_kernel adds the slabs of a unit in workgroup order and applies G^T . G.  No float atomics.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WG_KT = 8;                                  // tiles per chunk
+constexpr int WG_SLAB_FLOATS = WN_FREQ * 32 * 32;         // [f][co 32][ci 32]
+
+// Producer thread of the wgrad kernel: ONE tile k of the chunk and one channel slot n of each operand (input channel
+// 32 cib + slot, output channel 32 cob + slot).  Lanes of a quad are four consecutive tiles: the inner halo columns of the x
+// patch arrive by DPP inside the quad, lanes 0 / 3 of the quad fetch their outer halo element themselves.  A half-wave covers
+// 4 tiles x 8 channels, so the 4-byte LDS stores of a frequency hit each bank at most twice (free).
+struct TilePos {
+    int b, ty, tx;
+    bool exists;
+};
+
+__device__ __forceinline__ TilePos wn_tile_pos(int tile, const WinoGeom& g) {
+    TilePos t;
+    t.exists = tile < g.n_tiles;
+    const int tl = t.exists ? tile : 0;
+    t.b = tl / g.tiles_img;
+    const int rem = tl - t.b * g.tiles_img;
+    t.ty = rem / g.tiles_x;
+    t.tx = rem - t.ty * g.tiles_x;
+    return t;
+}
+
+__device__ __forceinline__ void wn_tile_advance(TilePos& t, int step, int tile_after, const WinoGeom& g) {
+    t.tx += step;
+    while (t.tx >= g.tiles_x) {
+        t.tx -= g.tiles_x;
+        if (++t.ty == g.tiles_y) {
+            t.ty = 0;
+            ++t.b;
+        }
+    }
+    t.exists = tile_after < g.n_tiles;
+}
+
+__device__ __forceinline__ float wn_quad_from_prev(float own, float v) {   // lane t <- lane t-1 of its quad (quad_perm [0,0,1,2]); lane 0: own
+    const float s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x90, 0xF, 0xF, false));
+    return (threadIdx.x & 3) == 0 ? own : s;
+}
+__device__ __forceinline__ float wn_quad_from_next(float own, float v) {   // lane t <- lane t+1 of its quad (quad_perm [1,2,3,3]); lane 3: own
+    const float s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xF9, 0xF, 0xF, false));
+    return (threadIdx.x & 3) == 3 ? own : s;
+}
+
+struct XRaw {
+    f32x4 c[6];
+    float e[6];
+    bool left, right, tail;
+};
+
+__device__ __forceinline__ void wn_load_x(__amdgpu_buffer_rsrc_t rsrc, const TilePos& t, int chan, const WinoGeom& g, XRaw& d) {
+    const int y0 = 4 * t.ty, x0 = 4 * t.tx, tq = threadIdx.x & 3;
+    const int base = ((t.b * g.Cin + chan) * g.H + (y0 - 1)) * g.W + x0;
+    const bool has_l = x0 > 0, has_r = x0 + 4 < g.W;
+    d.left = has_l || tq == 0;
+    d.right = has_r || tq == 3;
+    d.tail = x0 + 3 >= g.W;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int yy = y0 - 1 + r;
+        const bool rv = t.exists && yy >= 0 && yy < g.H;
+        const int row = base + r * g.W;
+        d.c[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rv ? (unsigned)row * 4u : WN_OOB, 0, 0));
+        const unsigned oe = (rv && tq == 0 && has_l) ? (unsigned)(row - 1) * 4u : (rv && tq == 3 && has_r) ? (unsigned)(row + 4) * 4u : WN_OOB;
+        d.e[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, oe, 0, 0));
+    }
+}
+
+__device__ __forceinline__ void wn_x_transform_store(const XRaw& d, float* __restrict__ dst) {
+    Patch a;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const f32x4 c = d.c[r];
+        const float l = wn_quad_from_prev(d.e[r], c[3]), rr = wn_quad_from_next(d.e[r], c[0]);
+        a.p[r] = f32x2{c[0], c[1]};
+        a.q[r] = f32x2{d.tail ? 0.0f : c[2], d.tail ? 0.0f : c[3]};
+        a.e[r] = f32x2{d.left ? l : 0.0f, d.right ? rr : 0.0f};
+    }
+    wn_input_transform_store(a, dst);
+}
+
+struct DyRaw {
+    f32x4 c[4];
+    bool tail;
+};
+
+__device__ __forceinline__ void wn_load_dy(__amdgpu_buffer_rsrc_t rsrc, const TilePos& t, int chan, const WinoGeom& g, DyRaw& d) {
+    const int y0 = 4 * t.ty, x0 = 4 * t.tx;
+    const int base = ((t.b * g.Cout + chan) * g.H + y0) * g.W + x0;
+    d.tail = x0 + 3 >= g.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        d.c[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (t.exists && y0 + i < g.H) ? (unsigned)(base + i * g.W) * 4u : WN_OOB, 0, 0));
+}
+
+// dY tile (4 x 4) -> A dY A^T
+__device__ __forceinline__ void wn_dy_transform_store(const DyRaw& d, float* __restrict__ dst) {
+    float m[6][4];        // column pass: A applied down the 4 rows of every column
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = (x >= 2 && d.tail) ? 0.0f : d.c[i][x];
+        wn_a(y[0], y[1], y[2], y[3], m[0][x], m[1][x], m[2][x], m[3][x], m[4][x], m[5][x]);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float v[6];
+        wn_a(m[i][0], m[i][1], m[i][2], m[i][3], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * WN_IMG] = v[j];
+    }
+}
+
+struct WgradGeom {
+    WinoGeom g;
+    int n_ci_blocks, n_co_blocks, n_units, steps_per_unit;
+};
+
+__global__ void __launch_bounds__(WS_BLOCK, 2)
+wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const WgradGeom wg, float* __restrict__ slabs) {
+    __shared__ float lds[4 * WN_FREQ * WN_IMG];   // V0 | V1 | dM0 | dM1
+    constexpr int IMG = WN_FREQ * WN_IMG;
+    const WinoGeom& g = wg.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    const int w = wn_work_id();
+    const long long S = (long long)wg.n_units * wg.steps_per_unit;
+    const long long lo = ws_range_lo(w, G, S), hi = ws_range_lo(w + 1, G, S);
+    const int total = (int)(hi - lo);
+    if (total == 0) return;
+
+    if (wave < 4) {
+        // consumers: rows = input channels (V image, group wm), columns = output channels (dM image, group wn)
+        const int wm = wave >> 1, wn = wave & 1;
+        const f32x2* const a_frag = reinterpret_cast<const f32x2*>(lds) + wm * 64 + lane;
+        const f32x2* const b_frag = reinterpret_cast<const f32x2*>(lds + 2 * IMG) + wn * 64 + lane;
+        int q = 0;
+        long long s = lo;
+        while (s < hi) {
+            const int unit = (int)(s / wg.steps_per_unit);
+            const int c_begin = (int)(s - (long long)unit * wg.steps_per_unit);
+            const int c_end = (hi - s < wg.steps_per_unit - c_begin) ? c_begin + (int)(hi - s) : wg.steps_per_unit;
+            f32x4 acc[WN_FREQ];
+#pragma unroll
+            for (int f = 0; f < WN_FREQ; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int chunk = c_begin; chunk < c_end; ++chunk, ++q) {
+                __syncthreads();
+                const f32x2* const ap = a_frag + (q & 1) * (IMG / 2);
+                const f32x2* const bp = b_frag + (q & 1) * (IMG / 2);
+                constexpr int AHEAD = 4;
+                f32x2 fa[WN_FREQ], fb[WN_FREQ];
+#pragma unroll
+                for (int f = 0; f < AHEAD; ++f) {
+                    fa[f] = ap[f * 128];
+                    fb[f] = bp[f * 128];
+                }
+#pragma unroll
+                for (int f = 0; f < WN_FREQ; f += 2) {
+                    if (f + AHEAD < WN_FREQ) {
+                        fa[f + AHEAD] = ap[(f + AHEAD) * 128];
+                        fb[f + AHEAD] = bp[(f + AHEAD) * 128];
+                        fa[f + AHEAD + 1] = ap[(f + AHEAD + 1) * 128];
+                        fb[f + AHEAD + 1] = bp[(f + AHEAD + 1) * 128];
+                    }
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][0], fb[f][0], acc[f], 0, 0, 0);
+                    acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][0], fb[f + 1][0], acc[f + 1], 0, 0, 0);
+                    acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][1], fb[f][1], acc[f], 0, 0, 0);
+                    acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][1], fb[f + 1][1], acc[f + 1], 0, 0, 0);
+                }
+            }
+            s += c_end - c_begin;
+            // segment done: acc[f][r] = dU[f][ci = 16 wm + 4 quad + r][co = 16 wn + (lane & 15)] -> slab [f][co][ci]
+            float* const sl = slabs + (size_t)(w + unit) * WG_SLAB_FLOATS + (wn * 16 + (lane & 15)) * 32 + wm * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int f = 0; f < WN_FREQ; ++f) *reinterpret_cast<f32x4*>(sl + f * 1024) = acc[f];
+        }
+    } else {
+        // producers: thread = (tile k of the chunk, channel slot); see TilePos
+        const int pw = wave - 4;
+        const int k = (lane & 3) + 4 * (pw & 1), slot = (lane >> 2) + 16 * (pw >> 1);
+        const __amdgpu_buffer_rsrc_t xr = wn_rsrc(x, (unsigned)((size_t)g.B * g.Cin * g.H * g.W * 4u));
+        const __amdgpu_buffer_rsrc_t yr = wn_rsrc(dy, (unsigned)((size_t)g.B * g.Cout * g.H * g.W * 4u));
+        const int img_off = (slot >> 4) * 128 + ((k >> 1) * 16 + (slot & 15)) * 2 + (k & 1);
+        int unit = (int)(lo / wg.steps_per_unit), chunk = (int)(lo - (long long)unit * wg.steps_per_unit);
+        TilePos tp = wn_tile_pos(chunk * WG_KT + k, g);
+
+        XRaw px;
+        DyRaw py;
+        auto fetch = [&](int q_fetch) {
+            if (q_fetch >= total) return;
+            const int cib = unit / wg.n_co_blocks, cob = unit - cib * wg.n_co_blocks;
+            wn_load_x(xr, tp, cib * 32 + slot, g, px);
+            wn_load_dy(yr, tp, cob * 32 + slot, g, py);
+            if (++chunk == wg.steps_per_unit) {
+                chunk = 0;
+                ++unit;
+                tp = wn_tile_pos(k, g);
+            } else {
+                wn_tile_advance(tp, WG_KT, chunk * WG_KT + k, g);
+            }
+        };
+        auto produce = [&](int buf) {
+            wn_x_transform_store(px, lds + buf * IMG + img_off);
+            wn_dy_transform_store(py, lds + (2 + buf) * IMG + img_off);
+        };
+        fetch(0);
+        produce(0);
+        fetch(1);
+        for (int q = 0;; ++q) {
+            __syncthreads();            // barrier q: images of chunk q published
+            if (q + 1 >= total) break;
+            produce((q + 1) & 1);       // chunk q + 1 from the registers fetched one iteration ago
+            fetch(q + 2);
+        }
+    }
+}
+
+// stage 1 of the fold: red[unit][f][co][ci] = sum of the unit's segment slabs in workgroup order (one thread per element:
+// coalesced, and enough threads even when a 64-channel layer has 4 units cut into 64 segments each)
+__global__ void __launch_bounds__(WN_BLOCK)
+wino_wgrad_reduce_kernel(const float* __restrict__ slabs, const WgradGeom wg, int G, float* __restrict__ red) {
+    const long long e = (long long)blockIdx.x * WN_BLOCK + threadIdx.x;
+    if (e >= (long long)wg.n_units * WG_SLAB_FLOATS) return;
+    const int unit = (int)(e / WG_SLAB_FLOATS), off = (int)(e - (long long)unit * WG_SLAB_FLOATS);
+    const long long S = (long long)wg.n_units * wg.steps_per_unit;
+    const long long u_lo = (long long)unit * wg.steps_per_unit, u_hi = u_lo + wg.steps_per_unit;
+    int w0 = (int)(u_lo * G / S);
+    while (w0 > 0 && ws_range_lo(w0, G, S) > u_lo) --w0;
+    while (w0 + 1 < G && ws_range_lo(w0 + 1, G, S) <= u_lo) ++w0;
+    float acc = 0.0f;
+    for (int w = w0; w < G && ws_range_lo(w, G, S) < u_hi; ++w) {
+        if (ws_range_lo(w + 1, G, S) <= u_lo || ws_range_lo(w + 1, G, S) == ws_range_lo(w, G, S)) continue;
+        acc += slabs[(size_t)(w + unit) * WG_SLAB_FLOATS + off];
+    }
+    red[e] = acc;
+}
+
+// stage 2: dw[co][ci][3][3] = G^T dU G
+__global__ void __launch_bounds__(WN_BLOCK)
+wino_wgrad_finish_kernel(const float* __restrict__ red, const WgradGeom wg, float* __restrict__ dw) {
+    const int e = blockIdx.x * WN_BLOCK + threadIdx.x;
+    const int cin = wg.g.Cin, cout = wg.g.Cout;
+    if (e >= cin * cout) return;
+    const int co = e / cin, ci = e - co * cin;
+    const int unit = (ci >> 5) * wg.n_co_blocks + (co >> 5);
+    const float* sl = red + (size_t)unit * WG_SLAB_FLOATS + (co & 31) * 32 + (ci & 31);
+    double du[WN_FREQ];
+#pragma unroll
+    for (int f = 0; f < WN_FREQ; ++f) du[f] = (double)sl[f * 1024];
+    double t[3][6];     // G^T dU: t[a][j] = sum_i G[i][a] dU[i][j]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc += WN_G[i][a] * du[i * 6 + j];
+            t[a][j] = acc;
+        }
+    float* out = dw + ((size_t)co * cin + ci) * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc += t[a][j] * WN_G[j][b];
+            out[a * 3 + b] = (float)acc;
+        }
+}
+
 static int wino_geom(const char* who, int batch, int cin, int cout, int H, int W, WinoGeom* g) {
     TODA_CHECK_ARG(batch >= 1 && H >= 1 && W >= 2 && W % 2 == 0, "%s: needs batch >= 1, H >= 1 and an even W (got %d x %d x %d)", who, batch, H, W);
     TODA_CHECK_ARG(cin >= WN_KC && cin % WN_KC == 0, "%s: input channels must be a multiple of %d (got %d)", who, WN_KC, cin);
@@ -662,6 +945,57 @@ extern "C" int toda_conv3x3_fwd(const float* x, const float* u, const float* bia
         hipLaunchKernelGGL(wino_fwd_ws_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, u, bias, y, g, n_units, slabs, flags,
                            ablate);
     }
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+static int wgrad_geom(const char* who, int batch, int cin, int cout, int H, int W, WgradGeom* wg) {
+    int rc = wino_geom(who, batch, cin, cout, H, W, &wg->g);
+    if (rc) return rc;
+    TODA_CHECK_ARG(cin % 32 == 0, "%s: input channels must be a multiple of 32 (got %d)", who, cin);
+    wg->n_ci_blocks = cin / 32;
+    wg->n_co_blocks = cout / 32;
+    wg->n_units = wg->n_ci_blocks * wg->n_co_blocks;
+    wg->steps_per_unit = cdiv(wg->g.n_tiles, WG_KT);
+    return TODA_OK;
+}
+
+extern "C" size_t toda_conv3x3_wgrad_workspace_bytes(int batch, int cin, int cout, int H, int W) {
+    (void)batch, (void)H, (void)W;
+    const size_t units = (size_t)(cin / 32) * (cout / 32);
+    return (WS_MAX_GRID + 2 * units) * WG_SLAB_FLOATS * sizeof(float);   // one slab per stream-K segment (index w + unit) + the per-unit sums
+}
+
+extern "C" int toda_conv3x3_wgrad(const float* x, const float* dy, int batch, int cin, int cout, int H, int W, float* dw, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    TODA_CHECK_ARG(x && dy && dw, "conv3x3_wgrad: null pointer");
+    WgradGeom wg;
+    int rc = wgrad_geom("conv3x3_wgrad", batch, cin, cout, H, W, &wg);
+    if (rc) return rc;
+    const size_t need = toda_conv3x3_wgrad_workspace_bytes(batch, cin, cout, H, W);
+    if (!ws || ws_bytes < need) {
+        toda::set_error("conv3x3_wgrad: workspace too small (%zu < %zu bytes)", ws_bytes, need);
+        return TODA_EWORKSPACE;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TODA_HIP(hipGetDevice(&dev));
+        TODA_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (n_cu > WS_MAX_GRID) n_cu = WS_MAX_GRID;
+    }
+    const long long steps = (long long)wg.n_units * wg.steps_per_unit;
+    const int grid = steps < n_cu ? (int)steps : n_cu;
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, dy, wg, (float*)ws);
+    TODA_LAUNCH_CHECK();
+    float* red = (float*)ws + (size_t)(WS_MAX_GRID + wg.n_units) * WG_SLAB_FLOATS;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv((long long)wg.n_units * WG_SLAB_FLOATS, WN_BLOCK)), dim3(WN_BLOCK), 0,
+                       (hipStream_t)stream, (const float*)ws, wg, grid, red);
+    TODA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cdiv((long long)cin * cout, WN_BLOCK)), dim3(WN_BLOCK), 0, (hipStream_t)stream,
+                       (const float*)red, wg, dw);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

@@ -64,6 +64,8 @@ SIGNATURES = {
     "toda_conv3x3_weight_floats": (_sz, [_i, _i]),
     "toda_conv3x3_transform_weight": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "toda_conv3x3_workspace_bytes": (_sz, []),
+    "toda_conv3x3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "toda_conv3x3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_conv3x3_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_timing_begin": (_i, [_i]),
     "toda_timing_end": (_i, [_vp, _i, _vp]),

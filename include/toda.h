@@ -300,11 +300,13 @@ int toda_points_world_transform(const float* src, int n, const int32_t* n_dev, i
  *   toda_conv3x3_supported        1 when (batch, cin, cout, H, W) can run here in all three directions
  *                                 (channels multiples of 32, W even, tensors below 4 GiB), else 0
  *   toda_conv3x3_transform_weight u = G w G^T in the kernel's operand order; mode 0: forward,
- *                                 mode 1: data gradient (filters rotated by 180 degrees, channel roles swapped)
+ *                                 mode 1: data gradient (filters rotated by 180 degrees, channel roles swapped),
+ *                                 mode 2: both, forward operand first (2 x toda_conv3x3_weight_floats floats)
  *   toda_conv3x3_fwd              y[B][cout][H][W] = conv(x[B][cin][H][W]) (+ bias[cout], nullable).  With the
  *                                 mode-1 operand and (cin, cout) = (Cout, Cin) of the layer it computes dX from dY.
- *                                 ws: toda_conv3x3_workspace_bytes() bytes used by one call at a time (hand-off
- *                                 flags, zeroed by the call itself, + partial-sum slabs of the stream-K work split)
+ *                                 ws: toda_conv3x3_workspace_bytes() bytes, ZERO before the first call and used by
+ *                                 one call at a time (hand-off flags, which every call leaves zero again, +
+ *                                 partial-sum slabs of the stream-K work split)
  *   toda_conv3x3_wgrad            dw[Cout][Cin][3][3] from x and dy (workspace: per-split partial sums, folded
  *                                 in fixed order - deterministic, no float atomics)
  * ---------------------------------------------------------------------- */

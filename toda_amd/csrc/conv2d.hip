@@ -103,31 +103,39 @@ __device__ __forceinline__ void wn_a(float y0, float y1, float y2, float y3, flo
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WN_BLOCK)
 wino_weight_kernel(const float* __restrict__ w, int cout, int cin, int mode, float* __restrict__ u) {
-    const int CO = mode ? cin : cout, CI = mode ? cout : cin;
-    const int e = blockIdx.x * WN_BLOCK + threadIdx.x;
-    if (e >= CO * CI) return;
-    const int co = e / CI, ci = e % CI;
-    double g[3][3];
+    // one thread per (cb, chunk, frequency row fi, position in the 256-float image row): the six frequencies (fi, 0..5) are
+    // six stores with the whole wave on consecutive floats; mode 2 writes the forward operand followed by the data-gradient
+    // operand (36 * cout * cin floats each)
+    const unsigned per = (unsigned)6 * cout * cin;          // threads per operand
+    unsigned e = blockIdx.x * WN_BLOCK + threadIdx.x;
+    if (e >= (mode == 2 ? 2 * per : per)) return;
+    const int md = mode == 2 ? (e >= per ? 1 : 0) : mode;
+    float* dst = u;
+    if (e >= per) {
+        e -= per;
+        dst += (size_t)WN_FREQ * cout * cin;
+    }
+    const int CI = md ? cout : cin;
+    const unsigned n_chunks = (unsigned)CI >> 3;
+    // e = ((cb * n_chunks + chunk) * 6 + fi) * 256 + wc * 128 + (j * 16 + n) * 2 + s
+    const int s_ = (int)(e & 1), n = (int)((e >> 1) & 15), j = (int)((e >> 5) & 3), wc = (int)((e >> 7) & 1);
+    unsigned t = e >> 8;
+    const int fi = (int)(t % 6u);
+    t /= 6u;
+    const int chunk = (int)(t % n_chunks), cb = (int)(t / n_chunks);
+    const int co = cb * 32 + wc * 16 + n, ci = chunk * 8 + 2 * j + s_;
+    const float* const gp = w + (md ? ((size_t)ci * cin + co) : ((size_t)co * cin + ci)) * 9;
+    double tb[3];       // (G g)[fi][b]
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int b2 = 0; b2 < 3; ++b2) {
+        double acc = 0.0;
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
-            g[a][b] = mode ? (double)w[(((size_t)ci * cin + co) * 3 + (2 - a)) * 3 + (2 - b)]
-                           : (double)w[(((size_t)co * cin + ci) * 3 + a) * 3 + b];
-    double t[6][3];
+        for (int a = 0; a < 3; ++a) acc += WN_G[fi][a] * (double)(md ? gp[(2 - a) * 3 + (2 - b2)] : gp[a * 3 + b2]);
+        tb[b2] = acc;
+    }
+    dst += ((size_t)(cb * n_chunks + chunk) * WN_FREQ + fi * 6) * WN_IMG + (e & 255u);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) t[i][b] = WN_G[i][0] * g[0][b] + WN_G[i][1] * g[1][b] + WN_G[i][2] * g[2][b];
-    const int cb = co >> 5, wc = (co >> 4) & 1, n = co & 15;
-    const int chunk = ci >> 3, j = (ci & 7) >> 1, s = ci & 1;
-    const int n_chunks = CI >> 3;
-    float* dst = u + ((size_t)(cb * n_chunks + chunk) * WN_FREQ) * WN_IMG + wc * 128 + (j * 16 + n) * 2 + s;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 6; ++jj)
-            dst[(size_t)(i * 6 + jj) * WN_IMG] = (float)(t[i][0] * WN_G[jj][0] + t[i][1] * WN_G[jj][1] + t[i][2] * WN_G[jj][2]);
+    for (int fj = 0; fj < 6; ++fj) dst[(size_t)fj * WN_IMG] = (float)(tb[0] * WN_G[fj][0] + tb[1] * WN_G[fj][1] + tb[2] * WN_G[fj][2]);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const float* base, unsigned bytes) {
@@ -353,8 +361,8 @@ wino_fwd_kernel(const float* __restrict__ x, const float* __restrict__ u, const 
 // the first thing they do) write their output-transformed partial sums to a per-workgroup slab and raise a per-wave flag
 // (agent-scope release); the owner, which reaches that unit at the END of its range, acquires the flags and adds the slabs in
 // workgroup order before its single store of y.  Fixed summation order: deterministic.  The slab bytes are stored
-// write-through (sc1) and each writing wave drains them before its flag store; the flag block is zeroed by a memset node in
-// front of every launch (cdna_hip_programming.md Guideline 16).
+// write-through (sc1) and each writing wave drains them before its flag store (cdna_hip_programming.md Guideline 16); a flag is
+// lowered again by the one wave that waited for it, so the caller zeroes the workspace once, not before every launch.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int WS_BLOCK = 512;
 constexpr size_t WS_FLAG_BYTES = 4096;   // WS_MAX_GRID x 4 ints, at the start of the workspace
@@ -509,6 +517,12 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
                 }
                 ws_epilogue(acc, y, bias, tile_base, co, g, lane, nullptr,
                             slabs + (size_t)(w + 1) * WS_SLAB_FLOATS + wave * (WS_SLAB_FLOATS / 4), n_in, WS_SLAB_FLOATS);
+                if (n_in) {      // every flag is read by exactly one wave: that wave lowers it again once the slab is in its registers,
+                                 // so the workspace is all-zero between launches and no memset node is needed in front of each one
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        for (int k2 = 1; k2 <= n_in; ++k2) __hip_atomic_store(flags + (w + k2) * 4 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
 
             }
         }
@@ -895,12 +909,13 @@ extern "C" int toda_conv3x3_supported(int batch, int cin, int cout, int H, int W
 }
 
 extern "C" int toda_conv3x3_transform_weight(const float* w, int cout, int cin, int mode, float* u, void* stream) {
-    TODA_CHECK_ARG(w && u && (mode == 0 || mode == 1), "conv3x3_transform_weight: null pointer or bad mode");
-    const int CO = mode ? cin : cout, CI = mode ? cout : cin;
-    TODA_CHECK_ARG(CO % WN_COUT == 0 && CI % WN_KC == 0 && CO > 0 && CI > 0,
+    TODA_CHECK_ARG(w && u && mode >= 0 && mode <= 2, "conv3x3_transform_weight: null pointer or bad mode");
+    const int CO = mode == 1 ? cin : cout, CI = mode == 1 ? cout : cin;
+    TODA_CHECK_ARG(CO % WN_COUT == 0 && CI % WN_KC == 0 && CO > 0 && CI > 0 && (mode != 2 || (CI % WN_COUT == 0)),
                    "conv3x3_transform_weight: produced channels %% 32 and contracted channels %% 8 must be 0 (got %d, %d)", CO, CI);
-    hipLaunchKernelGGL(wino_weight_kernel, dim3(cdiv((long long)CO * CI, WN_BLOCK)), dim3(WN_BLOCK), 0, (hipStream_t)stream, w, cout,
-                       cin, mode, u);
+    const long long threads = 6LL * cout * cin * (mode == 2 ? 2 : 1);
+    TODA_CHECK_ARG(threads * 6 < (1LL << 31), "conv3x3_transform_weight: operand above 2^31 elements");
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(cdiv(threads, WN_BLOCK)), dim3(WN_BLOCK), 0, (hipStream_t)stream, w, cout, cin, mode, u);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }
@@ -938,9 +953,8 @@ extern "C" int toda_conv3x3_fwd(const float* x, const float* u, const float* bia
         // one 144-KiB workgroup per CU; never more workgroups than chunk steps
         const long long steps = (long long)n_units * g.n_chunks;
         const int grid = steps < n_cu ? (int)steps : n_cu;
-        int* flags = (int*)ws;                                  // 4 words per workgroup, zeroed in front of every launch
+        int* flags = (int*)ws;                                  // 4 words per workgroup: zero on entry, zero again on exit
         float* slabs = (float*)((char*)ws + WS_FLAG_BYTES);
-        TODA_HIP(hipMemsetAsync(flags, 0, WS_FLAG_BYTES, (hipStream_t)stream));
         static const int ablate = getenv("TODA_WINO_ABLATE") ? atoi(getenv("TODA_WINO_ABLATE")) : 0;
         hipLaunchKernelGGL(wino_fwd_ws_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, u, bias, y, g, n_units, slabs, flags,
                            ablate);

@@ -260,8 +260,120 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
     }
 }
 
+// Weights-resident variant for the narrow layers (<= 32 x 32 channels: conv_input, conv1, conv2.*, spconv2 and their
+// dgrads).  With 4 KiB or less of weights per offset a workgroup's MFMA work per offset is tiny (32 MFMAs per wave at
+// 32 -> 32), so the per-offset barrier and the unpipelined gather of gather_gemm_lds_kernel set the pace (0.05-0.32 of the
+// roof in round 1).  Here the packed weights of ALL K offsets (<= 108 KiB) are staged in LDS once per workgroup; after that
+// single barrier the 16 waves of a workgroup are independent: each walks its row tiles with the neighbour ids of offset k+2
+// and the gathered rows of offset k+1 in flight under the MFMAs of offset k, reading B fragments with ds_read_b128.  One
+// 1024-thread workgroup per CU (4 waves per SIMD), persistent over its tiles.
+constexpr int WR_BLOCK = 1024;
+template <int Q, int NT, int RT, int KMAX>
+__global__ void __launch_bounds__(WR_BLOCK)
+gather_gemm_wres_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
+                        int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ f32x4 wl[KMAX * Q * NT * 64];
+    {
+        const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
+        const int total = K * Q * NT * 64;
+        for (int e = threadIdx.x; e < total; e += WR_BLOCK) wl[e] = wp4[e];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cg * 4u);
+    const int n_tiles = (n_out + 16 * RT - 1) / (16 * RT);
+    const int wave0 = blockIdx.x * (WR_BLOCK / 64) + (threadIdx.x >> 6), wave_stride = gridDim.x * (WR_BLOCK / 64);
+    float bv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bv[n] = (bias && NT * r + n < cp) ? bias[NT * r + n] : 0.0f;
+
+    for (int tile = wave0; tile < n_tiles; tile += wave_stride) {
+        const int row0 = tile * (16 * RT);
+        f32x4 acc[RT][NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][n] = f32x4{bv[n], bv[n], bv[n], bv[n]};
+        int rows[RT];
+        bool live[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            live[rt] = row0 + rt * 16 + r < n_out;
+            rows[rt] = live[rt] ? row0 + rt * 16 + r : n_out - 1;
+        }
+        auto load_ids = [&](int k, int (&dst)[RT]) {
+            const int kk = k < K ? k : K - 1;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int v = nbr[(size_t)kk * n_out + rows[rt]];
+                dst[rt] = (k < K && live[rt]) ? v : -1;
+            }
+        };
+        int s0[RT], s1[RT], s2[RT];
+        f32x4 a0[RT][Q], a1[RT][Q];
+        load_ids(0, s0);
+        load_ids(1, s1);
+        gather_rows<Q, RT, true>(in_rsrc, cg, g, s0, a0);
+        for (int k = 0; k < K; ++k) {
+            load_ids(k + 2, s2);
+            gather_rows<Q, RT, true>(in_rsrc, cg, g, s1, a1);      // rows of offset k + 1, in flight during the MFMAs below
+            bool hit[RT];
+            bool any = false;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                hit[rt] = __any(s0[rt] >= 0);
+                any = any || hit[rt];
+            }
+            if (any) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    f32x4 b[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) b[n] = wl[((k * Q + q) * NT + n) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+                                if (hit[rt]) acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt][q][j], b[n][j], acc[rt][n], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                s0[rt] = s1[rt];
+                s1[rt] = s2[rt];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) a0[rt][q] = a1[rt][q];
+            }
+        }
+        const bool full = cp == 16 * NT;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = row0 + rt * 16 + 4 * g + reg;
+                if (row >= n_out) continue;
+                float* dst = out + (size_t)row * cp + NT * r;
+                if (full) {
+                    if constexpr (NT == 1) dst[0] = acc[rt][0][reg];
+                    else *reinterpret_cast<float2*>(dst) = make_float2(acc[rt][0][reg], acc[rt][1][reg]);
+                } else {
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        if (NT * r + n < cp) dst[n] = acc[rt][n][reg];
+                }
+            }
+        }
+    }
+}
+
 #ifndef GG_LDS_WAVES_WIDE
 #define GG_LDS_WAVES_WIDE 4   // 512-thread blocks of the 128-channel variant: 2 blocks x 8 waves per CU
+#endif
+#ifndef GG_LDS_WAVES_NARROW
+#define GG_LDS_WAVES_NARROW 4   // <= 32 x 32 channels: few MFMAs per offset, so more resident waves hide the dependent id -> row loads
 #endif
 #ifndef GG_LDS_WAVES
 #define GG_LDS_WAVES 4   // waves per SIMD asked of the compiler for the <= 64-channel LDS variants (97+32 registers otherwise: 3)
@@ -272,7 +384,7 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
 // 64 B/clk L1 path, not the MFMA pipe, sets the pace - measured 59 % matrix-pipe utilisation).
 // One barrier per offset; waves still skip the MFMAs of offsets without a neighbour in their rows.
 template <int Q, int NT, int RT, bool VEC, bool DB = true, int BLK = SC_BLOCK>
-__global__ void __launch_bounds__(BLK, (Q * NT * RT <= 32 && Q * NT <= 16) ? GG_LDS_WAVES : (BLK > SC_BLOCK ? GG_LDS_WAVES_WIDE : 1))
+__global__ void __launch_bounds__(BLK, (Q * NT <= 4 && RT <= 2) ? GG_LDS_WAVES_NARROW : (Q * NT * RT <= 32 && Q * NT <= 16) ? GG_LDS_WAVES : (BLK > SC_BLOCK ? GG_LDS_WAVES_WIDE : 1))
 gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                        const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
                        float* __restrict__ out, const int* __restrict__ order) {
@@ -744,6 +856,31 @@ extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_
         else
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
                                dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
+    // narrow layers: all K offsets of the packed weights resident in LDS (<= 108 KiB), barrier-free offset loop
+    static const int env_wres = getenv("TODA_GG_WRES") ? atoi(getenv("TODA_GG_WRES")) : 0;   // measured slower than the per-offset LDS slices (32->32 @ 682k rows 0.356 vs 0.321 ms, 16->32 0.234 vs 0.168): off
+    if (env_wres && vec_ok && order == nullptr && Q <= 2 && NT <= 2 && k_vol <= 27 && n_out >= 4096) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            TODA_HIP(hipGetDevice(&dev));
+            TODA_HIP(hipGetDeviceProperties(&prop, dev));
+            n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int tiles = cdiv(n_out, 32);
+        const int per_cu = Q * NT <= 2 ? 2 : 1;      // <= 54 KiB of weights: two workgroups (8 waves / SIMD) per CU
+        const int grid = cdiv(tiles, WR_BLOCK / 64) < n_cu * per_cu ? cdiv(tiles, WR_BLOCK / 64) : n_cu * per_cu;
+#define WR(QQ, NN)                                                                                                     \
+    GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_wres_kernel<QQ, NN, 2, 27>), dim3(grid), dim3(WR_BLOCK), 0, s, in, n_in, c_gather, wp, \
+              nbr, n_out, k_vol, c_produce, bias, out)
+        if (Q == 1 && NT == 1) WR(1, 1);
+        else if (Q == 1) WR(1, 2);
+        else if (NT == 1) WR(2, 1);
+        else WR(2, 2);
+#undef WR
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }

@@ -653,10 +653,11 @@ def conv3x3_supported(x, conv):
 
 
 def conv3x3_transform_weight(weight, mode):
-    """[Cout, Cin, 3, 3] -> G w G^T in the kernel's operand order (mode 0 forward, 1 data gradient)."""
+    """[Cout, Cin, 3, 3] -> G w G^T in the kernel's operand order (mode 0 forward, 1 data gradient, 2 both: [2, n])."""
     lib = L.load()
     cout, cin = weight.shape[0], weight.shape[1]
-    u = torch.empty((lib.toda_conv3x3_weight_floats(cout, cin),), dtype=torch.float32, device=weight.device)
+    n = lib.toda_conv3x3_weight_floats(cout, cin)
+    u = torch.empty((2, n) if mode == 2 else (n,), dtype=torch.float32, device=weight.device)
     L.check(lib.toda_conv3x3_transform_weight(L.ptr(weight.contiguous()), cout, cin, int(mode), L.ptr(u), L.stream()),
             "toda_conv3x3_transform_weight")
     return u
@@ -688,18 +689,20 @@ class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = x.contiguous()
-        y = conv3x3_run(x, conv3x3_transform_weight(weight, 0), bias, weight.shape[0])
-        ctx.save_for_backward(x, weight)
+        need_dx = ctx.needs_input_grad[0]
+        u = conv3x3_transform_weight(weight, 2 if need_dx else 0)      # both operands in one launch when dX will be wanted
+        y = conv3x3_run(x, u[0] if need_dx else u, bias, weight.shape[0])
+        ctx.save_for_backward(x, weight, u[1] if need_dx else None)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight, u_dgrad = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = conv3x3_run(gy, conv3x3_transform_weight(weight, 1), None, weight.shape[1])
+            gx = conv3x3_run(gy, u_dgrad if u_dgrad is not None else conv3x3_transform_weight(weight, 1), None, weight.shape[1])
         if ctx.needs_input_grad[1]:
             gw = conv3x3_wgrad(x, gy, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:

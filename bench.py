@@ -175,7 +175,7 @@ def run_gpu(args, rank, world, device):
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), dataset).to(device)
     model.train()
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
-    total_steps = max(args.steps + args.warmup, 10)
+    total_steps = max(args.steps + args.warmup, 10) + 16      # + the untimed steps of --layers / the comm report
     scheduler, _ = build_scheduler(optimizer, total_steps, 1, -1, cfg.OPTIMIZATION)
     net = model
     if pair:
@@ -266,24 +266,50 @@ def run_gpu(args, rank, world, device):
     final_loss = float(loss.item())
     assert np.isfinite(final_loss), "training diverged"
     step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+    op_rows = None
+    if args.layers and rank == 0:
+        from toda_amd.tools.op_table import OpTable
+        table = OpTable()
+        table.enabled = True
+        extra = 3
+        for it in range(args.warmup + args.steps, args.warmup + args.steps + extra):
+            step(it)
+        table.enabled = False
+        op_rows = table.rows(extra)
+        table.restore()
     comm = None
     if world > 1 and not fwd_only:
         comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3)
     return {"elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
-            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm}
+            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows}
+
+
+PMC_FILE = "r02_pmc_gather_gemm_64x64.json"
+
+
+def _sha256(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
 
 
 def pmc_traffic(d):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (separate FETCH_SIZE / WRITE_SIZE passes of this same command, profiles/r01_e_pmc_*.json); None
-    when no profiled launch shape matches (PMC counters cannot be read from inside bench.py)."""
-    path = os.path.join(ROOT, "profiles", "r01_e_pmc_gather_gemm_64x64.json")
-    if not os.path.exists(path) or (d["c_gather"], d["c_produce"], d["K"]) != (64, 64, 27):
-        return None
-    for shape in json.load(open(path))["launch_shapes"]:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (separate FETCH_SIZE / WRITE_SIZE
+    passes of this same command; PMC counters cannot be read from inside bench.py).  The summary records the SHA-256 of the
+    kernel source it was collected on: when toda_amd/csrc/spconv.hip has changed since, or no profiled launch shape matches,
+    the traffic is reported as null instead of a stale number.  Returns (bytes or None, where it came from)."""
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
+    if not os.path.exists(path):
+        return None, "no PMC summary committed"
+    if (d["c_gather"], d["c_produce"], d["K"]) != (64, 64, 27):
+        return None, "dominant launch shape is not the profiled 64->64 K=27 kernel"
+    pmc = json.load(open(path))
+    src = os.path.join(ROOT, "toda_amd", "csrc", "spconv.hip")
+    if pmc.get("source_sha256", {}).get("toda_amd/csrc/spconv.hip") != _sha256(src):
+        return None, f"profiles/{PMC_FILE} was collected on another version of spconv.hip (stale)"
+    for shape in pmc["launch_shapes"]:
         if 0 <= shape["grid_threads"] // 2 - d["n_out"] < 1024:      # 64 lanes per 32-row tile -> 2 threads per row
-            return shape["hbm_bytes"]
-    return None
+            return shape["hbm_bytes"], f"profiles/{PMC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel {pmc['kernel'][0]}, grid {shape['grid_threads']}"
+    return None, "no profiled launch shape matches"
 
 
 def roofline_from_timer(timer):
@@ -308,8 +334,9 @@ def roofline_from_timer(timer):
         achieved, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
     else:
         achieved, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+    traffic, traffic_source = pmc_traffic(d)
     roof = {"bound": d["bound"], "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-            "frac": round(achieved / peak, 4), "traffic": pmc_traffic(d),
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": f"gather_gemm_kernel rows={d['n_out']} K={d['K']} {d['c_gather']}->{d['c_produce']} pairs={d['pairs']}",
             "avg_launch_ms": round(d["ms"], 4)}
     return roof, rows
@@ -493,7 +520,10 @@ def main(argv=None):
     ap.add_argument("--batches", type=int, default=2, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-gpu", type=int, default=None, help="override the workload's samples per GPU (exploration)")
-    ap.add_argument("--layers", action="store_true", help="also print the per-kernel roofline table to stderr")
+    ap.add_argument("--layers", action="store_true",
+                    help="after the timed region run 3 more steps with every hand-written kernel bracketed by HIP events and print the "
+                         "per-kernel roofline table (gather-GEMM, wgrad, Winograd conv, voxelise, rulebooks, BN rows, .dense()) to stderr")
+    ap.add_argument("--layers-out", default=None, help="also write that table as JSON to this path")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # plain `python bench.py --gpus N`: become the launcher
@@ -523,7 +553,12 @@ def main(argv=None):
         roof, rows = roofline_from_timer(res["timer"])
         if args.layers:
             for r in rows:
+                print(json.dumps(dict(r, source="dispatch-stamped gather-GEMM launches inside the timed region")), file=sys.stderr)
+            for r in res["op_rows"] or []:
                 print(json.dumps(r), file=sys.stderr)
+            if args.layers_out:
+                json.dump({"workload": args.workload, "gather_gemm_timed_region": rows, "kernels": res["op_rows"]}, open(args.layers_out, "w"),
+                          indent=1)
         step_ms = res["step_ms"]
         line = {
             "metric": "LiDAR training samples/sec" if args.workload != "c2" else "LiDAR backbone forward samples/sec", "value": round(total_samples / res["elapsed"], 3),

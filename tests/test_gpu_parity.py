@@ -196,6 +196,31 @@ def test_subm_conv_fwd_dgrad_wgrad(cin, cout):
     np.testing.assert_allclose(bt.grad.cpu().numpy(), g.sum(0), rtol=1e-4, atol=1e-3)
 
 
+def test_wave_specialised_64x64_kernel_matches_oracle():
+    """The 64 -> 64 producer / consumer kernel (gather_gemm_ws_kernel: >= 8192 rows) on a set whose row count is no multiple of
+    its 128-row tiles, sparse enough that whole tiles miss some offsets, forward (with bias) and dgrad against the oracle."""
+    from toda_amd import ops
+
+    shape, batch = [11, 96, 90], 2
+    idx, feat = H.clustered_sparse(batch, shape, 7000, 64, seed=5)
+    assert len(idx) >= 8192 and len(idx) % 128 != 0
+    rng = np.random.default_rng(2)
+    w = (rng.standard_normal((64, 3, 3, 3, 64)) / np.sqrt(27 * 64)).astype(np.float32)
+    bias = rng.standard_normal(64).astype(np.float32)
+    nbr0, _ = O.rulebook_subm(idx, batch, shape)
+    out0 = O.spconv_fwd(feat, w, nbr0, bias)
+    g = rng.standard_normal(out0.shape).astype(np.float32)
+    din0 = O.spconv_dgrad(g, w, nbr0, flip_k=True)
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    x, wt, bt = dev(feat).requires_grad_(True), dev(w).requires_grad_(True), dev(bias)
+    out = ops.sparse_conv(x, wt, bt, rb)
+    out.backward(dev(g))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out0, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), din0, rtol=1e-4, atol=1e-4)
+    again = ops.sparse_conv(x.detach(), wt.detach(), bt, rb)
+    assert torch.equal(again, out.detach())       # no atomics: bit-reproducible
+
+
 @pytest.mark.parametrize("ks,st,pd", CONV_GEOMS)
 @pytest.mark.parametrize("cin,cout", [(16, 32), (64, 128)])
 def test_strided_conv_fwd_dgrad_wgrad(ks, st, pd, cin, cout):

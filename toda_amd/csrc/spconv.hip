@@ -369,6 +369,158 @@ gather_gemm_wres_kernel(const float* __restrict__ in, int n_in, int cg, const fl
     }
 }
 
+// Wave-specialised variant for the 64 -> 64 layers (the dominant launches of the step; forward and dgrad).
+// gather_gemm_lds_kernel keeps the matrix pipe 71 % busy: every wave gathers its own A fragments (dependent id -> row loads)
+// between its MFMA bursts and meets the other waves at a barrier per offset.  Here a 512-thread workgroup owns 128 rows:
+//   waves 4-7  PRODUCERS: per offset, the 128 gathered rows go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 64 rows x
+//              one 16-byte piece per instruction; "no neighbour" = out-of-range offset = hardware zero; the neighbour ids
+//              are fetched one offset earlier), laid out [piece = 16 q + 4 g][row] so that the consumers' ds_read_b128 are
+//              conflict free; the offset's 16 KiB weight slice follows the same way; a ballot of the ids gives the per-tile
+//              "any neighbour" flags.  Two stages in flight (96 KiB of LDS), ONE barrier per offset.
+//   waves 0-3  CONSUMERS: 32 rows x 64 produced channels each, nothing but ds_read_b128 + MFMA (tiles without a neighbour at
+//              this offset skipped wave-uniformly), output rows stored at the end of the tile.
+// Workgroups are persistent (one per CU) over the 128-row tiles, so the producers run ahead across tile boundaries.
+constexpr int GW_BLOCK = 512, GW_ROWS = 128, GW_STAGES = 3;
+#define GW_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+template <int Q, int NT>
+__global__ void __launch_bounds__(GW_BLOCK, 2)
+gather_gemm_ws_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
+                      int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out, int n_tiles) {
+    constexpr int A_F4 = Q * 4 * GW_ROWS, B_F4 = Q * NT * 64, STAGE = A_F4 + B_F4;
+    constexpr int PER_STEP = 1 + 2 * Q + B_F4 / 256;     // LDS-DMA instructions a producer wave issues per step: ids, rows, weights
+    __shared__ f32x4 lds[GW_STAGES * STAGE];
+    __shared__ int ids[GW_STAGES][4][64];                // neighbour ids of the step, one private copy per producer wave
+    __shared__ int hits[GW_STAGES][GW_ROWS / 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int my_tiles = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int total = my_tiles * K;          // (tile, offset) steps of this workgroup = barriers every wave passes
+    if (total == 0) return;
+
+    if (wave < 4) {
+        // ---------------------------------------------------------------- consumers
+        const int r = lane & 15, g = lane >> 4;
+        float bv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[n] = (bias && NT * r + n < cp) ? bias[NT * r + n] : 0.0f;
+        int step = 0, buf = 0;
+        for (int t = 0; t < my_tiles; ++t) {
+            const int row0 = (blockIdx.x + t * gridDim.x) * GW_ROWS + wave * 32;
+            f32x4 acc[2][NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[0][n] = acc[1][n] = f32x4{bv[n], bv[n], bv[n], bv[n]};
+            for (int k = 0; k < K; ++k, ++step, buf = (buf + 1 == GW_STAGES ? 0 : buf + 1)) {
+                __syncthreads();                         // stage of this step published (producers waited for its DMA)
+                const f32x4* const A = lds + buf * STAGE + (wave * 2 * 16 + r) * 4 + g;      // [q][16-row block][r][g]
+                const f32x4* const B = lds + buf * STAGE + A_F4 + lane;
+                const bool hit0 = hits[buf][wave * 2] != 0, hit1 = hits[buf][wave * 2 + 1] != 0;     // wave-uniform
+                if (!(hit0 || hit1)) continue;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const f32x4 a0 = A[q * (GW_ROWS * 4)], a1 = A[q * (GW_ROWS * 4) + 64];
+                    f32x4 b[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) b[n] = B[(q * NT + n) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            if (hit0) acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[n][j], acc[0][n], 0, 0, 0);
+                            if (hit1) acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b[n][j], acc[1][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            const bool full = cp == 16 * NT;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int row = row0 + rt * 16 + 4 * g + reg;
+                    if (row >= n_out) continue;
+                    float* dst = out + (size_t)row * cp + NT * r;
+                    if (full) {
+#pragma unroll
+                        for (int n = 0; n < NT; n += 4)
+                            *reinterpret_cast<f32x4*>(dst + n) = f32x4{acc[rt][n][reg], acc[rt][n + 1][reg], acc[rt][n + 2][reg], acc[rt][n + 3][reg]};
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            if (NT * r + n < cp) dst[n] = acc[rt][n][reg];
+                    }
+                }
+            }
+        }
+    } else {
+        // ---------------------------------------------------------------- producers
+        // Every vector-memory instruction of a producer is an LDS-DMA and every step issues exactly PER_STEP of them (out of
+        // range = writes zeros, touches no memory), so "the DMAs of the stage that is consumed next have landed" is the
+        // counted wait vmcnt(PER_STEP): two steps of memory latency are covered instead of one.
+        const int p = wave - 4;                  // owns rows 32 p .. 32 p + 31 of the tile (= consumer p's rows): 16-row blocks 2 p, 2 p + 1
+        const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cg * 4u);
+        const __amdgpu_buffer_rsrc_t w_rsrc = table_rsrc(wp, (unsigned)K * B_F4 * 16u);
+        const __amdgpu_buffer_rsrc_t id_rsrc = table_rsrc(reinterpret_cast<const float*>(nbr), (unsigned)((size_t)K * n_out * 4u));
+        auto dma_ids = [&](int s) {              // ids of rows 32 p + lane (lanes 0..31) of step s -> ids[s % 3][p][lane]
+            unsigned off = OOB;
+            if (s < total && lane < 32) {
+                const int t = s / K, k = s - t * K;
+                const int row = (blockIdx.x + t * gridDim.x) * GW_ROWS + p * 32 + lane;
+                if (row < n_out) off = (unsigned)(((size_t)k * n_out + row) * 4u);
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(id_rsrc, GW_LDS_PTR(&ids[s % GW_STAGES][p][0]), 4, off, 0, 0, 0);
+        };
+        auto dma_stage = [&](int s) {            // rows + weights of step s; its ids have landed
+            const int st = s % GW_STAGES;
+            // one DMA instruction = 16 rows x the four 16-byte pieces g of channel group q: a row's 64 bytes are fetched by 4
+            // adjacent lanes (whole sectors; one row per lane quadrupled the fill traffic).  LDS image [q][block][r][g].
+            // ids through inline asm: hipcc drains every outstanding LDS-DMA (vmcnt(0)) in front of an LDS read it can see, which
+            // would put the row gathers of the previous step back on the critical path; these words were written by the DMA
+            // this wave waited for at the end of the previous step
+            int id[2];
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"        // one statement: the results exist only after the wait
+                         : "=&v"(id[0]), "=&v"(id[1])
+                         : "v"((unsigned)(size_t)GW_LDS_PTR(&ids[st][p][lane >> 2])), "v"((unsigned)(size_t)GW_LDS_PTR(&ids[st][p][16 + (lane >> 2)]))
+                         : "memory");
+            const int t = s < total ? s / K : 0;
+            const int row_base = (blockIdx.x + t * gridDim.x) * GW_ROWS + p * 32 + (lane >> 2);
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2)
+                if (s >= total || row_base + 16 * b2 >= n_out) id[b2] = -1;      // past the end the LDS word holds a zero, not "no neighbour"
+            f32x4* const stage = lds + st * STAGE;
+            const bool any0 = __any(id[0] >= 0), any1 = __any(id[1] >= 0);
+            if (lane < 2)
+                asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(size_t)GW_LDS_PTR(&hits[st][2 * p + lane])), "v"((int)(lane ? any1 : any0)) : "memory");
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const unsigned row_off = (unsigned)id[b2] * (unsigned)cg * 4u + (unsigned)(lane & 3) * 16u;
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, GW_LDS_PTR(stage + ((q * 8 + 2 * p + b2) * 16) * 4), 16,
+                                                             id[b2] >= 0 ? row_off + (unsigned)q * 64u : OOB, 0, 0, 0);
+            }
+            const int k = s < total ? s % K : 0;
+#pragma unroll
+            for (int it = 0; it < B_F4 / 256; ++it) {
+                const int blk = p * (B_F4 / 256) + it;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, GW_LDS_PTR(stage + A_F4 + blk * 64), 16,
+                                                         s < total ? ((unsigned)k * B_F4 + blk * 64 + lane) * 16u : OOB, 0, 0, 0);
+            }
+        };
+        dma_ids(0);
+        dma_ids(1);
+        dma_ids(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dma_stage(0);
+        dma_stage(1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PER_STEP - 1) : "memory");     // barrier 0: stage 0 landed
+        for (int s = 0; s + 1 < total; ++s) {
+            dma_ids(s + 3);
+            dma_stage(s + 2);
+            // all but the 12 row / weight DMAs just issued have landed: stage s + 1 AND the ids of step s + 3 (first DMA of this step)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(PER_STEP - 1) : "memory");     // barrier s + 1
+        }
+    }
+}
+
 #ifndef GG_LDS_WAVES_WIDE
 #define GG_LDS_WAVES_WIDE 4   // 512-thread blocks of the 128-channel variant: 2 blocks x 8 waves per CU
 #endif
@@ -856,6 +1008,29 @@ extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_
         else
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
                                dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
+    // 64 -> 64: wave-specialised producer / consumer kernel (persistent, one 512-thread workgroup per CU)
+    // OFF by default: measured 0.653 ms against 0.539 ms for gather_gemm_lds_kernel on the 389.5k-row stride-4 level (0.245 vs
+    // 0.207 ms at 117k rows).  The consumers' MFMA stream is clean (about 2,950 cycles per offset and 128 rows), but the
+    // producers' LDS-DMA row gather runs at 16-30 GB/s per CU out of a 100 MB feature table (MI355X_MICROARCH.md "Indexed
+    // rows: gather into LDS"), i.e. about 4,800 cycles for the 32 KiB of an offset: the design is gather-bound, three stages
+    // deep or not.  The register gathers of the 16 resident waves of gather_gemm_lds_kernel re-hit L1 for the rows that
+    // neighbouring offsets share and keep more requests in flight.
+    static const int env_ws = getenv("TODA_GG_WS") ? atoi(getenv("TODA_GG_WS")) : 0;
+    if (env_ws && vec_ok && order == nullptr && Q == 4 && NT == 4 && c_gather == 64 && n_out >= 8192) {
+        static int n_cu_ws = 0;
+        if (!n_cu_ws) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            TODA_HIP(hipGetDevice(&dev));
+            TODA_HIP(hipGetDeviceProperties(&prop, dev));
+            n_cu_ws = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        const int n_tiles = cdiv(n_out, GW_ROWS);
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_ws_kernel<4, 4>), dim3(n_tiles < n_cu_ws ? n_tiles : n_cu_ws), dim3(GW_BLOCK), 0, s, in, n_in,
+                  c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, n_tiles);
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }

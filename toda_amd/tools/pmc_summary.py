@@ -1,12 +1,18 @@
 #!/usr/bin/env python
 """Fold rocprofv3 --pmc counter_collection CSVs into the per-launch-shape summary bench.py reads for `roofline.traffic`.
     pmc_summary.py <kernel substring> <out.json> <counter_collection.csv> [more csv ...]
+The summary records the SHA-256 of the kernel sources at collection time; bench.py refuses it once they change.
 Every CSV comes from its own pass (one --pmc set per run, as MI355X_MICROARCH.md prescribes).  Counters are averaged
 per (kernel, grid size); hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction of the guide's HBM section)."""
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SOURCES = ["toda_amd/csrc/spconv.hip", "toda_amd/csrc/conv2d.hip"]
 
 
 def main():
@@ -29,7 +35,8 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in row and "SQ_BUSY_CU_CYCLES" in row:
             row["mfma_pipe_busy"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * row["SQ_BUSY_CU_CYCLES"])
         shapes.append(row)
-    json.dump({"kernel": sorted(names), "note": "one rocprofv3 --pmc pass per counter set over `python bench.py --steps 2 --warmup 2 "
+    sha = {p: hashlib.sha256(open(os.path.join(ROOT, p), "rb").read()).hexdigest() for p in SOURCES if os.path.exists(os.path.join(ROOT, p))}
+    json.dump({"kernel": sorted(names), "source_sha256": sha, "note": "one rocprofv3 --pmc pass per counter set over `python bench.py --steps 2 --warmup 2 "
                "--no-cpu-baseline`; FETCH_SIZE / WRITE_SIZE in KiB per dispatch; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
                "launch_shapes": shapes}, open(out, "w"), indent=1)
     for s in shapes:

@@ -291,6 +291,18 @@ int toda_points_world_transform(const float* src, int n, const int32_t* n_dev, i
                                 int rotate, float cosv, float sinv, int rescale, float scale, float* dst,
                                 void* stream);
 
+/* Forward convolution that also returns the BatchNorm statistics of its output (reference
+ * pcdet/models/backbones_3d/spconv_backbone.py:21-25,54-64: every sparse conv is followed by BatchNorm1d): the
+ * per-channel sum and sum of squares are taken from the accumulators in the kernel's epilogue, so the separate
+ * statistics pass over the output (toda_rows_moments) disappears.  sums: toda_spconv_gather_gemm_stats_doubles()
+ * doubles; on return sums[0:c] = sum, sums[c:2c] = sum of squares (the layout toda_bn_finalize reads; fixed-order
+ * fold, deterministic).  Only for channel pairs toda_spconv_gather_gemm_stats_supported() accepts. */
+int toda_spconv_gather_gemm_stats_supported(int c_gather, int c_produce);
+size_t toda_spconv_gather_gemm_stats_doubles(int n_out, int c_produce);
+int toda_spconv_gather_gemm_stats(const float* in, int n_in, int c_gather, const float* packed_w, const int32_t* nbr,
+                                  int n_out, int k_vol, int c_produce, const float* bias, float* out, double* sums,
+                                  size_t sums_doubles, void* stream);
+
 /* ------------------------------------------------------------------------
  * Dense 3x3 / stride 1 / pad 1 fp32 convolution of the BEV neck and the dense heads (NCHW), replacing
  * torch.nn.Conv2d -> cuDNN / MIOpen at pcdet/models/backbones_2d/base_bev_backbone.py:37-58,81-112 and

@@ -197,8 +197,9 @@ def test_subm_conv_fwd_dgrad_wgrad(cin, cout):
 
 
 def test_wave_specialised_64x64_kernel_matches_oracle():
-    """The 64 -> 64 producer / consumer kernel (gather_gemm_ws_kernel: >= 8192 rows) on a set whose row count is no multiple of
-    its 128-row tiles, sparse enough that whole tiles miss some offsets, forward (with bias) and dgrad against the oracle."""
+    """The 64 -> 64 kernels on >= 8192 rows whose count is no multiple of 128 (the tile of the opt-in producer / consumer
+    variant gather_gemm_ws_kernel, TODA_GG_WS=1; the default is gather_gemm_lds_kernel), sparse enough that whole tiles miss
+    some offsets: forward (with bias) and dgrad against the oracle."""
     from toda_amd import ops
 
     shape, batch = [11, 96, 90], 2
@@ -219,6 +220,36 @@ def test_wave_specialised_64x64_kernel_matches_oracle():
     np.testing.assert_allclose(x.grad.cpu().numpy(), din0, rtol=1e-4, atol=1e-4)
     again = ops.sparse_conv(x.detach(), wt.detach(), bt, rb)
     assert torch.equal(again, out.detach())       # no atomics: bit-reproducible
+
+
+@pytest.mark.parametrize("cin,cout,k", [(32, 32, 27), (32, 64, 27), (64, 64, 27), (64, 128, 3)])
+def test_conv_epilogue_bn_moments_equal_a_pass_over_the_output(cin, cout, k):
+    """toda_spconv_gather_gemm_stats (reference spconv_backbone.py:21-25: conv -> BatchNorm1d): the per-channel sum and sum of
+    squares taken from the accumulators equal those of the stored output (fp64 reference), the output itself is bit-identical
+    to the plain launch, and the fused BatchNorm path gives the same result as the unfused one."""
+    from toda_amd import ops
+
+    shape, batch = [9, 60, 64], 2
+    idx, feat = H.clustered_sparse(batch, shape, 3300, cin, seed=cin + cout)
+    rng = np.random.default_rng(3)
+    ks = 3 if k == 27 else (3, 1, 1)
+    kshape = (3, 3, 3) if k == 27 else (3, 1, 1)
+    w = (rng.standard_normal((cout,) + kshape + (cin,)) / np.sqrt(k * cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape, ks)
+    assert ops.gather_gemm_stats_supported(cin, cout)
+    wp = ops.pack_weight(dev(w), False, False)
+    out, sums = ops.gather_gemm_with_stats(dev(feat), wp, rb.nbr_fwd, cout, dev(bias))
+    plain = ops.gather_gemm(dev(feat), wp, rb.nbr_fwd, cout, dev(bias))
+    assert torch.equal(out, plain)
+    ref = out.double()
+    np.testing.assert_allclose(sums[:cout].cpu().numpy(), ref.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(sums[cout:2 * cout].cpu().numpy(), (ref * ref).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    bn = torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01).cuda().train()
+    bn2 = torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01).cuda().train()
+    a = ops.bn_rows(out, bn, True, sums=sums)
+    b = ops.bn_rows(out, bn2, True)
+    assert float((a - b).abs().max()) < 1e-5 and torch.allclose(bn.running_var, bn2.running_var, rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("ks,st,pd", CONV_GEOMS)

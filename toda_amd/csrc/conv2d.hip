@@ -467,29 +467,41 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
             for (int f = 0; f < WN_FREQ; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int chunk = c_begin; chunk < c_end; ++chunk, ++q) {
                 __syncthreads();                                  // images of chunk q complete, images of q - 1 free
-                const f32x2* const ap = a_frag + (q & 1) * (IMG / 2);
-                const f32x2* const bp = b_frag + (q & 1) * (IMG / 2);
+                // Fragment reads as inline-asm ds_read_b64 with a counted lgkmcnt: left to itself hipcc fuses the 8-byte reads of
+                // two frequencies into ds_read2st64_b64, which moves the same bytes at HALF the LDS rate (128 instead of 256
+                // B/clk, MI355X_MICROARCH.md LDS table) - with 72 fragment reads per chunk and wave the LDS pipe, not the matrix
+                // pipe, then sets the pace.  LDS returns in order: after the reads of frequencies f+4, f+5 are issued, 8 newer
+                // reads than those of f, f+1 are outstanding.
                 if (ablate & 8) continue;
-                constexpr int AHEAD = 4;                          // frequencies whose fragments are in flight
+                const unsigned a_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(a_frag + (q & 1) * (IMG / 2));
+                const unsigned b_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(b_frag + (q & 1) * (IMG / 2));
                 f32x2 fa[WN_FREQ], fb[WN_FREQ];
-#pragma unroll
-                for (int f = 0; f < AHEAD; ++f) {
-                    fa[f] = ap[f * 128];
-                    fb[f] = bp[f * 128];
-                }
+#define WN_RD(f_)                                                                                                      \
+    asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4" : "=&v"(fa[f_]), "=&v"(fb[f_]) : "v"(a_addr), "v"(b_addr), "n"((f_) * 1024))
+#define WN_WAIT(f_, n_)                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(fa[f_]), "+v"(fb[f_]), "+v"(fa[(f_) + 1]), "+v"(fb[(f_) + 1]))
+                WN_RD(0);
+                WN_RD(1);
+                WN_RD(2);
+                WN_RD(3);
 #pragma unroll
                 for (int f = 0; f < WN_FREQ; f += 2) {
-                    if (f + AHEAD < WN_FREQ) {
-                        fa[f + AHEAD] = ap[(f + AHEAD) * 128];
-                        fb[f + AHEAD] = bp[(f + AHEAD) * 128];
-                        fa[f + AHEAD + 1] = ap[(f + AHEAD + 1) * 128];
-                        fb[f + AHEAD + 1] = bp[(f + AHEAD + 1) * 128];
+                    if (f + 4 < WN_FREQ) {
+                        WN_RD(f + 4);
+                        WN_RD(f + 5);
+                        WN_WAIT(f, 8);
+                    } else if (f + 2 < WN_FREQ) {
+                        WN_WAIT(f, 4);
+                    } else {
+                        WN_WAIT(f, 0);
                     }
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][0], fb[f][0], acc[f], 0, 0, 0);
                     acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][0], fb[f + 1][0], acc[f + 1], 0, 0, 0);
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][1], fb[f][1], acc[f], 0, 0, 0);
                     acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][1], fb[f + 1][1], acc[f + 1], 0, 0, 0);
                 }
+#undef WN_RD
+#undef WN_WAIT
             }
             s += c_end - c_begin;
             const int tile_base = tb * WN_TILES + wt * 16, co = cb * WN_COUT + wc * 16 + (lane & 15);

@@ -539,7 +539,7 @@ template <int Q, int NT, int RT, bool VEC, bool DB = true, int BLK = SC_BLOCK>
 __global__ void __launch_bounds__(BLK, (Q * NT <= 4 && RT <= 2) ? GG_LDS_WAVES_NARROW : (Q * NT * RT <= 32 && Q * NT <= 16) ? GG_LDS_WAVES : (BLK > SC_BLOCK ? GG_LDS_WAVES_WIDE : 1))
 gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                        const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
-                       float* __restrict__ out, const int* __restrict__ order) {
+                       float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stats) {
     constexpr int SLICE = Q * NT * 64;                    // float4 per offset
     constexpr int PER_THREAD = (SLICE + BLK - 1) / BLK;
     __shared__ f32x4 wl[DB ? 2 : 1][SLICE];  // DB = false: one 64 KiB buffer (128-channel layers), two barriers per offset
@@ -626,7 +626,45 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
         }
         __syncthreads();
     }
-    if (row0 >= n_out) return;
+    if (row0 >= n_out && !stats) return;
+
+    // BatchNorm statistics of the layer's output, taken from the accumulators (reference spconv_backbone.py:21-25: every conv
+    // of post_act_block / SparseBasicBlock is followed by BatchNorm1d): per-channel sum and sum of squares of this workgroup's
+    // rows -> stats scratch [2 cp][gridDim.x] behind the 2 cp results, folded in fixed order by fold_partials_kernel.  fp32
+    // over the <= 8 values of a lane and the 4 lane groups, fp64 across waves and workgroups (as toda_rows_moments).
+    if (stats) {
+        __shared__ float st_sh[BLK / 64][2][16 * NT];
+        float sm[NT], sq[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            sm[n] = sq[n] = 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (row0 + rt * 16 + 4 * g + reg < n_out) {
+                        const float v = acc[rt][n][reg];
+                        sm[n] += v;
+                        sq[n] += v * v;
+                    }
+            sm[n] += __shfl_xor(sm[n], 16, 64);
+            sq[n] += __shfl_xor(sq[n], 16, 64);
+            sm[n] += __shfl_xor(sm[n], 32, 64);
+            sq[n] += __shfl_xor(sq[n], 32, 64);
+            if (g == 0) {
+                st_sh[threadIdx.x >> 6][0][NT * r + n] = sm[n];
+                st_sh[threadIdx.x >> 6][1][NT * r + n] = sq[n];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * cp) {
+            const int qq = threadIdx.x / cp, ch = threadIdx.x - qq * cp;
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < BLK / 64; ++w) a += (double)st_sh[w][qq][ch];
+            stats[2 * cp + (size_t)(qq * cp + ch) * gridDim.x + blockIdx.x] = a;
+        }
+    }
 
     const bool full = cp == 16 * NT;
 #pragma unroll
@@ -971,9 +1009,42 @@ extern "C" int toda_timing_end(float* ms_out, int cap, int* n_out) {
     return TODA_OK;
 }
 
+namespace toda {
+__global__ void fold_partials_kernel(double* __restrict__ sums, int blocks, int cols);   // dense.hip
+static bool gg_stats_supported(int c_gather, int c_produce) {
+    const int Q = tiles_pow2(c_gather), NT = tiles_pow2(c_produce);
+    return (c_gather & 3) == 0 && Q >= 2 && NT >= Q && Q * NT <= 32 && !(Q == 8 && NT == 8) && c_produce % 4 == 0 && c_produce == 16 * NT;
+}
+}  // namespace toda
+
+static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
+                            int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream);
+
 extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
                                                int n_out, int k_vol, int c_produce, const float* bias, float* out,
                                                const int32_t* order, void* stream) {
+    return gather_gemm_impl(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, nullptr, stream);
+}
+
+extern "C" int toda_spconv_gather_gemm_stats_supported(int c_gather, int c_produce) {
+    return gg_stats_supported(c_gather, c_produce) ? 1 : 0;
+}
+
+extern "C" size_t toda_spconv_gather_gemm_stats_doubles(int n_out, int c_produce) {
+    return (size_t)2 * c_produce * (1 + (size_t)cdiv(n_out > 0 ? n_out : 1, 64));     // 2 c results + [2 c][workgroups] scratch
+}
+
+extern "C" int toda_spconv_gather_gemm_stats(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
+                                             int n_out, int k_vol, int c_produce, const float* bias, float* out, double* sums,
+                                             size_t sums_doubles, void* stream) {
+    TODA_CHECK_ARG(sums != nullptr && gg_stats_supported(c_gather, c_produce) && n_out > 0 && n_in > 0,
+                   "gather_gemm_stats: unsupported channel pair (%d -> %d) or empty table", c_gather, c_produce);
+    TODA_CHECK_ARG(sums_doubles >= toda_spconv_gather_gemm_stats_doubles(n_out, c_produce), "gather_gemm_stats: statistics buffer too small");
+    return gather_gemm_impl(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, nullptr, sums, stream);
+}
+
+static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
+                            int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream) {
     TODA_CHECK_ARG(c_gather >= 1 && c_gather <= 128 && c_produce >= 1 && c_produce <= 128,
                    "gather_gemm: channels must be in [1,128] (gather %d, produce %d)", c_gather, c_produce);
     TODA_CHECK_ARG(n_out >= 0 && n_in >= 0 && k_vol >= 1, "gather_gemm: bad sizes");
@@ -998,16 +1069,16 @@ extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_
     if (env_lds88 && vec_ok && Q == 8 && NT == 8) {
         if (env_lds88 == 2)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)),
-                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
+                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats);
         else if (env_lds88 == 3)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false, 512>), dim3(cdiv(cdiv(n_out, 16), 8)),
-                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
+                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats);
         else if (env_lds88 == 4)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false, 512>), dim3(cdiv(cdiv(n_out, 32), 8)),
-                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
+                               dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats);
         else
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
-                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order);
+                               dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats);
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
@@ -1019,7 +1090,7 @@ extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_
     // deep or not.  The register gathers of the 16 resident waves of gather_gemm_lds_kernel re-hit L1 for the rows that
     // neighbouring offsets share and keep more requests in flight.
     static const int env_ws = getenv("TODA_GG_WS") ? atoi(getenv("TODA_GG_WS")) : 0;
-    if (env_ws && vec_ok && order == nullptr && Q == 4 && NT == 4 && c_gather == 64 && n_out >= 8192) {
+    if (env_ws && !stats && vec_ok && order == nullptr && Q == 4 && NT == 4 && c_gather == 64 && n_out >= 8192) {
         static int n_cu_ws = 0;
         if (!n_cu_ws) {
             int dev = 0;
@@ -1036,7 +1107,7 @@ extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_
     }
     // narrow layers: all K offsets of the packed weights resident in LDS (<= 108 KiB), barrier-free offset loop
     static const int env_wres = getenv("TODA_GG_WRES") ? atoi(getenv("TODA_GG_WRES")) : 0;   // measured slower than the per-offset LDS slices (32->32 @ 682k rows 0.356 vs 0.321 ms, 16->32 0.234 vs 0.168): off
-    if (env_wres && vec_ok && order == nullptr && Q <= 2 && NT <= 2 && k_vol <= 27 && n_out >= 4096) {
+    if (env_wres && !stats && vec_ok && order == nullptr && Q <= 2 && NT <= 2 && k_vol <= 27 && n_out >= 4096) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -1059,11 +1130,11 @@ extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
-    if (env_lds && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
+    if ((env_lds || stats) && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
 #define GL(QQ, NN, RR)                                                                                                   \
     GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
-                       k_vol, c_produce, bias, out, order)
+                       k_vol, c_produce, bias, out, order, stats)
 #define GL_RT(QQ, NN)                          \
     if (env_rt == 4 && QQ <= 4 && NN <= 4) {   \
         GL(QQ, NN, 4);                         \
@@ -1089,8 +1160,15 @@ extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_
 #undef GL_RT
 #undef GL
         TODA_LAUNCH_CHECK();
+        if (stats) {      // fold the per-workgroup partial sums of the launch above (same grid arithmetic as GL_RT / GL_ROW)
+            const int rr = NT >= 8 ? 1 : ((env_rt == 4 && Q <= 4 && NT <= 4) ? 4 : (env_rt == 1 ? 1 : 2));
+            const int blocks = cdiv(cdiv(n_out, 16 * rr), SC_BLOCK / 64);
+            hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c_produce), dim3(256), 0, s, stats, blocks, 2 * c_produce);
+            TODA_LAUNCH_CHECK();
+        }
         return TODA_OK;
     }
+    TODA_CHECK_ARG(stats == nullptr, "gather_gemm: statistics requested on a launch shape without the fused epilogue");
     int rt_sel = env_rt ? env_rt : ((NT >= 8 && Q < 8) ? 1 : 2);  // 128->128: RT = 2 measured 16 % faster than 1
     if (NT >= 8 && rt_sel > 2) rt_sel = 2;
     if (Q >= 8 && rt_sel > 2) rt_sel = 2;

@@ -304,6 +304,24 @@ def rulebook_row_order(nbr):
     return order
 
 
+def gather_gemm_stats_supported(c_gather, c_produce):
+    return bool(L.load().toda_spconv_gather_gemm_stats_supported(int(c_gather), int(c_produce)))
+
+
+def gather_gemm_with_stats(feat, wp, nbr, c_produce, bias=None):
+    """Forward gather-GEMM that also returns the BatchNorm moments of its output (sum, sum of squares per channel in
+    sums[:2c], fp64) from the kernel's epilogue - the layout toda_bn_finalize reads."""
+    lib = L.load()
+    K, n_out = nbr.shape
+    out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
+    nd = lib.toda_spconv_gather_gemm_stats_doubles(n_out, c_produce)
+    sums = torch.empty((nd,), dtype=torch.float64, device=feat.device)
+    rc = lib.toda_spconv_gather_gemm_stats(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce,
+                                           L.ptr(bias), L.ptr(out), L.ptr(sums), nd, L.stream())
+    L.check(rc, "toda_spconv_gather_gemm_stats")
+    return out, sums
+
+
 def gather_gemm(feat, wp, nbr, c_produce, bias=None, order=None):
     lib = L.load()
     K, n_out = nbr.shape
@@ -351,18 +369,25 @@ class _SparseConv(torch.autograd.Function):
     (reference tools/train_utils/train_utils.py:55)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb, wp_fwd):
+    def forward(ctx, features, weight, bias, rb, wp_fwd, want_stats=False):
         features = features.contiguous()
         if wp_fwd is None:
             wp_fwd = pack_weight(weight, False, False)
-        out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, order=rb.order_for(rb.nbr_fwd))
+        sums = None
+        if want_stats:
+            out, sums = gather_gemm_with_stats(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
+        else:
+            out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, order=rb.order_for(rb.nbr_fwd))
         ctx.save_for_backward(features, weight)
         ctx.rb = rb
         ctx.has_bias = bias is not None
+        if want_stats:
+            ctx.mark_non_differentiable(sums)
+            return out, sums
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, *unused):
         features, weight = ctx.saved_tensors
         rb = ctx.rb
         gout = gout.contiguous()
@@ -389,11 +414,22 @@ class _SparseConv(torch.autograd.Function):
         if side is not None:
             torch.cuda.current_stream(gout.device).wait_stream(side)
             gw.record_stream(torch.cuda.current_stream(gout.device))
-        return gfeat, gw, gb, None, None
+        return gfeat, gw, gb, None, None, None
 
 
-def sparse_conv(features, weight, bias, rulebook, packed_weight=None):
-    return _SparseConv.apply(features, weight, bias, rulebook, packed_weight)
+FUSE_BN_STATS = _os.environ.get("TODA_FUSE_BN_STATS", "1") == "1"
+
+
+def sparse_conv(features, weight, bias, rulebook, packed_weight=None, want_stats=False):
+    """want_stats: also return the BatchNorm moments of the output when the kernel's epilogue can take them
+    (returns (out, sums) with sums None when it cannot: empty tables, narrow channel pairs, mask-sorted row order)."""
+    if not want_stats:
+        return _SparseConv.apply(features, weight, bias, rulebook, packed_weight)
+    ok = (FUSE_BN_STATS and gather_gemm_stats_supported(weight.shape[-1], weight.shape[0]) and rulebook.nbr_fwd.shape[1] > 1
+          and features.shape[0] > 0 and rulebook.order_for(rulebook.nbr_fwd) is None)
+    if not ok:
+        return _SparseConv.apply(features, weight, bias, rulebook, packed_weight), None
+    return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, True)
 
 
 # ------------------------------------------------------------------------ sparse <-> dense
@@ -478,16 +514,17 @@ class _BNRows(torch.autograd.Function):
     (torch: 5 / 7): toda_rows_moments -> toda_bn_finalize -> toda_rows_affine_act, toda_rows_bn_bwd."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual=None, sums=None):
         lib = L.load()
         x = x.contiguous()
         residual = residual.contiguous() if residual is not None else None
         n, c = x.shape
         dev = x.device
         stats = torch.empty((4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
-        sums = torch.empty((lib.toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=dev)   # [0:2c] result + per-block scratch
-        if training:
-            L.check(lib.toda_rows_moments(L.ptr(x), n, c, L.ptr(sums), L.stream()), "toda_rows_moments")
+        if sums is None or not training:     # moments not delivered by the producing convolution: one pass over x
+            sums = torch.empty((lib.toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=dev)   # [0:2c] result + per-block scratch
+            if training:
+                L.check(lib.toda_rows_moments(L.ptr(x), n, c, L.ptr(sums), L.stream()), "toda_rows_moments")
         rc = lib.toda_bn_finalize(L.ptr(sums), n, c, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
                                   float(momentum), float(eps), int(bool(training)), L.ptr(stats[0]), L.ptr(stats[1]),
                                   L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
@@ -513,7 +550,7 @@ class _BNRows(torch.autograd.Function):
             dz = gy * (pre > 0) if relu else gy
             gx = dz * stats[2]
             xhat = (x - stats[0]) * stats[1]
-            return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None, (dz if want_res else None)
+            return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None, (dz if want_res else None), None
         sums = torch.empty((L.load().toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=x.device)
         gx = torch.empty_like(x)
         gamma = weight if weight is not None else torch.ones(c, device=x.device)
@@ -522,17 +559,18 @@ class _BNRows(torch.autograd.Function):
                                            L.ptr(sums), L.ptr(gx), L.ptr(gres), L.stream())
         L.check(rc, "toda_rows_bn_bwd_res")
         gs = sums[:2 * c].to(torch.float32)
-        return gx, gs[c:], gs[:c], None, None, None, None, None, None, gres
+        return gx, gs[c:], gs[:c], None, None, None, None, None, None, gres, None
 
 
-def bn_rows(x, bn, relu, residual=None):
+def bn_rows(x, bn, relu, residual=None, sums=None):
     """Apply an nn.BatchNorm1d module (its parameters, buffers and train/eval state) to rows [N, C], optionally
-    fused with a shortcut addition (y = bn(x) + residual) and the ReLU that follows."""
+    fused with a shortcut addition (y = bn(x) + residual) and the ReLU that follows.  sums: the moments of x when the
+    convolution that produced x has already taken them (ops.sparse_conv(..., want_stats=True))."""
     training = bn.training or not bn.track_running_stats
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = 0.0 if bn.momentum is None else bn.momentum
-    return _BNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu, residual)
+    return _BNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu, residual, sums)
 
 
 def bn_rows_supported(x, bn):

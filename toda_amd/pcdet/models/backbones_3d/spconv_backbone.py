@@ -44,13 +44,14 @@ class SparseBasicBlock(spconv.SparseModule):
 
     def forward(self, x):
         shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.conv1(x)
+        on_gpu = x.features.is_cuda      # the CPU oracle backend (tests) has no fused epilogue
+        y = self.conv1(x, want_bn_stats=True) if (on_gpu and self.bn1.training and type(self.bn1) is nn.BatchNorm1d) else self.conv1(x)
         if ops.bn_rows_supported(y.features, self.bn1) and ops.bn_rows_supported(y.features, self.bn2):
-            # BN + ReLU and BN + shortcut + ReLU as fused passes over the rows (3 forward / 5 backward sweeps each) instead
-            # of torch's BatchNorm1d + add + ReLU kernels; module tree and state_dict are unchanged
-            y = replace_feature(y, ops.bn_rows(y.features, self.bn1, True))
-            y = self.conv2(y)
-            return replace_feature(y, ops.bn_rows(y.features, self.bn2, True, residual=shortcut.features))
+            # BN + ReLU and BN + shortcut + ReLU as fused passes over the rows (the moments come out of the convolutions'
+            # epilogues) instead of torch's BatchNorm1d + add + ReLU kernels; module tree and state_dict are unchanged
+            y = replace_feature(y, ops.bn_rows(y.features, self.bn1, True, sums=getattr(y, "bn_sums", None)))
+            y = self.conv2(y, want_bn_stats=True) if self.bn2.training else self.conv2(y)
+            return replace_feature(y, ops.bn_rows(y.features, self.bn2, True, residual=shortcut.features, sums=getattr(y, "bn_sums", None)))
         y = replace_feature(y, self.relu(self.bn1(y.features)))
         y = self.conv2(y)
         y = replace_feature(y, self.bn2(y.features))

@@ -88,16 +88,23 @@ class SparseConvolution(SparseModule):
                                               "out_indices": out_idx, "out_shape": out_shape, "gi": gi}
         return rb, out_idx, out_shape, gi
 
-    def forward(self, x):
+    def forward(self, x, want_bn_stats=False):
+        """want_bn_stats (used by SparseSequential / SparseBasicBlock when a training-mode BatchNorm1d follows): the output
+        tensor carries `.bn_sums`, the moments of its features taken in the convolution's epilogue (None when unavailable)."""
         if not isinstance(x, SparseConvTensor):
             raise TypeError("sparse convolution expects a SparseConvTensor")
         if x.features.shape[1] != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {x.features.shape[1]}")
         rb, out_idx, out_shape, gi = self._rulebook(x)
         packed = self._packed_forward_weight()
-        feats = ops.sparse_conv(x.features, self.weight, self.bias, rb, packed)
+        sums = None
+        if want_bn_stats:
+            feats, sums = ops.sparse_conv(x.features, self.weight, self.bias, rb, packed, want_stats=True)
+        else:
+            feats = ops.sparse_conv(x.features, self.weight, self.bias, rb, packed)
         out = SparseConvTensor(feats, out_idx, out_shape, x.batch_size, indice_dict=x.indice_dict)
         out.grid_index = gi
+        out.bn_sums = sums
         return out
 
 

@@ -22,6 +22,8 @@ class SparseConvTensor:
         # GridIndex of THIS index set when one is already known (output of a strided conv)
         self.grid_index = grid
         self.benchmark = benchmark
+        # BatchNorm moments of `features` when the convolution that produced them took them in its epilogue (else None)
+        self.bn_sums = None
 
     def replace_feature(self, new_features):
         out = SparseConvTensor(new_features, self.indices, self.spatial_shape, self.batch_size,

@@ -16,6 +16,11 @@ def is_spconv_module(module):
     return isinstance(module, SparseModule)
 
 
+def _sparse_convolution():
+    from .conv import SparseConvolution
+    return SparseConvolution
+
+
 class SparseSequential(SparseModule):
     def __init__(self, *args, **kwargs):
         super().__init__()
@@ -47,13 +52,16 @@ class SparseSequential(SparseModule):
         while i < len(mods):
             module = mods[i]
             if is_spconv_module(module):
-                x = module(x)
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                fuse = (isinstance(module, _sparse_convolution()) and type(nxt) is nn.BatchNorm1d and nxt.training and isinstance(x, SparseConvTensor)
+                        and x.features.is_cuda)
+                x = module(x, want_bn_stats=True) if fuse else module(x)
             elif isinstance(x, SparseConvTensor):
                 if x.features.shape[0] != 0:
                     # BatchNorm1d (+ ReLU) over sparse rows: one fused HIP path instead of 2 modules
                     if isinstance(module, nn.BatchNorm1d) and ops.bn_rows_supported(x.features, module):
                         relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-                        x = x.replace_feature(ops.bn_rows(x.features, module, relu))
+                        x = x.replace_feature(ops.bn_rows(x.features, module, relu, sums=getattr(x, "bn_sums", None)))
                         i += 2 if relu else 1
                         continue
                     x = x.replace_feature(module(x.features))

@@ -253,6 +253,7 @@ def run_gpu(args, rank, world, device):
     for k, it in enumerate(range(args.warmup, args.warmup + args.steps)):
         loss = step(it)
         marks[k + 1].record()        # no sync: the median step time is read after the clock has stopped
+    t_issued = time.perf_counter() - t0      # host time to ENQUEUE the K steps (close to `elapsed` = the host, not the GPU, sets the pace)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -281,7 +282,7 @@ def run_gpu(args, rank, world, device):
     if world > 1 and not fwd_only:
         comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3)
     return {"elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
-            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows}
+            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows, "issue_s": t_issued}
 
 
 PMC_FILE = "r02_pmc_gather_gemm_64x64.json"
@@ -568,8 +569,11 @@ def main(argv=None):
             "config": {"workload": res["desc"], "global_batch": per_gpu * world,
                        "points_per_cloud": {"c3": 180000, "c2": 60000}.get(args.workload, "180000/35000 alternating"),
                        "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4),
-                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2)},
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+                       "alloc_retries": int(torch.cuda.memory_stats(device).get("num_alloc_retries", 0)),
+                       "reserved_gib": round(torch.cuda.memory_reserved(device) / 2 ** 30, 2)},
             # per-step GPU time between events recorded at the step boundaries of rank 0 (no sync inside the region)
+            "host_issue_ms_per_step": round(res["issue_s"] / args.steps * 1e3, 3),
             "ms_per_step_median": round(float(np.median(step_ms)), 3) if step_ms else None,
             "ms_per_step_p10_p90": [round(float(np.percentile(step_ms, q)), 3) for q in (10, 90)] if step_ms else None,
             "roofline": roof,

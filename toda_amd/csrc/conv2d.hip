@@ -439,16 +439,26 @@ __device__ __forceinline__ void ws_epilogue(const f32x4 (&acc)[WN_FREQ], float* 
 __global__ void __launch_bounds__(WS_BLOCK, 2)
 wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
                    float* __restrict__ y, const WinoGeom g, const int n_units, float* __restrict__ slabs,
-                   int* __restrict__ flags, const int ablate) {
+                   int* __restrict__ flags, const int gang, const int ablate) {
     __shared__ float lds[4 * WN_FREQ * WN_IMG];   // A0 | A1 | B0 | B1
     constexpr int IMG = WN_FREQ * WN_IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = gridDim.x;
     const int w = wn_work_id();
-    const long long S = (long long)n_units * g.n_chunks;
-    const long long lo = ws_range_lo(w, G, S), hi = ws_range_lo(w + 1, G, S);
+    // Gangs: the n_cout_blocks channel blocks of a tile block read the SAME input patches.  When the grid is a multiple of
+    // that count, consecutive workgroups (one XCD under the work-id remap) form a gang that walks the tile blocks in step,
+    // member m always on channel block m: the four (eight) readers of a patch run at the same time and share it in L2
+    // instead of re-fetching it 16 chunks later, when the XCD's 4 MiB have long been replaced (PMC: 204 MB fetched per
+    // launch against 36 MB of input).  The sequence a gang splits by stream-K is then (tile block, chunk); the partner of a
+    // cut unit is the same member of the next gang.  Otherwise (gsz = 1) the sequence is (tile block, channel block, chunk).
+    const int gsz = gang ? g.n_cout_blocks : 1;
+    const int G = gridDim.x / gsz;                  // ranges of the step sequence
+    const int rng = w / gsz, member = w - rng * gsz;
+    const long long S = (long long)(gang ? g.n_tile_blocks : n_units) * g.n_chunks;
+    const long long lo = ws_range_lo(rng, G, S), hi = ws_range_lo(rng + 1, G, S);
     const int total = (int)(hi - lo);               // chunks this workgroup multiplies = barriers every wave passes
     if (total == 0) return;
+    auto tb_of = [&](int useq) { return gang ? useq : useq / g.n_cout_blocks; };
+    auto cb_of = [&](int useq) { return gang ? member : useq % g.n_cout_blocks; };
 
     if (wave < 4) {
         // ------------------------------------------------------------------ consumers
@@ -461,7 +471,7 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
             const int unit = (int)(s / g.n_chunks);
             const int c_begin = (int)(s - (long long)unit * g.n_chunks);
             const int c_end = (hi - s < g.n_chunks - c_begin) ? c_begin + (int)(hi - s) : g.n_chunks;
-            const int tb = unit / g.n_cout_blocks, cb = unit - tb * g.n_cout_blocks;
+            const int tb = tb_of(unit), cb = cb_of(unit);
             f32x4 acc[WN_FREQ];
 #pragma unroll
             for (int f = 0; f < WN_FREQ; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -518,9 +528,8 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
                 int n_in = 0;
                 if (c_end < g.n_chunks) {
                     const long long unit_end = (long long)(unit + 1) * g.n_chunks;
-                    for (int w2 = w + 1; w2 < G && ws_range_lo(w2, G, S) < unit_end; ++w2) {
-                        if (ws_range_lo(w2 + 1, G, S) == ws_range_lo(w2, G, S)) continue;      // empty range: no slab
-                        int* const fl = flags + w2 * 4 + wave;
+                    for (int r2 = rng + 1; r2 < G && ws_range_lo(r2, G, S) < unit_end; ++r2) {
+                        int* const fl = flags + (r2 * gsz + member) * 4 + wave;       // same member of the following ranges
                         while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
                         ++n_in;
                     }
@@ -528,12 +537,12 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 ws_epilogue(acc, y, bias, tile_base, co, g, lane, nullptr,
-                            slabs + (size_t)(w + 1) * WS_SLAB_FLOATS + wave * (WS_SLAB_FLOATS / 4), n_in, WS_SLAB_FLOATS);
+                            slabs + (size_t)(w + gsz) * WS_SLAB_FLOATS + wave * (WS_SLAB_FLOATS / 4), n_in, (size_t)gsz * WS_SLAB_FLOATS);
                 if (n_in) {      // every flag is read by exactly one wave: that wave lowers it again once the slab is in its registers,
                                  // so the workspace is all-zero between launches and no memset node is needed in front of each one
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0)
-                        for (int k2 = 1; k2 <= n_in; ++k2) __hip_atomic_store(flags + (w + k2) * 4 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int k2 = 1; k2 <= n_in; ++k2) __hip_atomic_store(flags + (w + k2 * gsz) * 4 + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 
             }
@@ -548,11 +557,11 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
         const int pwave = wave - 4;
 
         auto patch_of = [&](int unit) {
-            const int tb = unit / g.n_cout_blocks;
+            const int tb = tb_of(unit);
             return wn_patch_off(tb * WN_TILES + t_grp * 16 + t_t, t_t, t_c, g.Cin, g);
         };
         auto produce = [&](const Patch& d, int unit, int chunk, int buf) {
-            const int cb = unit % g.n_cout_blocks;
+            const int cb = cb_of(unit);
             const float* usrc = u + ((size_t)cb * g.n_chunks + chunk) * IMG + pt * 4;
             float* const bdst = lds + (2 + buf) * IMG + pwave * 256;
             if (!(ablate & 2)) {
@@ -573,7 +582,7 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
                 if (++ld.chunk == g.n_chunks) {
                     ld.chunk = 0;
                     ld.unit += 1;
-                    if (q_fetch + 1 < total && ld.unit % g.n_cout_blocks == 0) pa = patch_of(ld.unit);   // next tile block
+                    if (q_fetch + 1 < total && (gang || ld.unit % g.n_cout_blocks == 0)) pa = patch_of(ld.unit);   // next tile block
                 }
             }
         };
@@ -963,13 +972,18 @@ extern "C" int toda_conv3x3_fwd(const float* x, const float* u, const float* bia
             if (n_cu > WS_MAX_GRID) n_cu = WS_MAX_GRID;
         }
         // one 144-KiB workgroup per CU; never more workgroups than chunk steps
+        // gang mode: n_cout_blocks workgroups per range of the (tile block, chunk) sequence (see the kernel)
+        static const int env_gang = getenv("TODA_WINO_GANG") ? atoi(getenv("TODA_WINO_GANG")) : 1;
+        const int ncb = g.n_cout_blocks;
+        const int gang = env_gang && ncb > 1 && ncb <= 32 && (32 % ncb) == 0 && (n_cu % ncb) == 0 &&
+                         (long long)g.n_tile_blocks * g.n_chunks >= n_cu / ncb;
         const long long steps = (long long)n_units * g.n_chunks;
-        const int grid = steps < n_cu ? (int)steps : n_cu;
+        const int grid = gang ? n_cu : (steps < n_cu ? (int)steps : n_cu);
         int* flags = (int*)ws;                                  // 4 words per workgroup: zero on entry, zero again on exit
         float* slabs = (float*)((char*)ws + WS_FLAG_BYTES);
         static const int ablate = getenv("TODA_WINO_ABLATE") ? atoi(getenv("TODA_WINO_ABLATE")) : 0;
         hipLaunchKernelGGL(wino_fwd_ws_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, u, bias, y, g, n_units, slabs, flags,
-                           ablate);
+                           gang, ablate);
     }
     TODA_LAUNCH_CHECK();
     return TODA_OK;

@@ -114,6 +114,14 @@ class KernelTimer:
             return self._orig(feat, wp, nbr, c_produce, bias, order)
 
         ops.gather_gemm = labelled
+        self._orig_stats = ops.gather_gemm_with_stats      # forward convs whose epilogue also takes the BatchNorm moments
+
+        def labelled_stats(feat, wp, nbr, c_produce, bias=None):
+            if self._enabled and len(self.records) < self.CAPACITY:
+                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+            return self._orig_stats(feat, wp, nbr, c_produce, bias)
+
+        ops.gather_gemm_with_stats = labelled_stats
 
     @property
     def enabled(self):
@@ -240,6 +248,12 @@ def run_gpu(args, rank, world, device):
             net.update_global_step()
         return loss
 
+    # The cyclic garbage collector is paused over the warm-up + timed steps (one collection up front): a generation-2 pass over
+    # the interpreter's heap (torch, sympy, the model tree) lands as a 10+ ms stall inside a random step and is the kind of
+    # host-side outlier a single driver run cannot average away.  Reference counting still frees every tensor at once.
+    import gc
+    gc.collect()
+    gc.disable()
     for it in range(args.warmup):
         loss = step(it)
     torch.cuda.synchronize()
@@ -259,6 +273,7 @@ def run_gpu(args, rank, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -308,8 +323,11 @@ def pmc_traffic(d):
     if pmc.get("source_sha256", {}).get("toda_amd/csrc/spconv.hip") != _sha256(src):
         return None, f"profiles/{PMC_FILE} was collected on another version of spconv.hip (stale)"
     for shape in pmc["launch_shapes"]:
+        if "<4, 4, 2" not in shape.get("kernel", ""):                # the 64 -> 64 instantiation only
+            continue
         if 0 <= shape["grid_threads"] // 2 - d["n_out"] < 1024:      # 64 lanes per 32-row tile -> 2 threads per row
-            return shape["hbm_bytes"], f"profiles/{PMC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernel {pmc['kernel'][0]}, grid {shape['grid_threads']}"
+            return shape["hbm_bytes"], (f"profiles/{PMC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2*FETCH + WRITE), "
+                                        f"{shape['kernel']}, grid {shape['grid_threads']}, {shape['dispatches']} dispatches")
     return None, "no profiled launch shape matches"
 
 

@@ -30,6 +30,7 @@ class OpTable:
                      "toda_center_assign"):
             self._wrap_c(name)
         self._wrap_py("gather_gemm", self._cost_gather_gemm)
+        self._wrap_py("gather_gemm_with_stats", self._cost_gather_gemm)
         self._wrap_py("wgrad", self._cost_wgrad)
         self._wrap_py("conv3x3_run", self._cost_conv3x3)
         self._wrap_py("conv3x3_wgrad", self._cost_conv3x3_wgrad)

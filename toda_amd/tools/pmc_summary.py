@@ -23,11 +23,12 @@ def main():
         for r in csv.DictReader(open(path)):
             if pattern not in r["Kernel_Name"]:
                 continue
-            names.add(r["Kernel_Name"].split("(")[0])
-            acc[int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kname = r["Kernel_Name"].split("(")[0]
+            names.add(kname)
+            acc[(kname, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     shapes = []
-    for grid, counters in sorted(acc.items()):
-        row = {"grid_threads": grid, "dispatches": max(len(v) for v in counters.values())}
+    for (kname, grid), counters in sorted(acc.items()):
+        row = {"kernel": kname, "grid_threads": grid, "dispatches": max(len(v) for v in counters.values())}
         for name, vals in sorted(counters.items()):
             row[name] = sum(vals) / len(vals)
         if "FETCH_SIZE" in row and "WRITE_SIZE" in row:

@@ -263,11 +263,13 @@ def run_gpu(args, rank, world, device):
     timer.enabled = True
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    cpu0 = time.thread_time()
     marks[0].record()
     for k, it in enumerate(range(args.warmup, args.warmup + args.steps)):
         loss = step(it)
         marks[k + 1].record()        # no sync: the median step time is read after the clock has stopped
-    t_issued = time.perf_counter() - t0      # host time to ENQUEUE the K steps (close to `elapsed` = the host, not the GPU, sets the pace)
+    t_issued = time.perf_counter() - t0      # host wall time to ENQUEUE the K steps (includes waiting at the two host syncs per step)
+    cpu_busy = time.thread_time() - cpu0     # CPU time of this thread over the same span: what the host really WORKS per step
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -297,7 +299,7 @@ def run_gpu(args, rank, world, device):
     if world > 1 and not fwd_only:
         comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3)
     return {"elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
-            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows, "issue_s": t_issued}
+            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows, "issue_s": t_issued, "cpu_s": cpu_busy}
 
 
 PMC_FILE = "r02_pmc_gather_gemm_64x64.json"
@@ -592,6 +594,7 @@ def main(argv=None):
                        "reserved_gib": round(torch.cuda.memory_reserved(device) / 2 ** 30, 2)},
             # per-step GPU time between events recorded at the step boundaries of rank 0 (no sync inside the region)
             "host_issue_ms_per_step": round(res["issue_s"] / args.steps * 1e3, 3),
+            "host_cpu_ms_per_step": round(res["cpu_s"] / args.steps * 1e3, 3),
             "ms_per_step_median": round(float(np.median(step_ms)), 3) if step_ms else None,
             "ms_per_step_p10_p90": [round(float(np.percentile(step_ms, q)), 3) for q in (10, 90)] if step_ms else None,
             "roofline": roof,

@@ -695,6 +695,137 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
     }
 }
 
+// Staged variant of gather_gemm_lds_kernel for the 64 -> 64 layers: the weight slices of KS consecutive offsets share one LDS
+// stage and the waves of a workgroup meet only at the stage boundaries (two barriers per KS offsets instead of one per offset).
+// Why: with a barrier per offset every wave waits for the busiest wave OF THAT OFFSET.  A wave's 32 rows have a neighbour at a
+// given offset in 0, 1 or 2 of its two 16-row tiles (72 % of the (tile, offset) pairs are non-empty on the stride-4 level), so
+// the expected maximum over the 4 waves of a block is ~1.35x the mean - exactly the 70 % matrix-pipe utilisation the PMC pass
+// shows.  Over 3 offsets the waves' sums differ much less.  512-thread workgroups (8 waves share a stage, 2 workgroups = 16
+// waves per CU as before), 48 KiB of LDS per workgroup.
+template <int Q, int NT, int KS, int BLK>
+__global__ void __launch_bounds__(BLK, 4)
+gather_gemm_stage_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
+                         int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out, double* __restrict__ stats) {
+    constexpr int RT = 2;
+    constexpr int SLICE = Q * NT * 64;                    // float4 per offset
+    constexpr int STG = KS * SLICE;
+    constexpr int PER_THREAD = STG / BLK;
+    static_assert(STG % BLK == 0, "stage must divide over the workgroup");
+    __shared__ f32x4 wl[STG];
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = wave * (16 * RT);
+    const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        float b = 0.0f;
+        if (bias && NT * r + n < cp) b = bias[NT * r + n];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][n] = f32x4{b, b, b, b};
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cg * 4u);
+    int rows[RT];
+    bool live[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        live[rt] = row0 + rt * 16 + r < n_out;
+        rows[rt] = live[rt] ? row0 + rt * 16 + r : n_out - 1;
+    }
+    const int total_f4 = K * SLICE;
+    for (int k0 = 0; k0 < K; k0 += KS) {
+        f32x4 stage[PER_THREAD];
+#pragma unroll
+        for (int t = 0; t < PER_THREAD; ++t) {
+            const int e = k0 * SLICE + t * BLK + threadIdx.x;
+            stage[t] = e < total_f4 ? wp4[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();          // every wave has finished the previous stage
+#pragma unroll
+        for (int t = 0; t < PER_THREAD; ++t) wl[t * BLK + threadIdx.x] = stage[t];
+        __syncthreads();
+#pragma unroll 1
+        for (int kk = 0; kk < KS; ++kk) {
+            const int k = k0 + kk;
+            if (k >= K) break;
+            int src[RT];
+            bool hit[RT];
+            bool any = false;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int v = nbr[(size_t)k * n_out + rows[rt]];
+                src[rt] = live[rt] ? v : -1;
+                hit[rt] = __any(src[rt] >= 0);
+                any = any || hit[rt];
+            }
+            if (!any) continue;
+            f32x4 a[RT][Q];
+            gather_rows<Q, RT, true>(in_rsrc, cg, g, src, a);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                f32x4 b[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[n] = wl[kk * SLICE + (q * NT + n) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+                            if (hit[rt]) acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[n][j], acc[rt][n], 0, 0, 0);
+            }
+        }
+    }
+
+    if (stats) {      // BatchNorm moments of the output rows (see gather_gemm_lds_kernel)
+        __shared__ float st_sh[BLK / 64][2][16 * NT];
+        float sm[NT], sq[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            sm[n] = sq[n] = 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (row0 + rt * 16 + 4 * g + reg < n_out) {
+                        const float v = acc[rt][n][reg];
+                        sm[n] += v;
+                        sq[n] += v * v;
+                    }
+            sm[n] += __shfl_xor(sm[n], 16, 64);
+            sq[n] += __shfl_xor(sq[n], 16, 64);
+            sm[n] += __shfl_xor(sm[n], 32, 64);
+            sq[n] += __shfl_xor(sq[n], 32, 64);
+            if (g == 0) {
+                st_sh[threadIdx.x >> 6][0][NT * r + n] = sm[n];
+                st_sh[threadIdx.x >> 6][1][NT * r + n] = sq[n];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * cp) {
+            const int qq = threadIdx.x / cp, ch = threadIdx.x - qq * cp;
+            double a2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < BLK / 64; ++w) a2 += (double)st_sh[w][qq][ch];
+            stats[2 * cp + (size_t)(qq * cp + ch) * gridDim.x + blockIdx.x] = a2;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + rt * 16 + 4 * g + reg;
+            if (row >= n_out) continue;
+            float* dst = out + (size_t)row * cp + NT * r;
+#pragma unroll
+            for (int n = 0; n < NT; n += 4)
+                *reinterpret_cast<f32x4*>(dst + n) = f32x4{acc[rt][n][reg], acc[rt][n + 1][reg], acc[rt][n + 2][reg], acc[rt][n + 3][reg]};
+        }
+    }
+}
+
 // wgrad: dW[co][k][ci] = sum_o in[nbr[k][o]][ci] * dout[o][co].  Grid (row chunk, offset, channel
 // sub-block).  The contraction runs over PAIRS, not rows: every wave reads 64 neighbour ids at a
 // time (one coalesced 256-byte load), compacts the valid (in,out) pairs into a small LDS queue
@@ -1080,6 +1211,21 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false>), dim3(cdiv(cdiv(n_out, 16), SC_BLOCK / 64)),
                                dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats);
         TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
+    // 64 -> 64: 3 offsets per LDS stage, 512-thread workgroups (fewer, better balanced barriers)
+    // OFF by default: measured 0.502 ms against 0.498 ms for the per-offset barrier kernel on the 389.5k-row level - the
+    // barrier imbalance it removes is not what holds the matrix pipe at 70 %.
+    static const int env_stage = getenv("TODA_GG_STAGE") ? atoi(getenv("TODA_GG_STAGE")) : 0;
+    if (env_stage && vec_ok && order == nullptr && Q == 4 && NT == 4 && c_gather == 64 && c_produce == 64 && n_out >= 8192) {
+        const int blocks = cdiv(cdiv(n_out, 32), 8);
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_stage_kernel<4, 4, 3, 512>), dim3(blocks), dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out,
+                  k_vol, c_produce, bias, out, stats);
+        TODA_LAUNCH_CHECK();
+        if (stats) {
+            hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c_produce), dim3(256), 0, s, stats, blocks, 2 * c_produce);
+            TODA_LAUNCH_CHECK();
+        }
         return TODA_OK;
     }
     // 64 -> 64: wave-specialised producer / consumer kernel (persistent, one 512-thread workgroup per CU)

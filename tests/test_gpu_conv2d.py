@@ -78,3 +78,33 @@ def test_module_routing_keeps_unsupported_layers_on_torch():
     assert len(calls) == 2
     ref = seq(x)
     assert float((y - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("geom", [(2, 64, 20, 24), (1, 16, 7, 188), (3, 8, 33, 4)])
+def test_narrow_output_conv_group_matches_fp64(geom):
+    """toda_conv3x3_narrow_{fwd,dgrad,wgrad}: the 64 -> {2, 1, 3, 2, 3} output convolutions of the five CenterHead branches
+    (reference center_head.py:20-28) in one launch per direction, against torch.nn.functional.conv2d in float64."""
+    from toda_amd import ops
+
+    b, cin, h, w_ = geom
+    couts = [2, 1, 3, 2, 3]
+    g = torch.Generator().manual_seed(cin + h)
+    convs = []
+    for co in couts:
+        c = torch.nn.Conv2d(cin, co, 3, padding=1, bias=True)
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5
+        c.bias.data = torch.randn(co, generator=g)
+        convs.append(c.cuda())
+    xs = [torch.randn((b, cin, h, w_), generator=g).cuda().requires_grad_(True) for _ in couts]
+    gys = [torch.randn((b, co, h, w_), generator=g).cuda() for co in couts]
+    assert all(ops.conv3x3_narrow_supported(x, c) for x, c in zip(xs, convs))
+    ys = ops.conv3x3_narrow_group(xs, convs)
+    torch.autograd.backward(ys, gys)
+    for x, c, y, gy in zip(xs, convs, ys, gys):
+        xd = x.detach().double().cpu().requires_grad_(True)
+        wd, bd = c.weight.detach().double().cpu().requires_grad_(True), c.bias.detach().double().cpu().requires_grad_(True)
+        ref = F.conv2d(xd, wd, bd, padding=1)
+        ref.backward(gy.double().cpu())
+        for name, got, want in (("y", y, ref), ("dx", x.grad, xd.grad), ("dw", c.weight.grad, wd.grad), ("db", c.bias.grad, bd.grad)):
+            err = float((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max())
+            assert err < 2e-5, (name, err)

@@ -767,6 +767,77 @@ def conv3x3(x, weight, bias=None):
     return _Conv3x3.apply(x, weight, bias)
 
 
+# ---------------------------------------------------- narrow-output 3x3 convolutions (last layer of the head branches)
+def conv3x3_narrow_supported(x, conv):
+    if DENSE_CONV != "winograd" or type(conv) is not torch.nn.Conv2d or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return False
+    if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or conv.padding != (1, 1):
+        return False
+    if conv.padding_mode != "zeros" or conv.in_channels != x.shape[1]:
+        return False
+    b, c, h, w = x.shape
+    return bool(L.load().toda_conv3x3_narrow_supported(b, c, conv.out_channels, h, w))
+
+
+class _Conv3x3NarrowGroup(torch.autograd.Function):
+    """y_i = conv2d(x_i, w_i, b_i, padding 1) for the n branches of a head in one launch per direction.
+    apply(n, x_0..x_{n-1}, w_0.., b_0..) -> (y_0, .., y_{n-1}); biases may be None."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        lib = L.load()
+        xs = [a.contiguous() for a in args[:n]]
+        ws = [a.contiguous() for a in args[n:2 * n]]
+        bs = list(args[2 * n:3 * n])
+        b, cin, h, w = xs[0].shape
+        couts = [int(wt.shape[0]) for wt in ws]
+        ys = [torch.empty((b, co, h, w), dtype=torch.float32, device=xs[0].device) for co in couts]
+        co_host = L.host_i32(couts)
+        has_bias = any(t is not None for t in bs)
+        rc = lib.toda_conv3x3_narrow_fwd(n, L.host_ptrs(xs), L.host_ptrs(ws), L.host_ptrs(bs) if has_bias else None, L.hptr(co_host),
+                                         b, cin, h, w, L.host_ptrs(ys), L.stream())
+        L.check(rc, "toda_conv3x3_narrow_fwd")
+        ctx.n, ctx.couts, ctx.geom = n, couts, (b, cin, h, w)
+        ctx.has_bias = [t is not None for t in bs]
+        ctx.save_for_backward(*xs, *ws)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        lib = L.load()
+        n, couts = ctx.n, ctx.couts
+        b, cin, h, w = ctx.geom
+        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        gys = [g.contiguous() for g in gys]
+        dev = gys[0].device
+        co_host = L.host_i32(couts)
+        gxs = [None] * n
+        if any(ctx.needs_input_grad[1:1 + n]):
+            gxs = [torch.empty((b, cin, h, w), dtype=torch.float32, device=dev) for _ in range(n)]
+            rc = lib.toda_conv3x3_narrow_dgrad(n, L.host_ptrs(gys), L.host_ptrs(ws), L.hptr(co_host), b, cin, h, w, L.host_ptrs(gxs), L.stream())
+            L.check(rc, "toda_conv3x3_narrow_dgrad")
+        total = sum(co * (cin * 9 + 1) for co in couts)
+        out = torch.empty((total,), dtype=torch.float32, device=dev)
+        ws_bytes = lib.toda_conv3x3_narrow_wgrad_workspace_bytes(n, b, cin, h)
+        wsp = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        rc = lib.toda_conv3x3_narrow_wgrad(n, L.host_ptrs(xs), L.host_ptrs(gys), L.hptr(co_host), b, cin, h, w, L.ptr(out), L.ptr(wsp), ws_bytes,
+                                           L.stream())
+        L.check(rc, "toda_conv3x3_narrow_wgrad")
+        gws, gbs, off = [], [], 0
+        for co, hb in zip(couts, ctx.has_bias):
+            gws.append(out[off:off + co * cin * 9].view(co, cin, 3, 3))
+            off += co * cin * 9
+            gbs.append(out[off:off + co] if hb else None)
+            off += co
+        return (None, *gxs, *gws, *gbs)
+
+
+def conv3x3_narrow_group(xs, convs):
+    """The final nn.Conv2d of several head branches (same input geometry) in one launch; returns the list of outputs."""
+    n = len(xs)
+    return list(_Conv3x3NarrowGroup.apply(n, *xs, *[c.weight for c in convs], *[c.bias for c in convs]))
+
+
 # --------------------------------------------------------------- CenterHead target assign
 def center_assign(gt_boxes, num_classes, fm_w, fm_h, pc_range, voxel_size, fm_stride, max_objs=500, overlap=0.1,
                   min_radius=2):

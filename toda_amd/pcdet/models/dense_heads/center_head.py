@@ -39,7 +39,17 @@ class SeparateHead(nn.Module):
             setattr(self, name, branch)
 
     def forward(self, x):
-        return {name: ops.run_dense_sequential(getattr(self, name), x) for name in self.sep_head_dict}
+        names = list(self.sep_head_dict)
+        branches = [getattr(self, name) for name in names]
+        last = [br[-1] for br in branches]
+        # every branch ends in Conv2d(C, out_channels <= 4, 3, padding=1): the hidden layers run branch by branch, the five
+        # output convolutions (and their backward) as ONE launch per direction (toda_conv3x3_narrow_*)
+        if len(names) <= 8 and all(len(br) >= 1 and ops.conv3x3_narrow_supported(x, conv) for br, conv in zip(branches, last)):
+            hidden = [ops.run_dense_sequential(br[:-1], x) if len(br) > 1 else x for br in branches]
+            if all(h.shape == hidden[0].shape for h in hidden):
+                return dict(zip(names, ops.conv3x3_narrow_group(hidden, last)))
+            return {name: last_conv(h) for name, last_conv, h in zip(names, last, hidden)}
+        return {name: ops.run_dense_sequential(br, x) for name, br in zip(names, branches)}
 
 
 class CenterHead(nn.Module):

@@ -47,6 +47,77 @@ def voxelize_on_gpu(batch_dict, voxel_cfg):
     return batch_dict
 
 
+def prepare_batch_on_gpu(batch_dict, net):
+    """Everything of a training step that depends only on the INPUT: H2D, voxelisation, the sparse backbone's rulebooks.
+    The reference does this part (voxelisation) in DataLoader workers, concurrently with the previous training step
+    (pcdet/datasets/processor/data_processor.py:115-143); InputPrefetcher below does it on a side stream."""
+    load_data_to_gpu(batch_dict)
+    if "voxels" not in batch_dict and "points" in batch_dict:
+        voxelize_on_gpu(batch_dict, net.dataset.voxel_cfg)
+    backbone = getattr(net, "backbone_3d", None)
+    if backbone is not None and hasattr(backbone, "plan") and "voxel_coords" in batch_dict and batch_dict["voxel_coords"].is_cuda:
+        backbone.plan(batch_dict)
+    return batch_dict
+
+
+def _record_stream(obj, stream, seen=None):
+    """Tell the caching allocator that every CUDA tensor reachable from obj is used on `stream` too."""
+    seen = set() if seen is None else seen
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream, seen)
+    elif hasattr(obj, "__dict__") and not isinstance(obj, torch.nn.Module):
+        _record_stream(vars(obj), stream, seen)
+
+
+class InputPrefetcher:
+    """Device-side input pipeline: batch t + 1 is voxelised and its rulebooks are built on a side HIP stream while the main
+    stream still runs step t, so the two host syncs of the index building (voxel counts, output-set sizes) and the ~1 ms of
+    small index kernels leave the critical path.  next() hands out a prepared batch (the main stream waits for its event);
+    kick() starts the preparation of the following one - call it once the forward pass of the current step is enqueued."""
+
+    def __init__(self, batches, net, device):
+        self.it = iter(batches)
+        self.net = net
+        self.side = torch.cuda.Stream(device=device)
+        self.pending = None
+        self.kick()
+
+    def kick(self):
+        if self.pending is not None:
+            return
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            return
+        with torch.cuda.stream(self.side):
+            batch = prepare_batch_on_gpu(batch, self.net)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.pending = (batch, ev)
+
+    def next(self):
+        if self.pending is None:
+            self.kick()
+        if self.pending is None:
+            raise StopIteration
+        batch, ev = self.pending
+        self.pending = None
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        _record_stream(batch, main)
+        return batch
+
+
 ModelReturn = namedtuple("ModelReturn", ["loss", "tb_dict", "disp_dict"])
 
 
@@ -54,7 +125,7 @@ def model_fn_decorator():
     def model_func(model, batch_dict):
         load_data_to_gpu(batch_dict)
         if "voxels" not in batch_dict and "points" in batch_dict:
-            net = model.module if hasattr(model, "module") else model
+            net = model.module if hasattr(model, "module") and not hasattr(model, "dataset") else model
             voxelize_on_gpu(batch_dict, net.dataset.voxel_cfg)
         ret_dict, tb_dict, disp_dict = model(batch_dict)
         loss = ret_dict["loss"].mean()

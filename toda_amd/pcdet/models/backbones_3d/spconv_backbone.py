@@ -3,6 +3,7 @@
 reference's state_dict keys (conv_input.0.weight, conv2.0.0.weight, conv1.0.conv1.weight, ...)."""
 from functools import partial
 
+import torch
 import torch.nn as nn
 
 from toda_amd import ops
@@ -77,9 +78,25 @@ class _Backbone8xBase(nn.Module):
             batch_size=batch_dict["batch_size"],
         )
 
+    def plan(self, batch_dict):
+        """Every rulebook of the backbone for this batch's voxel_coords, built ahead of the forward pass (one host sync; also
+        what the input prefetcher runs on its side stream for the NEXT batch).  Stored as batch_dict['sparse_index_plan']."""
+        if not hasattr(spconv, "plan_indices"):
+            return batch_dict
+        coords = batch_dict["voxel_coords"]
+        probe = spconv.SparseConvTensor(features=coords.new_zeros((coords.shape[0], 1), dtype=torch.float32), indices=coords.int(),
+                                        spatial_shape=self.sparse_shape, batch_size=batch_dict["batch_size"])
+        spconv.plan_indices(probe, self)
+        batch_dict["sparse_index_plan"] = (probe.indice_dict, probe.grid_index)
+        return batch_dict
+
     def forward(self, batch_dict):
         x = self._input_tensor(batch_dict)
-        if hasattr(spconv, "plan_indices"):
+        ready = batch_dict.get("sparse_index_plan")
+        if ready is not None:
+            x.indice_dict.update(ready[0])
+            x.grid_index = ready[1]
+        elif hasattr(spconv, "plan_indices"):
             # all 8/9 rulebooks with one host sync instead of one per strided conv
             spconv.plan_indices(x, self)
         x = self.conv_input(x)

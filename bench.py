@@ -315,6 +315,16 @@ def run_gpu(args, rank, world, device):
         table.enabled = False
         op_rows = table.rows(extra)
         table.restore()
+    if os.environ.get("TODA_TORCH_PROFILE") and rank == 0:
+        # which Python line launches which small kernel: two extra steps under torch.profiler, grouped by call stack
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            for it in range(args.warmup + args.steps + 3, args.warmup + args.steps + 5):
+                step(it)
+            torch.cuda.synchronize()
+        with open(os.environ["TODA_TORCH_PROFILE"], "w") as f:
+            f.write(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=150, max_name_column_width=60,
+                                                                 max_src_column_width=110))
     comm = None
     if world > 1 and not fwd_only:
         comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3)

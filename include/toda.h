@@ -337,19 +337,23 @@ int toda_conv3x3_fwd(const float* x, const float* u, const float* bias, int batc
  * (pcdet/models/dense_heads/center_head.py:20-28: Conv2d(64, out_channels, 3, padding=1, bias=True) of center /
  * center_z / dim / rot / hm), forward and autograd backward.  All n <= 8 branches of a head go through ONE launch
  * per direction.  Pointer arguments ending in [] are HOST arrays of n device pointers, cout_host holds the n
- * output-channel counts; every branch has the same (batch, cin, H, W), W % 4 == 0, W <= 256.
+ * output-channel counts; every branch has the same (batch, cin, H, W), W % 4 == 0, W <= 256.  x_image_stride /
+ * dx_image_stride: floats between two images of a branch input (its gradient): 0 = dense (cin * H * W); larger when
+ * the branch inputs are channel slices of one [B][n * cin][H][W] tensor (the fused hidden layer of the head).
  *   _fwd     y_i[B][cout_i][H][W] = conv(x_i[B][cin][H][W], w_i[cout_i][cin][3][3]) + bias_i (bias_host may be NULL)
  *   _dgrad   dx_i[B][cin][H][W] from dy_i and w_i
  *   _wgrad   out = for i in order: dw_i [cout_i][cin][3][3] then db_i [cout_i]  (band slabs in ws, fixed-order fold)
  * ---------------------------------------------------------------------- */
 int toda_conv3x3_narrow_supported(int batch, int cin, int cout, int H, int W);
 int toda_conv3x3_narrow_fwd(int n, const float* const* x_host, const float* const* w_host, const float* const* bias_host,
-                            const int32_t* cout_host, int batch, int cin, int H, int W, float* const* y_host, void* stream);
+                            const int32_t* cout_host, int batch, int cin, int H, int W, long long x_image_stride,
+                            float* const* y_host, void* stream);
 int toda_conv3x3_narrow_dgrad(int n, const float* const* dy_host, const float* const* w_host, const int32_t* cout_host,
-                              int batch, int cin, int H, int W, float* const* dx_host, void* stream);
+                              int batch, int cin, int H, int W, long long dx_image_stride, float* const* dx_host, void* stream);
 size_t toda_conv3x3_narrow_wgrad_workspace_bytes(int n, int batch, int cin, int H);
 int toda_conv3x3_narrow_wgrad(int n, const float* const* x_host, const float* const* dy_host, const int32_t* cout_host,
-                              int batch, int cin, int H, int W, float* out, void* ws, size_t ws_bytes, void* stream);
+                              int batch, int cin, int H, int W, long long x_image_stride, float* out, void* ws, size_t ws_bytes,
+                              void* stream);
 
 /* ------------------------------------------------------------------------
  * Instrumentation (no counterpart in the reference): per-launch durations of the gather-GEMM kernels, taken

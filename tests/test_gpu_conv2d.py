@@ -108,3 +108,72 @@ def test_narrow_output_conv_group_matches_fp64(geom):
         for name, got, want in (("y", y, ref), ("dx", x.grad, xd.grad), ("dw", c.weight.grad, wd.grad), ("db", c.bias.grad, bd.grad)):
             err = float((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max())
             assert err < 2e-5, (name, err)
+
+
+def test_narrow_output_conv_group_on_channel_slices():
+    """Same kernels with the branch inputs given as channel slices of one [B, n C, H, W] tensor (image stride argument): outputs
+    and all gradients equal the separate-tensor call bit for bit, the input gradient comes back as one wide tensor."""
+    from toda_amd import ops
+
+    b, cin, h, w_ = 2, 32, 12, 20
+    couts = [2, 1, 3]
+    g = torch.Generator().manual_seed(5)
+    convs_a, convs_b = [], []
+    for co in couts:
+        c = torch.nn.Conv2d(cin, co, 3, padding=1, bias=True)
+        c.weight.data = torch.randn(c.weight.shape, generator=g) * 0.1
+        convs_a.append(c.cuda())
+        convs_b.append(__import__("copy").deepcopy(c).cuda())
+    wide = torch.randn((b, cin * len(couts), h, w_), generator=g).cuda().requires_grad_(True)
+    xs = [wide.detach()[:, i * cin:(i + 1) * cin].contiguous().requires_grad_(True) for i in range(len(couts))]
+    gys = [torch.randn((b, co, h, w_), generator=g).cuda() for co in couts]
+    ya = ops.conv3x3_narrow_group(xs, convs_a)
+    yb = ops.conv3x3_narrow_group_fused(wide, convs_b)
+    torch.autograd.backward(ya, gys)
+    torch.autograd.backward(yb, gys)
+    for i in range(len(couts)):
+        assert torch.equal(ya[i], yb[i])
+        assert torch.equal(xs[i].grad, wide.grad[:, i * cin:(i + 1) * cin])
+        assert torch.equal(convs_a[i].weight.grad, convs_b[i].weight.grad)
+        assert torch.equal(convs_a[i].bias.grad, convs_b[i].bias.grad)
+
+
+def test_separate_head_fused_hidden_layer_matches_branchwise_modules():
+    """SeparateHead.forward (one 64 -> 5 x 64 convolution + one BatchNorm over 320 channels + sliced output convolutions)
+    against the plain nn.Sequential branches of the reference (center_head.py:20-41): outputs, every parameter gradient, the
+    input gradient, and the BatchNorm running statistics / step counters of every branch."""
+    import copy
+
+    from toda_amd import ops
+    from toda_amd.pcdet.models.dense_heads.center_head import SeparateHead
+
+    torch.manual_seed(3)
+    head_dict = {"center": dict(out_channels=2, num_conv=2), "center_z": dict(out_channels=1, num_conv=2), "dim": dict(out_channels=3, num_conv=2),
+                 "rot": dict(out_channels=2, num_conv=2), "hm": dict(out_channels=3, num_conv=2)}
+    head = SeparateHead(64, head_dict).cuda().train()
+    ref = copy.deepcopy(head)
+    x = torch.randn(2, 64, 24, 28, device="cuda")
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    with ops.bn_counter_scope():
+        out = head(xa)
+    want = {name: getattr(ref, name)(xb) for name in head_dict}
+    gys = {name: torch.randn_like(want[name]) for name in head_dict}
+    torch.autograd.backward([out[n] for n in head_dict], [gys[n] for n in head_dict])
+    torch.autograd.backward([want[n] for n in head_dict], [gys[n] for n in head_dict])
+    for name in head_dict:
+        assert float((out[name] - want[name]).abs().max()) < 2e-4 * float(want[name].abs().max()), name
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-3 * float(xb.grad.abs().max())
+    for (k, p), (_, q) in zip(head.named_parameters(), ref.named_parameters()):
+        assert float((p.grad - q.grad).abs().max()) <= 1e-3 * float(q.grad.abs().max()) + 1e-6, k
+    for (k, p), (_, q) in zip(head.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(p.float(), q.float(), rtol=1e-4, atol=1e-6), k
+    assert set(head.state_dict()) == set(ref.state_dict())
+    # a buffer replaced from outside (module.to(), load) is re-aliased without losing its value
+    head.center[0][1].running_mean = head.center[0][1].running_mean.clone() + 1.0
+    ref.center[0][1].running_mean += 1.0
+    with ops.bn_counter_scope():
+        head(x)
+    for name in head_dict:
+        getattr(ref, name)(x)
+    for (k, p), (_, q) in zip(head.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(p.float(), q.float(), rtol=1e-4, atol=1e-6), k

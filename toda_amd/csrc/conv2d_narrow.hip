@@ -33,6 +33,8 @@ struct NarrowArgs {
     float* db[NW_MAX_BRANCH];          // wgrad: bias-gradient slab base or nullptr
     int cout[NW_MAX_BRANCH];
     int n, B, Cin, H, W;
+    int xbs;                           // floats between two images of x (forward, wgrad) / dx (dgrad): Cin * H * W, or more when the
+                                       // branch inputs are channel slices of one wider tensor
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t nw_rsrc(const float* base, size_t bytes) {
@@ -69,14 +71,14 @@ narrow_fwd_kernel(const NarrowArgs a) {
     const int b = row / a.H, y = row - b * a.H;
     const int cout = a.cout[br];
     const float* __restrict__ w = a.w[br];
-    const __amdgpu_buffer_rsrc_t xr = nw_rsrc(a.x[br], (size_t)a.B * a.Cin * a.H * a.W * 4u);
+    const __amdgpu_buffer_rsrc_t xr = nw_rsrc(a.x[br], ((size_t)(a.B - 1) * a.xbs + (size_t)a.Cin * a.H * a.W) * 4u);
     f32x4 acc[NW_CO];
 #pragma unroll
     for (int co = 0; co < NW_CO; ++co) acc[co] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int per = (a.Cin + 3) >> 2;
     const int ci_end = min(a.Cin, (wv + 1) * per);
     for (int ci = wv * per; ci < ci_end; ++ci) {
-        const int plane = (b * a.Cin + ci) * a.H * a.W;
+        const int plane = b * a.xbs + ci * a.H * a.W;
         Row6 r[3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) r[dy] = nw_load_row(xr, plane, y + dy - 1, a.H, a.W, lane);
@@ -148,7 +150,7 @@ narrow_dgrad_kernel(const NarrowArgs a) {
                     for (int p = 0; p < 4; ++p) acc[p] = __builtin_fmaf(wv2, g[co][2 - ta].v[p + 2 - tb], acc[p]);
                 }
         }
-        if (4 * lane < a.W) *reinterpret_cast<f32x4*>(dx + (((size_t)b * a.Cin + ci) * a.H + y) * a.W + 4 * lane) = acc;
+        if (4 * lane < a.W) *reinterpret_cast<f32x4*>(dx + (size_t)b * a.xbs + ((size_t)ci * a.H + y) * a.W + 4 * lane) = acc;
     }
 }
 
@@ -161,7 +163,7 @@ narrow_wgrad_kernel(const NarrowArgs a, const int band_stride) {
     const int lane = threadIdx.x & 63, ci = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ci >= a.Cin) return;
     const int cout = a.cout[br];
-    const __amdgpu_buffer_rsrc_t xr = nw_rsrc(a.x[br], (size_t)a.B * a.Cin * a.H * a.W * 4u);
+    const __amdgpu_buffer_rsrc_t xr = nw_rsrc(a.x[br], ((size_t)(a.B - 1) * a.xbs + (size_t)a.Cin * a.H * a.W) * 4u);
     const __amdgpu_buffer_rsrc_t gr = nw_rsrc(a.dy[br], (size_t)a.B * cout * a.H * a.W * 4u);
     float acc[NW_CO][9], bsum[NW_CO];
 #pragma unroll
@@ -176,7 +178,7 @@ narrow_wgrad_kernel(const NarrowArgs a, const int band_stride) {
         const int b = rr / a.H, y = rr - b * a.H;
         Row6 r[3];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) r[d] = nw_load_row(xr, (b * a.Cin + ci) * a.H * a.W, y + d - 1, a.H, a.W, lane);
+        for (int d = 0; d < 3; ++d) r[d] = nw_load_row(xr, b * a.xbs + ci * a.H * a.W, y + d - 1, a.H, a.W, lane);
 #pragma unroll
         for (int co = 0; co < NW_CO; ++co) {
             if (co >= cout) break;
@@ -221,11 +223,12 @@ narrow_fold_kernel(const float* __restrict__ slab, int bands, int elems, float* 
     out[e] = acc;
 }
 
-static int narrow_check(const char* who, int n, int batch, int cin, int H, int W, const int* cout) {
+static int narrow_check(const char* who, int n, int batch, int cin, int H, int W, const int* cout, long long xbs) {
+    TODA_CHECK_ARG(xbs == 0 || (xbs >= (long long)cin * H * W && xbs % 4 == 0), "%s: image stride %lld below one image (%d x %d x %d) or not a multiple of 4", who, xbs, cin, H, W);
+    TODA_CHECK_ARG(4LL * batch * (xbs ? xbs : (long long)cin * H * W) < (1LL << 32) - 65536, "%s: tensor above 4 GiB", who);
     TODA_CHECK_ARG(n >= 1 && n <= NW_MAX_BRANCH, "%s: 1..%d branches per call (got %d)", who, NW_MAX_BRANCH, n);
     TODA_CHECK_ARG(batch >= 1 && cin >= 1 && H >= 1 && W >= 4 && W % 4 == 0 && W <= 256, "%s: needs W %% 4 == 0 and W <= 256 (got %d x %d)", who, H, W);
     for (int i = 0; i < n; ++i) TODA_CHECK_ARG(cout[i] >= 1 && cout[i] <= NW_CO, "%s: 1..%d output channels per branch (got %d)", who, NW_CO, cout[i]);
-    TODA_CHECK_ARG(4LL * batch * cin * H * W < (1LL << 32) - 65536, "%s: tensor above 4 GiB", who);
     return TODA_OK;
 }
 
@@ -239,8 +242,8 @@ extern "C" int toda_conv3x3_narrow_supported(int batch, int cin, int cout, int H
 }
 
 extern "C" int toda_conv3x3_narrow_fwd(int n, const float* const* x, const float* const* w, const float* const* bias, const int32_t* cout,
-                                       int batch, int cin, int H, int W, float* const* y, void* stream) {
-    int rc = narrow_check("conv3x3_narrow_fwd", n, batch, cin, H, W, cout);
+                                       int batch, int cin, int H, int W, long long x_image_stride, float* const* y, void* stream) {
+    int rc = narrow_check("conv3x3_narrow_fwd", n, batch, cin, H, W, cout, x_image_stride);
     if (rc) return rc;
     NarrowArgs a = {};
     for (int i = 0; i < n; ++i) {
@@ -248,14 +251,15 @@ extern "C" int toda_conv3x3_narrow_fwd(int n, const float* const* x, const float
         a.x[i] = x[i], a.w[i] = w[i], a.b[i] = bias ? bias[i] : nullptr, a.y[i] = y[i], a.cout[i] = cout[i];
     }
     a.n = n, a.B = batch, a.Cin = cin, a.H = H, a.W = W;
+    a.xbs = x_image_stride ? (int)x_image_stride : cin * H * W;
     hipLaunchKernelGGL(narrow_fwd_kernel, dim3(batch * H, 1, n), dim3(256), 0, (hipStream_t)stream, a);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }
 
 extern "C" int toda_conv3x3_narrow_dgrad(int n, const float* const* dy, const float* const* w, const int32_t* cout, int batch, int cin, int H,
-                                         int W, float* const* dx, void* stream) {
-    int rc = narrow_check("conv3x3_narrow_dgrad", n, batch, cin, H, W, cout);
+                                         int W, long long dx_image_stride, float* const* dx, void* stream) {
+    int rc = narrow_check("conv3x3_narrow_dgrad", n, batch, cin, H, W, cout, dx_image_stride);
     if (rc) return rc;
     NarrowArgs a = {};
     for (int i = 0; i < n; ++i) {
@@ -263,6 +267,7 @@ extern "C" int toda_conv3x3_narrow_dgrad(int n, const float* const* dy, const fl
         a.dy[i] = dy[i], a.w[i] = w[i], a.y[i] = dx[i], a.cout[i] = cout[i];
     }
     a.n = n, a.B = batch, a.Cin = cin, a.H = H, a.W = W;
+    a.xbs = dx_image_stride ? (int)dx_image_stride : cin * H * W;
     hipLaunchKernelGGL(narrow_dgrad_kernel, dim3(batch * H, 1, n), dim3(256), 0, (hipStream_t)stream, a);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
@@ -275,8 +280,8 @@ extern "C" size_t toda_conv3x3_narrow_wgrad_workspace_bytes(int n, int batch, in
 
 // out: for branch i in order, dw_i [cout_i][cin][3][3] followed by db_i [cout_i] (sum over i of cout_i * (9 cin + 1) floats)
 extern "C" int toda_conv3x3_narrow_wgrad(int n, const float* const* x, const float* const* dy, const int32_t* cout, int batch, int cin, int H,
-                                         int W, float* out, void* ws, size_t ws_bytes, void* stream) {
-    int rc = narrow_check("conv3x3_narrow_wgrad", n, batch, cin, H, W, cout);
+                                         int W, long long x_image_stride, float* out, void* ws, size_t ws_bytes, void* stream) {
+    int rc = narrow_check("conv3x3_narrow_wgrad", n, batch, cin, H, W, cout, x_image_stride);
     if (rc) return rc;
     TODA_CHECK_ARG(out != nullptr, "conv3x3_narrow_wgrad: null output");
     if (!ws || ws_bytes < toda_conv3x3_narrow_wgrad_workspace_bytes(n, batch, cin, H)) {
@@ -296,6 +301,7 @@ extern "C" int toda_conv3x3_narrow_wgrad(int n, const float* const* x, const flo
         off += cout[i] * (cin * 9 + 1);
     }
     a.n = n, a.B = batch, a.Cin = cin, a.H = H, a.W = W;
+    a.xbs = x_image_stride ? (int)x_image_stride : cin * H * W;
     a.y[0] = nullptr;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(narrow_wgrad_kernel, dim3(cdiv(cin, 4), bands, n), dim3(256), 0, s, a, total);

@@ -71,10 +71,10 @@ SIGNATURES = {
     "toda_conv3x3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_conv3x3_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_conv3x3_narrow_supported": (_i, [_i, _i, _i, _i, _i]),
-    "toda_conv3x3_narrow_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "toda_conv3x3_narrow_dgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "toda_conv3x3_narrow_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, C.c_longlong, _vp, _vp]),
+    "toda_conv3x3_narrow_dgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, C.c_longlong, _vp, _vp]),
     "toda_conv3x3_narrow_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "toda_conv3x3_narrow_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "toda_conv3x3_narrow_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, C.c_longlong, _vp, _vp, _sz, _vp]),
     "toda_timing_begin": (_i, [_i]),
     "toda_timing_end": (_i, [_vp, _i, _vp]),
     "toda_center_assign": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _dbl, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -135,6 +135,11 @@ def stream():
 def host_ptrs(tensors):
     """Host array of device pointers (None -> NULL) for the entry points that take several tensors per call."""
     return (C.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+
+
+def host_addrs(addrs):
+    """Host array of raw device addresses (slices of one tensor)."""
+    return (C.c_void_p * len(addrs))(*[int(a) for a in addrs])
 
 
 def host_i32(vals):

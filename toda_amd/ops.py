@@ -567,8 +567,7 @@ def bn_rows(x, bn, relu, residual=None, sums=None):
     fused with a shortcut addition (y = bn(x) + residual) and the ReLU that follows.  sums: the moments of x when the
     convolution that produced x has already taken them (ops.sparse_conv(..., want_stats=True))."""
     training = bn.training or not bn.track_running_stats
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    bump_bn_counter(bn)
     momentum = 0.0 if bn.momentum is None else bn.momentum
     return _BNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu, residual, sums)
 
@@ -639,8 +638,7 @@ def bn_planes_supported(x, bn):
 
 def bn_planes(x, bn, relu):
     """Apply an nn.BatchNorm2d module (parameters, buffers, train / eval state) to an NCHW tensor, fused with a following ReLU."""
-    if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    bump_bn_counter(bn)
     return _BNPlanes.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, relu)
 
 
@@ -665,6 +663,9 @@ def run_dense_sequential(seq, x):
             x = bn_planes(x, m, relu)
             i += 2 if relu else 1
             continue
+        elif type(m) is torch.nn.BatchNorm2d and x.is_cuda and m.track_running_stats and m.momentum is not None:
+            bump_bn_counter(m)        # nn.BatchNorm2d.forward minus its own counter launch
+            x = torch.nn.functional.batch_norm(x, m.running_mean, m.running_var, m.weight, m.bias, m.training, m.momentum, m.eps)
         else:
             x = m(x)
         i += 1
@@ -781,23 +782,29 @@ def conv3x3_narrow_supported(x, conv):
 
 class _Conv3x3NarrowGroup(torch.autograd.Function):
     """y_i = conv2d(x_i, w_i, b_i, padding 1) for the n branches of a head in one launch per direction.
-    apply(n, x_0..x_{n-1}, w_0.., b_0..) -> (y_0, .., y_{n-1}); biases may be None."""
+    apply(n, fused, x_0..x_{m-1}, w_0.., b_0..) -> (y_0, .., y_{n-1}); biases may be None.  fused = False: m = n separate
+    inputs [B, C, H, W]; fused = True: m = 1, branch i reads channels [i C, (i + 1) C) of one [B, n C, H, W] tensor (and the
+    input gradient is produced as one tensor of that shape)."""
 
     @staticmethod
-    def forward(ctx, n, *args):
+    def forward(ctx, n, fused, *args):
         lib = L.load()
-        xs = [a.contiguous() for a in args[:n]]
-        ws = [a.contiguous() for a in args[n:2 * n]]
-        bs = list(args[2 * n:3 * n])
-        b, cin, h, w = xs[0].shape
+        m = 1 if fused else n
+        xs = [a.contiguous() for a in args[:m]]
+        ws = [a.contiguous() for a in args[m:m + n]]
+        bs = list(args[m + n:m + 2 * n])
+        b, ctot, h, w = xs[0].shape
+        cin = ctot // n if fused else ctot
+        stride = ctot * h * w if fused else 0
+        x_addr = [xs[0].data_ptr() + 4 * i * cin * h * w for i in range(n)] if fused else [L.ptr(x) for x in xs]
         couts = [int(wt.shape[0]) for wt in ws]
         ys = [torch.empty((b, co, h, w), dtype=torch.float32, device=xs[0].device) for co in couts]
         co_host = L.host_i32(couts)
         has_bias = any(t is not None for t in bs)
-        rc = lib.toda_conv3x3_narrow_fwd(n, L.host_ptrs(xs), L.host_ptrs(ws), L.host_ptrs(bs) if has_bias else None, L.hptr(co_host),
-                                         b, cin, h, w, L.host_ptrs(ys), L.stream())
+        rc = lib.toda_conv3x3_narrow_fwd(n, L.host_addrs(x_addr), L.host_ptrs(ws), L.host_ptrs(bs) if has_bias else None, L.hptr(co_host),
+                                         b, cin, h, w, stride, L.host_ptrs(ys), L.stream())
         L.check(rc, "toda_conv3x3_narrow_fwd")
-        ctx.n, ctx.couts, ctx.geom = n, couts, (b, cin, h, w)
+        ctx.n, ctx.m, ctx.couts, ctx.geom = n, m, couts, (b, cin, h, w, stride)
         ctx.has_bias = [t is not None for t in bs]
         ctx.save_for_backward(*xs, *ws)
         return tuple(ys)
@@ -805,23 +812,30 @@ class _Conv3x3NarrowGroup(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gys):
         lib = L.load()
-        n, couts = ctx.n, ctx.couts
-        b, cin, h, w = ctx.geom
-        xs, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        n, m, couts = ctx.n, ctx.m, ctx.couts
+        b, cin, h, w, stride = ctx.geom
+        xs, ws = ctx.saved_tensors[:m], ctx.saved_tensors[m:]
         gys = [g.contiguous() for g in gys]
         dev = gys[0].device
         co_host = L.host_i32(couts)
-        gxs = [None] * n
-        if any(ctx.needs_input_grad[1:1 + n]):
-            gxs = [torch.empty((b, cin, h, w), dtype=torch.float32, device=dev) for _ in range(n)]
-            rc = lib.toda_conv3x3_narrow_dgrad(n, L.host_ptrs(gys), L.host_ptrs(ws), L.hptr(co_host), b, cin, h, w, L.host_ptrs(gxs), L.stream())
+        gxs = [None] * m
+        if any(ctx.needs_input_grad[2:2 + m]):
+            if stride:
+                gxs = [torch.empty((b, n * cin, h, w), dtype=torch.float32, device=dev)]
+                gx_addr = [gxs[0].data_ptr() + 4 * i * cin * h * w for i in range(n)]
+            else:
+                gxs = [torch.empty((b, cin, h, w), dtype=torch.float32, device=dev) for _ in range(n)]
+                gx_addr = [L.ptr(g) for g in gxs]
+            rc = lib.toda_conv3x3_narrow_dgrad(n, L.host_ptrs(gys), L.host_ptrs(ws), L.hptr(co_host), b, cin, h, w, stride, L.host_addrs(gx_addr),
+                                               L.stream())
             L.check(rc, "toda_conv3x3_narrow_dgrad")
+        x_addr = [xs[0].data_ptr() + 4 * i * cin * h * w for i in range(n)] if stride else [L.ptr(x) for x in xs]
         total = sum(co * (cin * 9 + 1) for co in couts)
         out = torch.empty((total,), dtype=torch.float32, device=dev)
         ws_bytes = lib.toda_conv3x3_narrow_wgrad_workspace_bytes(n, b, cin, h)
         wsp = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        rc = lib.toda_conv3x3_narrow_wgrad(n, L.host_ptrs(xs), L.host_ptrs(gys), L.hptr(co_host), b, cin, h, w, L.ptr(out), L.ptr(wsp), ws_bytes,
-                                           L.stream())
+        rc = lib.toda_conv3x3_narrow_wgrad(n, L.host_addrs(x_addr), L.host_ptrs(gys), L.hptr(co_host), b, cin, h, w, stride, L.ptr(out), L.ptr(wsp),
+                                           ws_bytes, L.stream())
         L.check(rc, "toda_conv3x3_narrow_wgrad")
         gws, gbs, off = [], [], 0
         for co, hb in zip(couts, ctx.has_bias):
@@ -829,13 +843,110 @@ class _Conv3x3NarrowGroup(torch.autograd.Function):
             off += co * cin * 9
             gbs.append(out[off:off + co] if hb else None)
             off += co
-        return (None, *gxs, *gws, *gbs)
+        return (None, None, *gxs, *gws, *gbs)
 
 
 def conv3x3_narrow_group(xs, convs):
     """The final nn.Conv2d of several head branches (same input geometry) in one launch; returns the list of outputs."""
     n = len(xs)
-    return list(_Conv3x3NarrowGroup.apply(n, *xs, *[c.weight for c in convs], *[c.bias for c in convs]))
+    return list(_Conv3x3NarrowGroup.apply(n, False, *xs, *[c.weight for c in convs], *[c.bias for c in convs]))
+
+
+def conv3x3_narrow_group_fused(x, convs):
+    """Same, the branch inputs being the len(convs) equal channel slices of x [B, n C, H, W] (no slice copies)."""
+    n = len(convs)
+    return list(_Conv3x3NarrowGroup.apply(n, True, x, *[c.weight for c in convs], *[c.bias for c in convs]))
+
+
+# ------------------------------------------------- BatchNorm2d modules of parallel branches as one normalisation
+_BN_COUNTERS = []
+_BN_DEFER = [0]
+
+
+class bn_counter_scope:
+    """Inside the scope (a detector's forward) the `num_batches_tracked += 1` of every BatchNorm the hand-written paths
+    apply is collected and issued as ONE foreach launch on exit instead of one 4-us kernel per layer (53 per C3 step)."""
+
+    def __enter__(self):
+        _BN_DEFER[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _BN_DEFER[0] -= 1
+        if _BN_DEFER[0] == 0 and _BN_COUNTERS:
+            pending = list(_BN_COUNTERS)
+            _BN_COUNTERS.clear()
+            torch._foreach_add_(pending, 1)
+        return False
+
+
+def bump_bn_counter(bn):
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        if _BN_DEFER[0] and bn.num_batches_tracked.is_cuda:
+            _BN_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+
+
+def _aliased_running_stats(owner, bns):
+    """running_mean / running_var of the n BatchNorm2d modules as consecutive slices of two [n C] tensors, so that one
+    batch_norm call updates all of them in place.  The modules keep their buffers (same names, same values, state_dict
+    unchanged); the aliasing is re-established whenever something (module.to(), a fresh load) has replaced a buffer."""
+    c = bns[0].num_features
+    cache = getattr(owner, "_fused_bn_stats", None)
+    ok = cache is not None and cache[0].device == bns[0].running_mean.device
+    if ok:
+        for i, bn in enumerate(bns):
+            if bn.running_mean.data_ptr() != cache[0].data_ptr() + 4 * c * i or bn.running_var.data_ptr() != cache[1].data_ptr() + 4 * c * i:
+                ok = False
+                break
+    if not ok:
+        with torch.no_grad():
+            rm = torch.cat([bn.running_mean for bn in bns])
+            rv = torch.cat([bn.running_var for bn in bns])
+            for i, bn in enumerate(bns):
+                bn.running_mean = rm[i * c:(i + 1) * c]
+                bn.running_var = rv[i * c:(i + 1) * c]
+        cache = (rm, rv)
+        object.__setattr__(owner, "_fused_bn_stats", cache)
+    return cache
+
+
+def fused_branch_hidden_supported(x, blocks):
+    """blocks: the first layers Sequential(Conv2d(C, C, 3, padding 1), BatchNorm2d(C), ReLU) of n parallel branches on x."""
+    if len(blocks) < 2 or not x.is_cuda:
+        return False
+    c = x.shape[1]
+    ref_bn = blocks[0][1] if len(blocks[0]) == 3 else None
+    for blk in blocks:
+        if type(blk) is not torch.nn.Sequential or len(blk) != 3:
+            return False
+        conv, bn, act = blk[0], blk[1], blk[2]
+        if type(conv) is not torch.nn.Conv2d or type(bn) is not torch.nn.BatchNorm2d or type(act) is not torch.nn.ReLU:
+            return False
+        if conv.out_channels != c or conv.padding != (1, 1) or (conv.bias is None) != (blocks[0][0].bias is None) or not conv3x3_supported(x, conv):
+            return False
+        if (not bn.affine or not bn.track_running_stats or bn.momentum is None or bn.momentum != ref_bn.momentum or bn.eps != ref_bn.eps
+                or bn.training != ref_bn.training or bn.num_features != c):
+            return False
+    return bool(L.load().toda_conv3x3_supported(x.shape[0], c, c * len(blocks), x.shape[2], x.shape[3]))
+
+
+def fused_branch_hidden(owner, x, blocks):
+    """ReLU(BN_i(conv_i(x))) of n parallel branches as ONE C -> n C convolution, ONE batch norm over the n C channels and
+    one ReLU (reference center_head.py:20-26 runs them branch by branch).  Per-channel batch statistics make the wide norm
+    equal to the n narrow ones; the backward of the wide convolution sums the branches' input gradients inside its GEMM.
+    Returns [B, n C, H, W]; branch i owns channels [i C, (i + 1) C)."""
+    convs, bns = [blk[0] for blk in blocks], [blk[1] for blk in blocks]
+    w = torch.cat([cv.weight for cv in convs], 0)
+    bias = torch.cat([cv.bias for cv in convs]) if convs[0].bias is not None else None
+    y = conv3x3(x, w, bias)
+    rm, rv = _aliased_running_stats(owner, bns)
+    for bn in bns:
+        bump_bn_counter(bn)
+    y = torch.nn.functional.batch_norm(y, rm, rv, torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns]),
+                                       bns[0].training, bns[0].momentum, bns[0].eps)
+    return torch.relu_(y)
 
 
 # --------------------------------------------------------------- CenterHead target assign

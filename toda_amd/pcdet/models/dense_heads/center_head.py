@@ -45,6 +45,11 @@ class SeparateHead(nn.Module):
         # every branch ends in Conv2d(C, out_channels <= 4, 3, padding=1): the hidden layers run branch by branch, the five
         # output convolutions (and their backward) as ONE launch per direction (toda_conv3x3_narrow_*)
         if len(names) <= 8 and all(len(br) >= 1 and ops.conv3x3_narrow_supported(x, conv) for br, conv in zip(branches, last)):
+            # num_conv == 2 everywhere (every reference config): the n hidden Conv-BN-ReLU layers read the same x -> one
+            # C -> n C convolution + one norm; the output convolutions then read their channel slice of that tensor in place
+            if all(len(br) == 2 for br in branches) and ops.fused_branch_hidden_supported(x, [br[0] for br in branches]):
+                wide = ops.fused_branch_hidden(self, x, [br[0] for br in branches])
+                return dict(zip(names, ops.conv3x3_narrow_group_fused(wide, last)))
             hidden = [ops.run_dense_sequential(br[:-1], x) if len(br) > 1 else x for br in branches]
             if all(h.shape == hidden[0].shape for h in hidden):
                 return dict(zip(names, ops.conv3x3_narrow_group(hidden, last)))

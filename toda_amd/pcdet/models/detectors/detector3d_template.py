@@ -31,6 +31,12 @@ class Detector3DTemplate(nn.Module):
     def update_global_step(self):
         self.global_step += 1
 
+    def __call__(self, *args, **kwargs):
+        # the BatchNorm step counters of one forward are bumped by a single foreach launch (ops.bn_counter_scope)
+        from .... import ops
+        with ops.bn_counter_scope():
+            return super().__call__(*args, **kwargs)
+
     def build_networks(self):
         enc = self.dataset.point_feature_encoder
         info = {

@@ -3,7 +3,8 @@ libtoda_hip.so that a training step calls is bracketed by HIP events on the curr
 bytes / FLOPs (formulas of SURVEY.md §8 d and DESIGN.md §3), so each row carries GB/s against the 8 TB/s HBM roof and / or
 TFLOP/s against the 157.3 TFLOP/s fp32 matrix roof and the fraction of the binding one.
 
-Event brackets include the launch overhead of the call (a few microseconds), so rows of kernels shorter than ~20 us read
+Event brackets include the launch overhead of the call (a few microseconds) and whatever idle time the host left between
+the first event and the launch, so `ms` is the MEDIAN over the calls of a shape and rows of kernels shorter than ~20 us read
 low; the rocprofv3 kernel trace in profiles/ has the dispatch-stamped durations of the same kernels."""
 import collections
 
@@ -185,7 +186,7 @@ class OpTable:
         out = []
         for key, evs in self.events.items():
             ms = [a.elapsed_time(b) for a, b in evs]
-            mean = sum(ms) / len(ms)
+            mean = sorted(ms)[len(ms) // 2]      # median: a bracket also holds any idle time the host left in front of the launch
             cost = self.cost[key]
             note = ""
             if cost[0] == "pairs":

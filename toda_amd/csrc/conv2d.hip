@@ -211,6 +211,34 @@ __device__ __forceinline__ void wn_load_patch(__amdgpu_buffer_rsrc_t rsrc, const
     }
 }
 
+// The same patch as it leaves the loads: nothing here touches the loaded registers, so the compiler has no reason to wait for
+// them at the point of issue (wn_load_patch's DPP / select post-processing forces an s_waitcnt right behind the loads: zero
+// look-ahead).  wn_finish_patch does that post-processing when the patch is transformed, two chunks later.
+struct PatchRaw {
+    f32x4 c[6];
+    float e[6];
+    bool left, right, tail;
+};
+
+__device__ __forceinline__ void wn_load_raw(__amdgpu_buffer_rsrc_t rsrc, const PatchOff& o, unsigned soff, PatchRaw& d) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        d.c[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.offc[r], soff, 0));
+        d.e[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, o.offe[r], soff, 0));
+    }
+    d.left = o.left, d.right = o.right, d.tail = o.tail;
+}
+
+__device__ __forceinline__ void wn_finish_patch(const PatchRaw& s, Patch& d) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const float l = wn_dpp_from_prev(s.e[r], s.c[r][3]), rr = wn_dpp_from_next(s.e[r], s.c[r][0]);
+        d.p[r] = f32x2{s.c[r][0], s.c[r][1]};
+        d.q[r] = f32x2{s.tail ? 0.0f : s.c[r][2], s.tail ? 0.0f : s.c[r][3]};
+        d.e[r] = f32x2{s.left ? l : 0.0f, s.right ? rr : 0.0f};
+    }
+}
+
 __device__ __forceinline__ f32x2 wn_fma2(float c, f32x2 a, f32x2 b) {
     return __builtin_elementwise_fma(f32x2{c, c}, a, b);
 }
@@ -455,7 +483,9 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
     const int rng = w / gsz, member = w - rng * gsz;
     const long long S = (long long)(gang ? g.n_tile_blocks : n_units) * g.n_chunks;
     const long long lo = ws_range_lo(rng, G, S), hi = ws_range_lo(rng + 1, G, S);
-    const int total = (int)(hi - lo);               // chunks this workgroup multiplies = barriers every wave passes
+    // (64-bit division runs on the vector ALU: hand the wave-uniform results back to scalar registers, or every use as a
+    // scalar operand - the loads' soffset - becomes a waterfall loop)
+    const int total = __builtin_amdgcn_readfirstlane((int)(hi - lo));   // chunks this workgroup multiplies = barriers every wave passes
     if (total == 0) return;
     auto tb_of = [&](int useq) { return gang ? useq : useq / g.n_cout_blocks; };
     auto cb_of = [&](int useq) { return gang ? member : useq % g.n_cout_blocks; };
@@ -552,33 +582,68 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
         const int pt = tid - 256;
         const int t_t = pt & 15, t_c = (pt >> 4) & 7, t_grp = pt >> 7;
         const int a_off = t_grp * 128 + ((t_c >> 1) * 16 + wn_row_of_tile(t_t)) * 2 + (t_c & 1);
-        const __amdgpu_buffer_rsrc_t xr = wn_rsrc(x, (unsigned)((size_t)g.B * g.Cin * g.H * g.W * 4u));
         const unsigned chunk_bytes = (unsigned)(WN_KC * g.H * g.W) * 4u;
-        const int pwave = wave - 4;
 
         auto patch_of = [&](int unit) {
             const int tb = tb_of(unit);
             return wn_patch_off(tb * WN_TILES + t_grp * 16 + t_t, t_t, t_c, g.Cin, g);
         };
-        auto produce = [&](const Patch& d, int unit, int chunk, int buf) {
-            const int cb = cb_of(unit);
-            const float* usrc = u + ((size_t)cb * g.n_chunks + chunk) * IMG + pt * 4;
-            float* const bdst = lds + (2 + buf) * IMG + pwave * 256;
-            if (!(ablate & 2)) {
+        // Everything a chunk needs from global memory (its 6x6 patch and the thread's 9 x 16 bytes of the transformed filters)
+        // is LOADED TWO CHUNKS AHEAD into registers and only touched when the chunk is produced; the barrier of a producer is
+        // "my LDS writes are done" (lgkmcnt) - it never waits for loads in flight.  Measured (128 -> 128 @ 188^2, 105 us): this
+        // removes the forced waits the ISA showed (a patch post-processed at issue, a vmcnt(0) in front of every barrier) but not
+        // the time - the loads cost ~10 us each (patches, filters) whether they get one period of cover or two, i.e. memory-path
+        // throughput, not latency; the filters by LDS-DMA issued first in the period measure the same.  What does not overlap
+        // at all is the transform's vector-ALU work: fp32 MFMA and packed fp32 VALU share one datapath on this part (equal
+        // vendor peaks, 157.3 TFLOP/s), so the ~180 VALU instructions per chunk and producer wave ADD ~0.3 us to every chunk's 1.0
+        // us of MFMAs (ablation: arithmetic without stores +10.7 us, stores without arithmetic +2.7 us).
+        constexpr int B_IT = IMG / 1024;
+        struct Stage {
+            PatchRaw d;
+            f32x4 b[B_IT];
+        };
+        auto produce = [&](const Stage& st, int buf) {
+            float* const bdst = lds + (2 + buf) * IMG + pt * 4;
 #pragma unroll
-                for (int it = 0; it < IMG / 1024; ++it) __builtin_amdgcn_global_load_lds(usrc + it * 1024, bdst + it * 1024, 16, 0, 0);
-            }
-            if (!(ablate & 4)) wn_input_transform_store(d, lds + buf * IMG + a_off);
+            for (int it = 0; it < B_IT; ++it) *reinterpret_cast<f32x4*>(bdst + it * 1024) = st.b[it];
+            Patch d;
+            wn_finish_patch(st.d, d);
+            if (ablate & 64) {             // 36 LDS stores, no transform arithmetic
+                float* const dst = lds + buf * IMG + a_off;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    dst[(i * 6 + 0) * WN_IMG] = d.e[i][0];
+                    dst[(i * 6 + 1) * WN_IMG] = d.p[i][0];
+                    dst[(i * 6 + 2) * WN_IMG] = d.p[i][1];
+                    dst[(i * 6 + 3) * WN_IMG] = d.q[i][0];
+                    dst[(i * 6 + 4) * WN_IMG] = d.q[i][1];
+                    dst[(i * 6 + 5) * WN_IMG] = d.e[i][1];
+                }
+            } else if (!(ablate & 4)) wn_input_transform_store(d, lds + buf * IMG + a_off);
             else lds[buf * IMG + a_off] = d.p[0][0] + d.e[5][1] + d.q[2][0];
         };
 
         // chunk stream of this workgroup: step lo + q -> (unit, chunk); units are consecutive
-        const int unit0 = (int)(lo / g.n_chunks), chunk0 = (int)(lo - (long long)unit0 * g.n_chunks);
+        const int unit0 = __builtin_amdgcn_readfirstlane((int)(lo / g.n_chunks));
+        const int chunk0 = __builtin_amdgcn_readfirstlane((int)(lo - (long long)unit0 * g.n_chunks));
         WinoCursor ld{unit0, chunk0};       // next chunk to fetch
         PatchOff pa = patch_of(unit0);
-        auto fetch = [&](Patch& d, int q_fetch) {
-            if (q_fetch < total) {
-                if (!(ablate & 1)) wn_load_patch(xr, pa, (unsigned)ld.chunk * chunk_bytes, d);
+        const unsigned x_bytes = (unsigned)((size_t)g.B * g.Cin * g.H * g.W * 4u), u_bytes = (unsigned)((size_t)WN_FREQ * g.Cin * g.Cout * 4u);
+        const unsigned u_voff = (unsigned)pt * 16u;
+        auto fetch = [&](Stage& st, int q_fetch) {
+            // ALWAYS the same 21 loads, past the end of the range against an empty descriptor (hardware zeros, no memory access):
+            // the compiler's vmcnt bookkeeping is then the same on every path, and a wait for the previous period's registers
+            // never has to cover "or the fetch was skipped" by draining the loads just issued.  No vector-ALU work between the
+            // loads: per-thread offsets are fixed registers, the chunk moves the scalar offset.
+            const bool live = q_fetch < total;
+            const __amdgpu_buffer_rsrc_t xr_q = wn_rsrc(x, live && !(ablate & 1) ? x_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t ur_q = wn_rsrc(u, live && !(ablate & 2) ? u_bytes : 0u);
+            wn_load_raw(xr_q, pa, (unsigned)ld.chunk * chunk_bytes, st.d);
+            const unsigned u_soff = (unsigned)((cb_of(ld.unit) * g.n_chunks + ld.chunk) * IMG) * 4u;
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it)
+                st.b[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur_q, u_voff, u_soff + (unsigned)it * 4096u, 0));
+            if (live) {
                 if (++ld.chunk == g.n_chunks) {
                     ld.chunk = 0;
                     ld.unit += 1;
@@ -586,30 +651,23 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
                 }
             }
         };
-        WinoCursor pr{unit0, chunk0};       // next chunk to transform
-        auto step = [&](const Patch& d, int q_prod) {
-            produce(d, pr.unit, pr.chunk, q_prod & 1);
-            if (++pr.chunk == g.n_chunks) {
-                pr.chunk = 0;
-                pr.unit += 1;
-            }
-        };
-        Patch d0, d1;
-        fetch(d0, 0);
-        fetch(d1, 1);
-        step(d0, 0);                    // chunk 0 -> images 0
-        // loop body unrolled by two so that the patch registers alternate without copies
+        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        Stage s0, s1;
+        fetch(s0, 0);
+        fetch(s1, 1);
+        produce(s0, 0);                 // chunk 0 -> images 0
+        // loop body unrolled by two so that the stage registers alternate without copies
         int q = 0;
         while (true) {
-            __syncthreads();            // barrier q
+            barrier();                  // barrier q
             if (q + 1 >= total) break;
-            fetch(d0, q + 2);
-            step(d1, q + 1);
+            fetch(s0, q + 2);
+            produce(s1, (q + 1) & 1);
             ++q;
-            __syncthreads();            // barrier q
+            barrier();                  // barrier q
             if (q + 1 >= total) break;
-            fetch(d1, q + 2);
-            step(d0, q + 1);
+            fetch(s1, q + 2);
+            produce(s0, (q + 1) & 1);
             ++q;
         }
     }

@@ -333,6 +333,31 @@ int toda_conv3x3_fwd(const float* x, const float* u, const float* bias, int batc
                      int W, float* y, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * CenterHead.get_loss of one head group, value and gradient (pcdet/models/dense_heads/center_head.py:229-262:
+ * sigmoid + clamp(1e-4, 1 - 1e-4) of the heat-map logits; pcdet/utils/loss_utils.py:264-297 neg_loss_cornernet /
+ * FocalLossCenterNet; :300-385 _gather_feat, _transpose_and_gather_feat, _reg_loss / RegLossCenterNet; the
+ * code_weights / loc_weight / cls_weight products of center_head.py:250-257).
+ *   hm_logits, heatmap [B][classes][H][W]; reg_maps_host[] = n_branch device pointers [B][c_j][H][W] in HEAD_ORDER
+ *   (sum c_j = code_size <= 16); inds, mask [B][max_objs] int64; target_boxes [B][max_objs][code_size];
+ *   code_weights: HOST array.
+ *   _fwd  hm_prob = clamped sigmoid; out4 = {hm_loss * cls_weight, loc_loss * loc_weight, 1 / max(num_pos, 1),
+ *         1 / max(num_objs, 1)} (device); ws keeps what _bwd needs (the same ws must be passed on)
+ *   _bwd  up_hm / up_loc: device scalars dL/d(out4[0]), dL/d(out4[1]); hm_grad [B][classes][H][W];
+ *         reg_grads_host[]: gradient maps of the branches (zero-filled here, then scattered into)
+ * Sums are folded in a fixed order (fp64 partials): no atomics, bitwise reproducible.
+ * ---------------------------------------------------------------------- */
+size_t toda_center_loss_workspace_bytes(int batch, int classes, int H, int W, int max_objs, int code_size);
+int toda_center_loss_fwd(const float* hm_logits, const float* heatmap, int batch, int classes, int H, int W, int n_branch,
+                         const float* const* reg_maps_host, const int32_t* reg_channels_host, const int64_t* inds,
+                         const int64_t* mask, const float* target_boxes, int max_objs, int code_size,
+                         const float* code_weights_host, float cls_weight, float loc_weight, float* hm_prob, float* out4,
+                         void* ws, size_t ws_bytes, void* stream);
+int toda_center_loss_bwd(const float* out4, const float* up_hm, const float* up_loc, int batch, int classes, int H, int W,
+                         int n_branch, float* const* reg_grads_host, const int32_t* reg_channels_host, const int64_t* inds,
+                         int max_objs, int code_size, const float* code_weights_host, float cls_weight, float loc_weight,
+                         float* hm_grad, const void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolutions with 1..4 OUTPUT channels: the last layer of every CenterHead branch
  * (pcdet/models/dense_heads/center_head.py:20-28: Conv2d(64, out_channels, 3, padding=1, bias=True) of center /
  * center_z / dim / rot / hm), forward and autograd backward.  All n <= 8 branches of a head go through ONE launch

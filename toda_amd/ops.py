@@ -970,6 +970,69 @@ def center_assign(gt_boxes, num_classes, fm_w, fm_h, pc_range, voxel_size, fm_st
     return hm, rb, inds, mask
 
 
+class _CenterLoss(torch.autograd.Function):
+    """CenterHead.get_loss of one head group in three launches forward / one backward (toda_center_loss_*).
+    apply(n, hm_logits, reg_0..reg_{n-1}, heatmap, inds, mask, target_boxes, code_weights, cls_weight, loc_weight)
+    -> (hm_loss, loc_loss, clamped sigmoid); the first two are 0-d tensors carrying the graph."""
+
+    @staticmethod
+    def forward(ctx, n, hm, *args):
+        lib = L.load()
+        regs = [a.contiguous() for a in args[:n]]
+        heatmap, inds, mask, target, code_w, cls_w, loc_w = args[n:]
+        hm = hm.contiguous()
+        b, c, h, w = hm.shape
+        k, d = target.shape[1], target.shape[2]
+        chans = [int(r.shape[1]) for r in regs]
+        dev = hm.device
+        ws_bytes = lib.toda_center_loss_workspace_bytes(b, c, h, w, k, d)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        prob = torch.empty_like(hm)
+        out4 = torch.empty((4,), dtype=torch.float32, device=dev)
+        inds, mask = inds.contiguous(), mask.contiguous()
+        cw = L.host_f32(code_w)
+        rc = lib.toda_center_loss_fwd(L.ptr(hm), L.ptr(heatmap.contiguous()), b, c, h, w, n, L.host_ptrs(regs), L.hptr(L.host_i32(chans)),
+                                      L.ptr(inds), L.ptr(mask), L.ptr(target.contiguous().float()), k, d, L.hptr(cw), float(cls_w), float(loc_w),
+                                      L.ptr(prob), L.ptr(out4), L.ptr(ws), ws_bytes, L.stream())
+        L.check(rc, "toda_center_loss_fwd")
+        ctx.save_for_backward(out4, ws, inds)
+        ctx.meta = (n, b, c, h, w, k, d, chans, [float(v) for v in code_w], float(cls_w), float(loc_w))
+        ctx.mark_non_differentiable(prob)
+        return out4[0], out4[1], prob
+
+    @staticmethod
+    def backward(ctx, g_hm, g_loc, _g_prob):
+        lib = L.load()
+        out4, ws, inds = ctx.saved_tensors
+        n, b, c, h, w, k, d, chans, code_w, cls_w, loc_w = ctx.meta
+        dev = out4.device
+        g_hm = g_hm.contiguous() if g_hm is not None else torch.zeros((), device=dev)
+        g_loc = g_loc.contiguous() if g_loc is not None else torch.zeros((), device=dev)
+        dz = torch.empty((b, c, h, w), dtype=torch.float32, device=dev)
+        flat = torch.empty((b * d * h * w,), dtype=torch.float32, device=dev)      # the branch gradients, back to back: one zero fill
+        grads, off = [], 0
+        for ch in chans:
+            grads.append(flat[off:off + b * ch * h * w].view(b, ch, h, w))
+            off += b * ch * h * w
+        cw = L.host_f32(code_w)
+        rc = lib.toda_center_loss_bwd(L.ptr(out4), L.ptr(g_hm), L.ptr(g_loc), b, c, h, w, n, L.host_ptrs(grads), L.hptr(L.host_i32(chans)),
+                                      L.ptr(inds), k, d, L.hptr(cw), cls_w, loc_w, L.ptr(dz), L.ptr(ws), ws.numel(), L.stream())
+        L.check(rc, "toda_center_loss_bwd")
+        return (None, dz, *grads, None, None, None, None, None, None, None)
+
+
+def center_loss(hm_logits, regs, heatmap, inds, mask, target_boxes, code_weights, cls_weight, loc_weight):
+    """(hm_loss * cls_weight, loc_loss * loc_weight, clamp(sigmoid(hm_logits), 1e-4, 1 - 1e-4)) of one CenterHead group;
+    regs: the regression maps in HEAD_ORDER."""
+    return _CenterLoss.apply(len(regs), hm_logits, *regs, heatmap, inds, mask, target_boxes, list(code_weights), cls_weight, loc_weight)
+
+
+def center_loss_supported(hm_logits, regs, target_boxes):
+    return (hm_logits.is_cuda and hm_logits.dtype == torch.float32 and 1 <= len(regs) <= 8 and target_boxes.shape[2] <= 16
+            and all(r.dtype == torch.float32 and r.shape[0] == hm_logits.shape[0] and r.shape[2:] == hm_logits.shape[2:] for r in regs)
+            and sum(int(r.shape[1]) for r in regs) == target_boxes.shape[2] and _os.environ.get("TODA_FUSED_LOSS", "1") == "1")
+
+
 # ------------------------------------------------------------------ rotated IoU / NMS (eval path)
 def boxes_iou_bev(boxes_a, boxes_b):
     a, b = boxes_a[:, :7].contiguous().float(), boxes_b[:, :7].contiguous().float()

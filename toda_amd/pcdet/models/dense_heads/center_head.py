@@ -133,6 +133,17 @@ class CenterHead(nn.Module):
         weights = self.model_cfg.LOSS_CONFIG.LOSS_WEIGHTS
         tb_dict, loss = {}, 0
         for idx, pred in enumerate(pred_dicts):
+            regs = [pred[name] for name in self.separate_head_cfg.HEAD_ORDER]
+            if ops.center_loss_supported(pred["hm"], regs, target_dicts["target_boxes"][idx]):
+                # sigmoid-clamp + focal + gathered L1, value and gradient, in 3 + 1 launches (torch: ~110 small ones)
+                hm_loss, loc_loss, prob = ops.center_loss(pred["hm"], regs, target_dicts["heatmaps"][idx], target_dicts["inds"][idx],
+                                                          target_dicts["masks"][idx], target_dicts["target_boxes"][idx],
+                                                          weights["code_weights"], weights["cls_weight"], weights["loc_weight"])
+                pred["hm"] = prob
+                loss = loss + hm_loss + loc_loss
+                tb_dict[f"hm_loss_head_{idx}"] = hm_loss.detach()
+                tb_dict[f"loc_loss_head_{idx}"] = loc_loss.detach()
+                continue
             pred["hm"] = self.sigmoid(pred["hm"])
             hm_loss = self.hm_loss_func(pred["hm"], target_dicts["heatmaps"][idx]) * weights["cls_weight"]
             pred_boxes = torch.cat([pred[name] for name in self.separate_head_cfg.HEAD_ORDER], dim=1)

@@ -183,7 +183,7 @@ def run_gpu(args, rank, world, device):
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), dataset).to(device)
     model.train()
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
-    total_steps = max(args.steps + args.warmup, 10) + 16      # + the untimed steps of --layers / the comm report
+    total_steps = max(args.steps + args.warmup, 10) + 32      # + the untimed steps of --layers / the comm report
     scheduler, _ = build_scheduler(optimizer, total_steps, 1, -1, cfg.OPTIMIZATION)
     net = model
     if pair:
@@ -315,6 +315,18 @@ def run_gpu(args, rank, world, device):
         table.enabled = False
         op_rows = table.rows(extra)
         table.restore()
+    if os.environ.get("TODA_CPROFILE") and rank == 0:
+        # host-side cost per Python function over 10 extra steps (the step is close to host-bound: CPU ms / step is in the line)
+        import cProfile
+        import pstats
+        prof = cProfile.Profile()
+        prof.enable()
+        for it in range(args.warmup + args.steps + 5, args.warmup + args.steps + 15):
+            step(it)
+        torch.cuda.synchronize()
+        prof.disable()
+        with open(os.environ["TODA_CPROFILE"], "w") as f:
+            pstats.Stats(prof, stream=f).sort_stats("tottime").print_stats(60)
     if os.environ.get("TODA_TORCH_PROFILE") and rank == 0:
         # which Python line launches which small kernel: two extra steps under torch.profiler, grouped by call stack
         from torch.profiler import ProfilerActivity, profile

@@ -354,7 +354,7 @@ int toda_center_loss_fwd(const float* hm_logits, const float* heatmap, int batch
                          void* ws, size_t ws_bytes, void* stream);
 int toda_center_loss_bwd(const float* out4, const float* up_hm, const float* up_loc, int batch, int classes, int H, int W,
                          int n_branch, float* const* reg_grads_host, const int32_t* reg_channels_host, const int64_t* inds,
-                         int max_objs, int code_size, const float* code_weights_host, float cls_weight, float loc_weight,
+                         const int64_t* mask, int max_objs, int code_size, const float* code_weights_host, float cls_weight, float loc_weight,
                          float* hm_grad, const void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -114,37 +114,48 @@ struct CenterLossWeights {
     float cls_weight, loc_weight;
 };
 
-// out[0] = hm_loss, out[1] = loc_loss, out[2] = 1 / max(num_pos, 1), out[3] = 1 / max(num_obj, 1)
-__global__ void center_loss_final_kernel(const double* __restrict__ partials, int n_blocks, const double* __restrict__ reg_part, int B, int D,
-                                         const CenterLossWeights w, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// out[0] = hm_loss, out[1] = loc_loss, out[2] = 1 / max(num_pos, 1), out[3] = 1 / max(num_obj, 1).  One wave: lane l adds
+// partials l, l + 64, ... in that order, then a fixed butterfly.
+__device__ __forceinline__ double cl_wave_sum(double v) {
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(64)
+center_loss_final_kernel(const double* __restrict__ partials, int n_blocks, const double* __restrict__ reg_part, int B, int D,
+                         const CenterLossWeights w, float* __restrict__ out) {
+    const int lane = threadIdx.x;
     double pos = 0.0, neg = 0.0, cnt = 0.0;
-    for (int i = 0; i < n_blocks; ++i) {
+    for (int i = lane; i < n_blocks; i += 64) {
         pos += partials[3 * i + 0];
         neg += partials[3 * i + 1];
         cnt += partials[3 * i + 2];
     }
-    const double np = cnt > 1.0 ? cnt : 1.0;
-    out[0] = (float)(-(pos + neg) / np * (double)w.cls_weight);
-    out[2] = (float)(1.0 / np);
-    double num = 0.0;
-    for (int b = 0; b < B; ++b) num += reg_part[(size_t)b * (CL_MAX_DIM + 1) + CL_MAX_DIM];
+    pos = cl_wave_sum(pos), neg = cl_wave_sum(neg), cnt = cl_wave_sum(cnt);
+    // lane d < D: code dimension d; lane 63: the object count
+    double mine = 0.0;
+    const int col = lane == 63 ? CL_MAX_DIM : lane;
+    if (lane < D || lane == 63)
+        for (int b = 0; b < B; ++b) mine += reg_part[(size_t)b * (CL_MAX_DIM + 1) + col];
+    const double num = __shfl(mine, 63, 64);
     const double nn = num > 1.0 ? num : 1.0;
+    double term = lane < D ? (double)(float)(mine / nn) * (double)w.code[lane < CL_MAX_DIM ? lane : 0] : 0.0;
     double loc = 0.0;
-    for (int d = 0; d < D; ++d) {
-        double s = 0.0;
-        for (int b = 0; b < B; ++b) s += reg_part[(size_t)b * (CL_MAX_DIM + 1) + d];
-        loc += (double)(float)(s / nn) * (double)w.code[d];
+    for (int d = 0; d < D; ++d) loc += __shfl(term, d, 64);       // in code order
+    if (lane == 0) {
+        const double np = cnt > 1.0 ? cnt : 1.0;
+        out[0] = (float)(-(pos + neg) / np * (double)w.cls_weight);
+        out[1] = (float)(loc * (double)w.loc_weight);
+        out[2] = (float)(1.0 / np);
+        out[3] = (float)(1.0 / nn);
     }
-    out[1] = (float)(loc * (double)w.loc_weight);
-    out[3] = (float)(1.0 / nn);
 }
 
-// blocks [0, hm_blocks): dz = g * (-cls_weight * out[2] * up[0]).  blocks [hm_blocks, ..): one (b, k) slot per thread.
+// blocks [0, hm_blocks): dz = g * (-cls_weight * out[2] * up[0]).  blocks [hm_blocks, hm_blocks + B): the slots of one sample.
 __global__ void __launch_bounds__(CL_BLOCK)
 center_loss_bwd_kernel(const float* __restrict__ g, long long n, int hm_blocks, const float* __restrict__ out, const float* __restrict__ up_hm,
                        const float* __restrict__ up_loc, const CenterLossWeights w, const CenterLossMaps grads, const long long* __restrict__ inds,
-                       const float* __restrict__ sgn, int B, int K, int D, int hw, float* __restrict__ dz) {
+                       const long long* __restrict__ mask, const float* __restrict__ sgn, int B, int K, int D, int hw, float* __restrict__ dz) {
     if ((int)blockIdx.x < hm_blocks) {
         const float scale = -w.cls_weight * out[2] * up_hm[0];
         const long long base = (long long)blockIdx.x * (CL_BLOCK * CL_ITEMS) + threadIdx.x;
@@ -155,27 +166,33 @@ center_loss_bwd_kernel(const float* __restrict__ g, long long n, int hm_blocks, 
         }
         return;
     }
-    const long long slot = (long long)(blockIdx.x - hm_blocks) * CL_BLOCK + threadIdx.x;
-    if (slot >= (long long)B * K) return;
-    const int b = (int)(slot / K), k = (int)(slot - (long long)b * K);
-    const long long cell = inds[slot];
+    // one block per sample: the K cell indices in LDS, then every slot looks for an earlier slot on the same cell (owner = first)
+    extern __shared__ int cells[];
+    const int b = blockIdx.x - hm_blocks;
     const long long* row = inds + (long long)b * K;
-    for (int k2 = 0; k2 < k; ++k2)
-        if (row[k2] == cell) return;                     // an earlier slot owns this cell
+    for (int k = threadIdx.x; k < K; k += CL_BLOCK) cells[k] = mask[(long long)b * K + k] != 0 ? (int)row[k] : -1;   // empty slots: zero gradient
+    __syncthreads();
     const float scale = w.loc_weight * out[3] * up_loc[0];
-    float acc[CL_MAX_DIM];
+    for (int k = threadIdx.x; k < K; k += CL_BLOCK) {
+        const int cell = cells[k];
+        if (cell < 0) continue;
+        bool owner = true;
+        for (int k2 = 0; k2 < k; ++k2) owner = owner && cells[k2] != cell;
+        if (!owner) continue;
+        float acc[CL_MAX_DIM];
 #pragma unroll
-    for (int d = 0; d < CL_MAX_DIM; ++d) acc[d] = 0.0f;
-    for (int k2 = k; k2 < K; ++k2) {
-        if (row[k2] != cell) continue;
-        const float* s = sgn + ((long long)b * K + k2) * D;
+        for (int d = 0; d < CL_MAX_DIM; ++d) acc[d] = 0.0f;
+        for (int k2 = k; k2 < K; ++k2) {
+            if (cells[k2] != cell) continue;
+            const float* sg = sgn + ((long long)b * K + k2) * D;
+#pragma unroll
+            for (int d = 0; d < CL_MAX_DIM; ++d)
+                if (d < D) acc[d] += sg[d] * (w.code[d] * scale);
+        }
 #pragma unroll
         for (int d = 0; d < CL_MAX_DIM; ++d)
-            if (d < D) acc[d] += s[d] * (w.code[d] * scale);
+            if (d < D) grads.chan[d][(size_t)b * grads.sample_stride[d] + cell] = acc[d];
     }
-#pragma unroll
-    for (int d = 0; d < CL_MAX_DIM; ++d)
-        if (d < D) grads.chan[d][(size_t)b * grads.sample_stride[d] + cell] = acc[d];
 }
 
 static int cl_check(const char* who, int n_branch, const int32_t* ch, int batch, int classes, int H, int W, int K, int D) {
@@ -186,7 +203,8 @@ static int cl_check(const char* who, int n_branch, const int32_t* ch, int batch,
         sum += ch[j];
     }
     TODA_CHECK_ARG(sum == D && D <= CL_MAX_DIM, "%s: branch channels sum to %d, code size is %d (at most %d)", who, sum, D, CL_MAX_DIM);
-    TODA_CHECK_ARG(batch >= 1 && classes >= 1 && H >= 1 && W >= 1 && K >= 1, "%s: empty geometry", who);
+    TODA_CHECK_ARG(batch >= 1 && classes >= 1 && H >= 1 && W >= 1 && K >= 1 && K <= 8192, "%s: empty geometry or more than 8192 object slots", who);
+    TODA_CHECK_ARG((long long)H * W < (1LL << 31), "%s: feature map too large", who);
     return TODA_OK;
 }
 
@@ -260,12 +278,12 @@ extern "C" int toda_center_loss_fwd(const float* hm_logits, const float* heatmap
 }
 
 extern "C" int toda_center_loss_bwd(const float* out4, const float* up_hm, const float* up_loc, int batch, int classes, int H, int W,
-                                    int n_branch, float* const* reg_grads, const int32_t* reg_channels, const int64_t* inds, int max_objs,
-                                    int code_size, const float* code_weights, float cls_weight, float loc_weight, float* hm_grad, const void* ws,
+                                    int n_branch, float* const* reg_grads, const int32_t* reg_channels, const int64_t* inds, const int64_t* mask,
+                                    int max_objs, int code_size, const float* code_weights, float cls_weight, float loc_weight, float* hm_grad, const void* ws,
                                     size_t ws_bytes, void* stream) {
     int rc = cl_check("center_loss_bwd", n_branch, reg_channels, batch, classes, H, W, max_objs, code_size);
     if (rc) return rc;
-    TODA_CHECK_ARG(out4 && up_hm && up_loc && reg_grads && inds && code_weights && hm_grad, "center_loss_bwd: null pointer");
+    TODA_CHECK_ARG(out4 && up_hm && up_loc && reg_grads && inds && mask && code_weights && hm_grad, "center_loss_bwd: null pointer");
     if (!ws || ws_bytes < toda_center_loss_workspace_bytes(batch, classes, H, W, max_objs, code_size)) {
         toda::set_error("center_loss_bwd: workspace too small");
         return TODA_EWORKSPACE;
@@ -292,9 +310,8 @@ extern "C" int toda_center_loss_bwd(const float* out4, const float* up_hm, const
     for (int d = 0; d < code_size; ++d) w.code[d] = code_weights[d];
     w.cls_weight = cls_weight, w.loc_weight = loc_weight;
     const long long n = (long long)batch * classes * H * W;
-    const int slot_blocks = cdiv((long long)batch * max_objs, CL_BLOCK);
-    hipLaunchKernelGGL(center_loss_bwd_kernel, dim3(l.blocks + slot_blocks), dim3(CL_BLOCK), 0, s, (const float*)l.g, n, l.blocks, out4, up_hm, up_loc,
-                       w, grads, (const long long*)inds, (const float*)l.sgn, batch, max_objs, code_size, H * W, hm_grad);
+    hipLaunchKernelGGL(center_loss_bwd_kernel, dim3(l.blocks + batch), dim3(CL_BLOCK), (size_t)max_objs * sizeof(int), s, (const float*)l.g, n, l.blocks, out4, up_hm, up_loc,
+                       w, grads, (const long long*)inds, (const long long*)mask, (const float*)l.sgn, batch, max_objs, code_size, H * W, hm_grad);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

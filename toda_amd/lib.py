@@ -77,7 +77,7 @@ SIGNATURES = {
     "toda_conv3x3_narrow_wgrad": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, C.c_longlong, _vp, _vp, _sz, _vp]),
     "toda_center_loss_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "toda_center_loss_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _sz, _vp]),
-    "toda_center_loss_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, C.c_float, C.c_float, _vp, _vp, _sz, _vp]),
+    "toda_center_loss_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_float, C.c_float, _vp, _vp, _sz, _vp]),
     "toda_timing_begin": (_i, [_i]),
     "toda_timing_end": (_i, [_vp, _i, _vp]),
     "toda_center_assign": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _dbl, _i, _vp, _vp, _vp, _vp, _vp]),

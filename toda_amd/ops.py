@@ -995,7 +995,7 @@ class _CenterLoss(torch.autograd.Function):
                                       L.ptr(inds), L.ptr(mask), L.ptr(target.contiguous().float()), k, d, L.hptr(cw), float(cls_w), float(loc_w),
                                       L.ptr(prob), L.ptr(out4), L.ptr(ws), ws_bytes, L.stream())
         L.check(rc, "toda_center_loss_fwd")
-        ctx.save_for_backward(out4, ws, inds)
+        ctx.save_for_backward(out4, ws, inds, mask)
         ctx.meta = (n, b, c, h, w, k, d, chans, [float(v) for v in code_w], float(cls_w), float(loc_w))
         ctx.mark_non_differentiable(prob)
         return out4[0], out4[1], prob
@@ -1003,7 +1003,7 @@ class _CenterLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_hm, g_loc, _g_prob):
         lib = L.load()
-        out4, ws, inds = ctx.saved_tensors
+        out4, ws, inds, mask = ctx.saved_tensors
         n, b, c, h, w, k, d, chans, code_w, cls_w, loc_w = ctx.meta
         dev = out4.device
         g_hm = g_hm.contiguous() if g_hm is not None else torch.zeros((), device=dev)
@@ -1016,7 +1016,7 @@ class _CenterLoss(torch.autograd.Function):
             off += b * ch * h * w
         cw = L.host_f32(code_w)
         rc = lib.toda_center_loss_bwd(L.ptr(out4), L.ptr(g_hm), L.ptr(g_loc), b, c, h, w, n, L.host_ptrs(grads), L.hptr(L.host_i32(chans)),
-                                      L.ptr(inds), k, d, L.hptr(cw), cls_w, loc_w, L.ptr(dz), L.ptr(ws), ws.numel(), L.stream())
+                                      L.ptr(inds), L.ptr(mask), k, d, L.hptr(cw), cls_w, loc_w, L.ptr(dz), L.ptr(ws), ws.numel(), L.stream())
         L.check(rc, "toda_center_loss_bwd")
         return (None, dz, *grads, None, None, None, None, None, None, None)
 

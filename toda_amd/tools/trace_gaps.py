@@ -19,7 +19,9 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     marks = [int(r["Start_Timestamp"]) for r in rows if "vox_insert" in r["Kernel_Name"]]
     t0 = marks[-steps * 2]
-    sel = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
+    adam = [int(r["End_Timestamp"]) for r in rows if "FusedOptimizerTensorListMetadata" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower()]
+    t_end = max(adam) if adam else int(rows[-1]["End_Timestamp"])
+    sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) <= t_end]
     agg = collections.defaultdict(lambda: [0.0, 0])
     end = int(sel[0]["End_Timestamp"])
     total = 0.0

@@ -13,8 +13,10 @@ def main():
     marks = [int(r["Start_Timestamp"]) for r in rows if "vox_insert" in r["Kernel_Name"]]
     per_step = 2  # bs 2 -> two voxelise calls per step
     t0 = marks[-steps * per_step]
-    t_end = int(rows[-1]["End_Timestamp"])
-    sel = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
+    # the timed region ends with the last optimizer kernel: what follows (pair counting for the roofline, --layers) is not a step
+    adam = [int(r["End_Timestamp"]) for r in rows if "FusedOptimizerTensorListMetadata" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower()]
+    t_end = max(adam) if adam else int(rows[-1]["End_Timestamp"])
+    sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) <= t_end]
     agg = collections.defaultdict(lambda: [0, 0])
     for r in sel:
         agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])

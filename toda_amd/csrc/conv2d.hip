@@ -813,7 +813,7 @@ wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
     const int w = wn_work_id();
     const long long S = (long long)wg.n_units * wg.steps_per_unit;
     const long long lo = ws_range_lo(w, G, S), hi = ws_range_lo(w + 1, G, S);
-    const int total = (int)(hi - lo);
+    const int total = __builtin_amdgcn_readfirstlane((int)(hi - lo));
     if (total == 0) return;
 
     if (wave < 4) {
@@ -832,28 +832,37 @@ wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
             for (int f = 0; f < WN_FREQ; ++f) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int chunk = c_begin; chunk < c_end; ++chunk, ++q) {
                 __syncthreads();
-                const f32x2* const ap = a_frag + (q & 1) * (IMG / 2);
-                const f32x2* const bp = b_frag + (q & 1) * (IMG / 2);
-                constexpr int AHEAD = 4;
+                // fragment reads as single ds_read_b64 with a counted lgkmcnt, as in wino_fwd_ws_kernel (left alone hipcc pairs
+                // them into ds_read2st64_b64: the same bytes at half the LDS rate)
+                const unsigned a_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(a_frag + (q & 1) * (IMG / 2));
+                const unsigned b_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(b_frag + (q & 1) * (IMG / 2));
                 f32x2 fa[WN_FREQ], fb[WN_FREQ];
-#pragma unroll
-                for (int f = 0; f < AHEAD; ++f) {
-                    fa[f] = ap[f * 128];
-                    fb[f] = bp[f * 128];
-                }
+#define WN_RD(f_)                                                                                                      \
+    asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%4" : "=&v"(fa[f_]), "=&v"(fb[f_]) : "v"(a_addr), "v"(b_addr), "n"((f_) * 1024))
+#define WN_WAIT(f_, n_)                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(fa[f_]), "+v"(fb[f_]), "+v"(fa[(f_) + 1]), "+v"(fb[(f_) + 1]))
+                WN_RD(0);
+                WN_RD(1);
+                WN_RD(2);
+                WN_RD(3);
 #pragma unroll
                 for (int f = 0; f < WN_FREQ; f += 2) {
-                    if (f + AHEAD < WN_FREQ) {
-                        fa[f + AHEAD] = ap[(f + AHEAD) * 128];
-                        fb[f + AHEAD] = bp[(f + AHEAD) * 128];
-                        fa[f + AHEAD + 1] = ap[(f + AHEAD + 1) * 128];
-                        fb[f + AHEAD + 1] = bp[(f + AHEAD + 1) * 128];
+                    if (f + 4 < WN_FREQ) {
+                        WN_RD(f + 4);
+                        WN_RD(f + 5);
+                        WN_WAIT(f, 8);
+                    } else if (f + 2 < WN_FREQ) {
+                        WN_WAIT(f, 4);
+                    } else {
+                        WN_WAIT(f, 0);
                     }
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][0], fb[f][0], acc[f], 0, 0, 0);
                     acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][0], fb[f + 1][0], acc[f + 1], 0, 0, 0);
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][1], fb[f][1], acc[f], 0, 0, 0);
                     acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][1], fb[f + 1][1], acc[f + 1], 0, 0, 0);
                 }
+#undef WN_RD
+#undef WN_WAIT
             }
             s += c_end - c_begin;
             // segment done: acc[f][r] = dU[f][ci = 16 wm + 4 quad + r][co = 16 wn + (lane & 15)] -> slab [f][co][ci]
@@ -865,39 +874,56 @@ wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
         // producers: thread = (tile k of the chunk, channel slot); see TilePos
         const int pw = wave - 4;
         const int k = (lane & 3) + 4 * (pw & 1), slot = (lane >> 2) + 16 * (pw >> 1);
-        const __amdgpu_buffer_rsrc_t xr = wn_rsrc(x, (unsigned)((size_t)g.B * g.Cin * g.H * g.W * 4u));
-        const __amdgpu_buffer_rsrc_t yr = wn_rsrc(dy, (unsigned)((size_t)g.B * g.Cout * g.H * g.W * 4u));
         const int img_off = (slot >> 4) * 128 + ((k >> 1) * 16 + (slot & 15)) * 2 + (k & 1);
-        int unit = (int)(lo / wg.steps_per_unit), chunk = (int)(lo - (long long)unit * wg.steps_per_unit);
+        int unit = __builtin_amdgcn_readfirstlane((int)(lo / wg.steps_per_unit));
+        int chunk = __builtin_amdgcn_readfirstlane((int)(lo - (long long)unit * wg.steps_per_unit));
         TilePos tp = wn_tile_pos(chunk * WG_KT + k, g);
+        const unsigned x_bytes = (unsigned)((size_t)g.B * g.Cin * g.H * g.W * 4u), y_bytes = (unsigned)((size_t)g.B * g.Cout * g.H * g.W * 4u);
 
-        XRaw px;
-        DyRaw py;
-        auto fetch = [&](int q_fetch) {
-            if (q_fetch >= total) return;
+        // Two register stages, loaded two chunks ahead and untouched until their chunk is produced; always the same loads (an
+        // empty descriptor past the end of the range: hardware zeros, no memory access) so that the compiler's vmcnt waits are the
+        // same on every path; the producers' barrier waits for their LDS writes only (see wino_fwd_ws_kernel).
+        struct WStage {
+            XRaw x;
+            DyRaw y;
+        };
+        auto fetch = [&](WStage& st, int q_fetch) {
+            const bool live = q_fetch < total;
+            const __amdgpu_buffer_rsrc_t xr = wn_rsrc(x, live ? x_bytes : 0u), yr = wn_rsrc(dy, live ? y_bytes : 0u);
             const int cib = unit / wg.n_co_blocks, cob = unit - cib * wg.n_co_blocks;
-            wn_load_x(xr, tp, cib * 32 + slot, g, px);
-            wn_load_dy(yr, tp, cob * 32 + slot, g, py);
-            if (++chunk == wg.steps_per_unit) {
-                chunk = 0;
-                ++unit;
-                tp = wn_tile_pos(k, g);
-            } else {
-                wn_tile_advance(tp, WG_KT, chunk * WG_KT + k, g);
+            wn_load_x(xr, tp, cib * 32 + slot, g, st.x);
+            wn_load_dy(yr, tp, cob * 32 + slot, g, st.y);
+            if (live) {
+                if (++chunk == wg.steps_per_unit) {
+                    chunk = 0;
+                    ++unit;
+                    tp = wn_tile_pos(k, g);
+                } else {
+                    wn_tile_advance(tp, WG_KT, chunk * WG_KT + k, g);
+                }
             }
         };
-        auto produce = [&](int buf) {
-            wn_x_transform_store(px, lds + buf * IMG + img_off);
-            wn_dy_transform_store(py, lds + (2 + buf) * IMG + img_off);
+        auto produce = [&](const WStage& st, int buf) {
+            wn_x_transform_store(st.x, lds + buf * IMG + img_off);
+            wn_dy_transform_store(st.y, lds + (2 + buf) * IMG + img_off);
         };
-        fetch(0);
-        produce(0);
-        fetch(1);
-        for (int q = 0;; ++q) {
-            __syncthreads();            // barrier q: images of chunk q published
+        auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        WStage s0, s1;
+        fetch(s0, 0);
+        fetch(s1, 1);
+        produce(s0, 0);
+        int q = 0;
+        while (true) {
+            barrier();                  // barrier q: images of chunk q published
             if (q + 1 >= total) break;
-            produce((q + 1) & 1);       // chunk q + 1 from the registers fetched one iteration ago
-            fetch(q + 2);
+            fetch(s0, q + 2);
+            produce(s1, (q + 1) & 1);
+            ++q;
+            barrier();
+            if (q + 1 >= total) break;
+            fetch(s1, q + 2);
+            produce(s0, (q + 1) & 1);
+            ++q;
         }
     }
 }

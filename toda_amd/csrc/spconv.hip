@@ -521,6 +521,25 @@ gather_gemm_ws_kernel(const float* __restrict__ in, int n_in, int cg, const floa
     }
 }
 
+// Row blocks -> XCDs.  The hardware deals workgroup ids round-robin over the 8 XCDs, each with a private 4 MiB L2: with the
+// identity mapping every XCD walks the whole (sorted) row range, so all 8 L2s fetch the whole gathered table from HBM (PMC: 690 MB
+// fetched per launch of the 64 -> 64 kernel on a 100 MB table).  Handing each XCD one contiguous eighth balances badly (z-slabs
+// differ in density: measured 6-8 % slower).  In between: chunks of GG_XCD_CHUNK consecutive row blocks are dealt round-robin, XCD x
+// works on chunks x, x + 8, ...: neighbours in x / y of a row stay inside its chunk's L2, every XCD still samples the whole scene.
+// Measured on the 389.5k-row 64 -> 64 layer (FETCH_SIZE per launch, kernel ms): identity 337.8 MiB-units / 0.595, chunk 16
+// 191.1 / 0.593, 32 181.0 / 0.590, 64 185.3 / 0.606, 256 - / 0.629: HBM traffic 3.2x -> 1.9x the algorithmic bytes at equal speed.
+#ifndef GG_XCD_CHUNK
+#define GG_XCD_CHUNK 32
+#endif
+__device__ __forceinline__ int xcd_chunked_block(int b, int nblk) {
+    constexpr int C = GG_XCD_CHUNK;
+    if (C <= 0) return b;
+    const int per = 8 * C, full = (nblk / per) * per;
+    if (b >= full) return b;
+    const int xcd = b & 7, local = b >> 3;
+    return ((local / C) * 8 + xcd) * C + local % C;
+}
+
 #ifndef GG_LDS_WAVES_WIDE
 #define GG_LDS_WAVES_WIDE 4   // 512-thread blocks of the 128-channel variant: 2 blocks x 8 waves per CU
 #endif
@@ -535,8 +554,8 @@ gather_gemm_ws_kernel(const float* __restrict__ in, int n_in, int cg, const floa
 // streaming it through L1 (4x less vector-memory traffic: with per-wave weight loads the CU's
 // 64 B/clk L1 path, not the MFMA pipe, sets the pace - measured 59 % matrix-pipe utilisation).
 // One barrier per offset; waves still skip the MFMAs of offsets without a neighbour in their rows.
-template <int Q, int NT, int RT, bool VEC, bool DB = true, int BLK = SC_BLOCK>
-__global__ void __launch_bounds__(BLK, (Q * NT <= 4 && RT <= 2) ? GG_LDS_WAVES_NARROW : (Q * NT * RT <= 32 && Q * NT <= 16) ? GG_LDS_WAVES : (BLK > SC_BLOCK ? GG_LDS_WAVES_WIDE : 1))
+template <int Q, int NT, int RT, bool VEC, bool DB = true, int BLK = SC_BLOCK, bool PFL = false>
+__global__ void __launch_bounds__(BLK, PFL ? 3 : (Q * NT <= 4 && RT <= 2) ? GG_LDS_WAVES_NARROW : (Q * NT * RT <= 32 && Q * NT <= 16) ? GG_LDS_WAVES : (BLK > SC_BLOCK ? GG_LDS_WAVES_WIDE : 1))
 gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                        const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
                        float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stats) {
@@ -544,7 +563,8 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
     constexpr int PER_THREAD = (SLICE + BLK - 1) / BLK;
     __shared__ f32x4 wl[DB ? 2 : 1][SLICE];  // DB = false: one 64 KiB buffer (128-channel layers), two barriers per offset
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+    const int blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const int wave = blk * (BLK / 64) + (threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int row0 = wave * (16 * RT);
     const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
@@ -574,58 +594,130 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
     }
     __syncthreads();
 
-    for (int k = 0; k < K; ++k) {
-        const int cur = DB ? (k & 1) : 0;
-        // next offset's weights: global -> registers now, registers -> LDS after this offset's math
-        f32x4 stage[PER_THREAD];
-        if (k + 1 < K) {
+    if constexpr (PFL) {
+        // software-pipelined variant (experiment): neighbour ids two offsets ahead, gathered rows one offset ahead, in two
+        // register sets that alternate (loop body written twice: no register copies - vector moves cost matrix time here)
+        static_assert(DB, "pipelined variant needs the double-buffered weight slices");
+        auto load_ids = [&](int k, int (&dst)[RT]) {
+            const int kk = k < K ? k : K - 1;
 #pragma unroll
-            for (int t = 0; t < PER_THREAD; ++t) {
-                const int e = t * BLK + threadIdx.x;
-                if (e < SLICE) stage[t] = wp4[(size_t)(k + 1) * SLICE + e];
+            for (int rt = 0; rt < RT; ++rt) {
+                const int v = nbr[(size_t)kk * n_out + rows[rt]];
+                dst[rt] = (k < K && live[rt]) ? v : -1;
             }
+        };
+        auto body = [&](int k, const int (&s_cur)[RT], const f32x4 (&a_cur)[RT][Q], int (&s_ids)[RT], const int (&s_next)[RT], f32x4 (&a_next)[RT][Q]) {
+            const int cur = k & 1;
+            f32x4 stage[PER_THREAD];
+            if (k + 1 < K) {
+#pragma unroll
+                for (int t = 0; t < PER_THREAD; ++t) {
+                    const int e = t * BLK + threadIdx.x;
+                    if (e < SLICE) stage[t] = wp4[(size_t)(k + 1) * SLICE + e];
+                }
+            }
+            load_ids(k + 2, s_ids);                                   // overwrites the ids of offset k - 1 (dead)
+            gather_rows<Q, RT, VEC>(in_rsrc, cg, g, s_next, a_next);   // rows of offset k + 1, in flight under the MFMAs below
+            bool hit[RT];
+            bool any = false;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                hit[rt] = __any(s_cur[rt] >= 0);
+                any = any || hit[rt];
+            }
+            if (any) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    f32x4 b[NT];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) b[n] = wl[cur][(q * NT + n) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+                                if (hit[rt]) acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[rt][q][j], b[n][j], acc[rt][n], 0, 0, 0);
+                }
+            }
+            if (k + 1 < K) {
+#pragma unroll
+                for (int t = 0; t < PER_THREAD; ++t) {
+                    const int e = t * BLK + threadIdx.x;
+                    if (e < SLICE) wl[cur ^ 1][e] = stage[t];
+                }
+            }
+            __syncthreads();
+        };
+        int sA[RT], sB[RT], sC[RT];
+        f32x4 aA[RT][Q], aB[RT][Q];
+        load_ids(0, sA);
+        load_ids(1, sB);
+        gather_rows<Q, RT, VEC>(in_rsrc, cg, g, sA, aA);
+        // ids rotate through three sets (period 3), rows through two (period 2): six offsets per trip
+        int k = 0;
+        while (true) {
+            body(k, sA, aA, sC, sB, aB); if (++k >= K) break;      // cur ids A, next ids B, k+2 -> C
+            body(k, sB, aB, sA, sC, aA); if (++k >= K) break;
+            body(k, sC, aA, sB, sA, aB); if (++k >= K) break;
+            body(k, sA, aB, sC, sB, aA); if (++k >= K) break;
+            body(k, sB, aA, sA, sC, aB); if (++k >= K) break;
+            body(k, sC, aB, sB, sA, aA); if (++k >= K) break;
         }
-        int src[RT];
-        bool hit[RT];
-        bool any = false;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int v = nbr[(size_t)k * n_out + rows[rt]];
-            src[rt] = live[rt] ? v : -1;
-            hit[rt] = __any(src[rt] >= 0);
-            any = any || hit[rt];
-        }
-        if (any) {
-            f32x4 a[RT][Q];
-            gather_rows<Q, RT, VEC>(in_rsrc, cg, g, src, a);
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                f32x4 b[NT];
-#pragma unroll
-                for (int n = 0; n < NT; ++n) b[n] = wl[cur][(q * NT + n) * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) {
-                            if (hit[rt])
-                                acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[n][j], acc[rt][n], 0, 0, 0);
+    } else {
+    for (int k = 0; k < K; ++k) {
+            const int cur = DB ? (k & 1) : 0;
+            // next offset's weights: global -> registers now, registers -> LDS after this offset's math
+            f32x4 stage[PER_THREAD];
+            if (k + 1 < K) {
+    #pragma unroll
+                for (int t = 0; t < PER_THREAD; ++t) {
+                    const int e = t * BLK + threadIdx.x;
+                    if (e < SLICE) stage[t] = wp4[(size_t)(k + 1) * SLICE + e];
+                }
+            }
+            int src[RT];
+            bool hit[RT];
+            bool any = false;
+    #pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int v = nbr[(size_t)k * n_out + rows[rt]];
+                src[rt] = live[rt] ? v : -1;
+                hit[rt] = __any(src[rt] >= 0);
+                any = any || hit[rt];
+            }
+            if (any) {
+                f32x4 a[RT][Q];
+                gather_rows<Q, RT, VEC>(in_rsrc, cg, g, src, a);
+    #pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    f32x4 b[NT];
+    #pragma unroll
+                    for (int n = 0; n < NT; ++n) b[n] = wl[cur][(q * NT + n) * 64 + lane];
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+    #pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+    #pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                if (hit[rt])
+                                    acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[n][j], acc[rt][n], 0, 0, 0);
+                            }
                         }
                     }
                 }
             }
-        }
-        if (!DB) __syncthreads();  // everyone is done reading the single buffer
-        if (k + 1 < K) {
-#pragma unroll
-            for (int t = 0; t < PER_THREAD; ++t) {
-                const int e = t * BLK + threadIdx.x;
-                if (e < SLICE) wl[DB ? (cur ^ 1) : 0][e] = stage[t];
+            if (!DB) __syncthreads();  // everyone is done reading the single buffer
+            if (k + 1 < K) {
+    #pragma unroll
+                for (int t = 0; t < PER_THREAD; ++t) {
+                    const int e = t * BLK + threadIdx.x;
+                    if (e < SLICE) wl[DB ? (cur ^ 1) : 0][e] = stage[t];
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+}
     if (row0 >= n_out && !stats) return;
 
     // BatchNorm statistics of the layer's output, taken from the accumulators (reference spconv_backbone.py:21-25: every conv
@@ -662,7 +754,7 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
             double a = 0.0;
 #pragma unroll
             for (int w = 0; w < BLK / 64; ++w) a += (double)st_sh[w][qq][ch];
-            stats[2 * cp + (size_t)(qq * cp + ch) * gridDim.x + blockIdx.x] = a;
+            stats[2 * cp + (size_t)(qq * cp + ch) * gridDim.x + blk] = a;
         }
     }
 
@@ -1276,9 +1368,15 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
+    static const int env_pfl = getenv("TODA_GG_LDS_PF") ? atoi(getenv("TODA_GG_LDS_PF")) : 0;   // 64 -> 64: register-pipelined gathers (experiment)
     if ((env_lds || stats) && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
 #define GL(QQ, NN, RR)                                                                                                   \
-    GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
+    if (env_pfl && QQ == 4 && NN == 4 && RR == 2)                                                                        \
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<4, 4, 2, true, true, SC_BLOCK, true>),                          \
+                  dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
+                  k_vol, c_produce, bias, out, order, stats);                                                            \
+    else                                                                                                                 \
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
                        k_vol, c_produce, bias, out, order, stats)
 #define GL_RT(QQ, NN)                          \

@@ -7,6 +7,21 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
+cd /tmp && export TMPDIR=/tmp
+echo "== counters (one pass per set, kernel trace only)"
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  rm -rf /tmp/r02_pmc_$tag
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r02_pmc_$tag -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/r02_pmc_$tag.log 2>&1
+  echo "  $tag done"
+done
+CSVS=$(find /tmp/r02_pmc_FETCH_SIZE /tmp/r02_pmc_WRITE_SIZE /tmp/r02_pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv")
+python3 $R/toda_amd/tools/pmc_summary.py gather_gemm_lds_kernel $O/r02_pmc_gather_gemm_64x64.json $CSVS > /dev/null
+python3 $R/toda_amd/tools/pmc_summary.py wino_fwd_ws_kernel $O/r02_pmc_wino_fwd.json $CSVS > /dev/null
+python3 $R/toda_amd/tools/pmc_summary.py wino_wgrad_kernel $O/r02_pmc_wino_wgrad.json $CSVS > /dev/null
+python3 $R/toda_amd/tools/pmc_summary.py wgrad_kernel $O/r02_pmc_sparse_wgrad.json $CSVS > /dev/null
+cp $O/r02_pmc_gather_gemm_64x64.json $R/profiles/r02_pmc_gather_gemm_64x64.json
+cd $R
 echo "== bench lines"
 timeout -k 10 400 python bench.py --steps 50 --warmup 10 --layers --layers-out $O/r02_layers_c3.json > $O/r02_bench_c3.json 2> $O/r02_bench_c3.err
 for w in c2 c5 c5mix c5cl; do
@@ -30,21 +45,6 @@ timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/r02_kt_c5
 F5=$(find /tmp/r02_kt_c5 -name "*kernel_trace.csv" | head -1)
 python3 $R/toda_amd/tools/trace_summary.py $F5 5 $O/r02_bench_c5_timed_steps.csv > $O/r02_bench_c5_groups.txt
 python3 $R/toda_amd/tools/trace_gaps.py $F5 5 > $O/r02_gaps_c5.txt
-echo "== counters (one pass per set, kernel trace only)"
-for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"; do
-  tag=$(echo $c | cut -d' ' -f1)
-  rm -rf /tmp/r02_pmc_$tag
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r02_pmc_$tag -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/r02_pmc_$tag.log 2>&1
-  echo "  $tag done"
-done
-CSVS=$(find /tmp/r02_pmc_FETCH_SIZE /tmp/r02_pmc_WRITE_SIZE /tmp/r02_pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv")
-python3 $R/toda_amd/tools/pmc_summary.py gather_gemm_lds_kernel $O/r02_pmc_gather_gemm_64x64.json $CSVS > /dev/null
-python3 $R/toda_amd/tools/pmc_summary.py wino_fwd_ws_kernel $O/r02_pmc_wino_fwd.json $CSVS > /dev/null
-python3 $R/toda_amd/tools/pmc_summary.py wino_wgrad_kernel $O/r02_pmc_wino_wgrad.json $CSVS > /dev/null
-python3 $R/toda_amd/tools/pmc_summary.py wgrad_kernel $O/r02_pmc_sparse_wgrad.json $CSVS > /dev/null
 cd $R
-echo "== bench line with the fresh counter file in place"
-cp $O/r02_pmc_gather_gemm_64x64.json $R/profiles/r02_pmc_gather_gemm_64x64.json
-timeout -k 10 400 python bench.py --steps 50 --warmup 10 > $O/r02_bench_c3.json 2>> $O/r02_bench_c3.err
 cut -c1-300 $O/r02_bench_c3.json
 echo "== done"

@@ -125,6 +125,12 @@ int toda_rulebook_conv(const int32_t* idx_in, int n_in, int batch,
 size_t toda_spconv_packed_weight_floats(int k_vol, int c_gather, int c_produce);
 int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int cin,
                             int transpose, int flip_k, float* wp, void* stream);
+/* The same for n weights in one launch (the forward and the data-gradient operand of every sparse convolution of a
+ * backbone, once per optimizer step).  All array arguments are HOST arrays of length n; wp_host[i] receives
+ * toda_spconv_packed_weight_floats(k_vol[i], c_gather, c_produce) floats. */
+int toda_spconv_pack_weights(int n, const float* const* w_host, const int32_t* cout_host, const int32_t* k_vol_host,
+                             const int32_t* cin_host, const int32_t* transpose_host, const int32_t* flip_k_host,
+                             float* const* wp_host, void* stream);
 /* out[o, :] = bias + sum_k Wp[k] . in[nbr[k*n_out + o], :]   (rows with nbr<0 skipped).
  * `in` has n_in rows of c_gather floats (the table is read through a bounds-checked buffer
  * descriptor, so n_in * c_gather * 4 must be < 4 GiB). */

@@ -721,3 +721,29 @@ def test_mask_sorted_row_order_is_a_blockwise_permutation_and_changes_no_bit():
         assert torch.equal(a, b), (cin, cout)
         rev = torch.arange(n_rows - 1, -1, -1, dtype=torch.int32, device="cuda")          # any permutation works
         assert torch.equal(a, ops.gather_gemm(feat, wp, rb.nbr_fwd, cout, bias, order=rev))
+
+
+def test_batched_weight_pack_equals_single_packs():
+    """toda_spconv_pack_weights (every operand of a backbone in one launch) against toda_spconv_pack_weight, bit for bit;
+    spconv.prepack hands each convolution the same operands it would pack for itself, and a weight update invalidates them."""
+    from toda_amd import ops, spconv
+
+    g = torch.Generator().manual_seed(11)
+    items = []
+    for cout, cin, ks in ((16, 5, (3, 3, 3)), (32, 16, (3, 3, 3)), (64, 64, (3, 3, 3)), (128, 64, (3, 1, 1)), (128, 128, (3, 3, 3))):
+        w = torch.randn((cout, *ks, cin), generator=g).cuda()
+        items += [(w, False, False), (w, True, True), (w, True, False)]
+    got = ops.pack_weights_batched(items)
+    for (w, tr, fl), wp in zip(items, got):
+        assert torch.equal(wp, ops.pack_weight(w, tr, fl))
+
+    net = torch.nn.Sequential(spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="a"),
+                              spconv.SparseConv3d(32, 64, 3, stride=2, padding=1, bias=False, indice_key="b")).cuda()
+    spconv.prepack(net)
+    for m in net:
+        assert torch.equal(m._packed[1], ops.pack_weight(m.weight.detach(), False, False))
+        assert torch.equal(m._dgrad_operand(), ops.pack_weight(m.weight.detach(), True, m.subm))
+    with torch.no_grad():
+        net[0].weight.mul_(2.0)
+    assert net[0]._dgrad_operand() is None                                    # stale after an in-place update
+    assert torch.equal(net[0]._packed_forward_weight(), ops.pack_weight(net[0].weight.detach(), False, False))

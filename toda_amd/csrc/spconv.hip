@@ -66,6 +66,42 @@ pack_weight_kernel(const float* __restrict__ w, int cout, int K, int cin, int tr
     wp[e] = v;
 }
 
+// All packs of a training step (forward operand and dgrad operand of every sparse conv of a backbone) in ONE launch:
+// blockIdx.y = segment.  A step otherwise spends 46 launches of ~4 us (and as many host calls) on them.
+constexpr int PACK_MAX_SEG = 48;
+struct PackBatch {
+    const float* w[PACK_MAX_SEG];
+    float* wp[PACK_MAX_SEG];
+    int cout[PACK_MAX_SEG], K[PACK_MAX_SEG], cin[PACK_MAX_SEG];
+    unsigned char transpose[PACK_MAX_SEG], flip[PACK_MAX_SEG], Q[PACK_MAX_SEG], NT[PACK_MAX_SEG];
+};
+
+__global__ void __launch_bounds__(SC_BLOCK)
+pack_weight_batch_kernel(const PackBatch b) {
+    const int sg = blockIdx.y;
+    const int K = b.K[sg], Q = b.Q[sg], NT = b.NT[sg], cin = b.cin[sg], cout = b.cout[sg];
+    const long long e = (long long)blockIdx.x * SC_BLOCK + threadIdx.x;
+    if (e >= (long long)K * Q * NT * 256) return;
+    const int j = (int)(e & 3);
+    const int lane = (int)((e >> 2) & 63);
+    long long t = e >> 8;
+    const int n = (int)(t % NT);
+    t /= NT;
+    const int q = (int)(t % Q);
+    const int k = (int)(t / Q);
+    const int c = lane & 15, g = lane >> 4;
+    const int gch = 16 * q + 4 * g + j, pch = NT * c + n;
+    const int kk = b.flip[sg] ? K - 1 - k : k;
+    const float* __restrict__ w = b.w[sg];
+    float v = 0.0f;
+    if (!b.transpose[sg]) {
+        if (gch < cin && pch < cout) v = w[((size_t)pch * K + kk) * cin + gch];
+    } else {
+        if (gch < cout && pch < cin) v = w[((size_t)gch * K + kk) * cin + pch];
+    }
+    b.wp[sg][e] = v;
+}
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Buffer resource over a whole fp32 table.  Reads through it are bounds-checked by the hardware:
@@ -1127,6 +1163,30 @@ extern "C" int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int 
     hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(total, SC_BLOCK)), dim3(SC_BLOCK), 0, (hipStream_t)stream, w, cout,
                        k_vol, cin, transpose, flip_k, Q, NT, wp);
     TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_spconv_pack_weights(int n, const float* const* w, const int32_t* cout, const int32_t* k_vol, const int32_t* cin,
+                                        const int32_t* transpose, const int32_t* flip_k, float* const* wp, void* stream) {
+    TODA_CHECK_ARG(n >= 0 && w && cout && k_vol && cin && transpose && flip_k && wp, "pack_weights: null argument");
+    for (int base = 0; base < n; base += PACK_MAX_SEG) {
+        const int m = n - base < PACK_MAX_SEG ? n - base : PACK_MAX_SEG;
+        PackBatch b = {};
+        long long most = 0;
+        for (int i = 0; i < m; ++i) {
+            const int s = base + i;
+            TODA_CHECK_ARG(w[s] && wp[s] && cout[s] >= 1 && cin[s] >= 1 && k_vol[s] >= 1, "pack_weights: bad segment %d", s);
+            const int cgather = transpose[s] ? cout[s] : cin[s], cprod = transpose[s] ? cin[s] : cout[s];
+            TODA_CHECK_ARG(cgather <= 128 && cprod <= 128, "pack_weights: channels > 128 unsupported (segment %d)", s);
+            b.w[i] = w[s], b.wp[i] = wp[s], b.cout[i] = cout[s], b.K[i] = k_vol[s], b.cin[i] = cin[s];
+            b.transpose[i] = transpose[s] != 0, b.flip[i] = flip_k[s] != 0;
+            b.Q[i] = (unsigned char)tiles_pow2(cgather), b.NT[i] = (unsigned char)tiles_pow2(cprod);
+            const long long total = (long long)k_vol[s] * b.Q[i] * b.NT[i] * 256;
+            if (total > most) most = total;
+        }
+        hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(cdiv(most, SC_BLOCK), m), dim3(SC_BLOCK), 0, (hipStream_t)stream, b);
+        TODA_LAUNCH_CHECK();
+    }
     return TODA_OK;
 }
 

@@ -296,6 +296,33 @@ def pack_weight(weight, transpose, flip_k):
     return wp
 
 
+def pack_weights_batched(items):
+    """items: [(weight [Cout, kz, ky, kx, Cin], transpose, flip_k)] -> the packed operands, all written by ONE launch into
+    one allocation (toda_spconv_pack_weights).  Used once per step for every sparse convolution of a backbone."""
+    lib = L.load()
+    if not items:
+        return []
+    dev = items[0][0].device
+    sizes, couts, ks, cins = [], [], [], []
+    for w, tr, _ in items:
+        cout, cin = w.shape[0], w.shape[-1]
+        K = w.numel() // (cout * cin)
+        cg, cp = (cout, cin) if tr else (cin, cout)
+        sizes.append(lib.toda_spconv_packed_weight_floats(K, cg, cp))
+        couts.append(cout), ks.append(K), cins.append(cin)
+    flat = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+    outs, off = [], 0
+    for n in sizes:
+        outs.append(flat[off:off + n])
+        off += n
+    ws = [w.contiguous() for w, _, _ in items]
+    rc = lib.toda_spconv_pack_weights(len(items), L.host_ptrs(ws), L.hptr(L.host_i32(couts)), L.hptr(L.host_i32(ks)), L.hptr(L.host_i32(cins)),
+                                      L.hptr(L.host_i32([int(bool(t)) for _, t, _ in items])), L.hptr(L.host_i32([int(bool(f)) for _, _, f in items])),
+                                      L.host_ptrs(outs), L.stream())
+    L.check(rc, "toda_spconv_pack_weights")
+    return outs
+
+
 def rulebook_row_order(nbr):
     lib = L.load()
     K, n_out = nbr.shape
@@ -369,7 +396,7 @@ class _SparseConv(torch.autograd.Function):
     (reference tools/train_utils/train_utils.py:55)."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, rb, wp_fwd, want_stats=False):
+    def forward(ctx, features, weight, bias, rb, wp_fwd, want_stats=False, wp_bwd=None):
         features = features.contiguous()
         if wp_fwd is None:
             wp_fwd = pack_weight(weight, False, False)
@@ -380,6 +407,7 @@ class _SparseConv(torch.autograd.Function):
             out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, order=rb.order_for(rb.nbr_fwd))
         ctx.save_for_backward(features, weight)
         ctx.rb = rb
+        ctx.wp_bwd = wp_bwd          # the dgrad operand when the module packed it with the rest of the backbone
         ctx.has_bias = bias is not None
         if want_stats:
             ctx.mark_non_differentiable(sums)
@@ -405,7 +433,7 @@ class _SparseConv(torch.autograd.Function):
                 t.record_stream(side)
             need_w = False
         if need_d:
-            wp_t = pack_weight(weight, True, rb.flip_bwd)
+            wp_t = ctx.wp_bwd if ctx.wp_bwd is not None else pack_weight(weight, True, rb.flip_bwd)
             gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None, order=rb.order_for(rb.nbr_bwd))
         if need_w:
             gw = wgrad(features, gout, rb.nbr_fwd, tuple(weight.shape))
@@ -414,22 +442,22 @@ class _SparseConv(torch.autograd.Function):
         if side is not None:
             torch.cuda.current_stream(gout.device).wait_stream(side)
             gw.record_stream(torch.cuda.current_stream(gout.device))
-        return gfeat, gw, gb, None, None, None
+        return gfeat, gw, gb, None, None, None, None
 
 
 FUSE_BN_STATS = _os.environ.get("TODA_FUSE_BN_STATS", "1") == "1"
 
 
-def sparse_conv(features, weight, bias, rulebook, packed_weight=None, want_stats=False):
+def sparse_conv(features, weight, bias, rulebook, packed_weight=None, want_stats=False, packed_dgrad=None):
     """want_stats: also return the BatchNorm moments of the output when the kernel's epilogue can take them
     (returns (out, sums) with sums None when it cannot: empty tables, narrow channel pairs, mask-sorted row order)."""
     if not want_stats:
-        return _SparseConv.apply(features, weight, bias, rulebook, packed_weight)
+        return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, False, packed_dgrad)
     ok = (FUSE_BN_STATS and gather_gemm_stats_supported(weight.shape[-1], weight.shape[0]) and rulebook.nbr_fwd.shape[1] > 1
           and features.shape[0] > 0 and rulebook.order_for(rulebook.nbr_fwd) is None)
     if not ok:
-        return _SparseConv.apply(features, weight, bias, rulebook, packed_weight), None
-    return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, True)
+        return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, False, packed_dgrad), None
+    return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, True, packed_dgrad)
 
 
 # ------------------------------------------------------------------------ sparse <-> dense

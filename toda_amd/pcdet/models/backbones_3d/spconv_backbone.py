@@ -99,6 +99,8 @@ class _Backbone8xBase(nn.Module):
         elif hasattr(spconv, "plan_indices"):
             # all 8/9 rulebooks with one host sync instead of one per strided conv
             spconv.plan_indices(x, self)
+        if hasattr(spconv, "prepack"):
+            spconv.prepack(self)      # every conv's forward + dgrad operand in one launch (46 small launches per step otherwise)
         x = self.conv_input(x)
         stages = []
         for stage in (self.conv1, self.conv2, self.conv3, self.conv4):

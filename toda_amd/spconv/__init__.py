@@ -10,5 +10,6 @@ from .conv import SparseConv3d, SparseConvolution, SparseInverseConv3d, SubMConv
 from .core import SparseConvTensor  # noqa: F401
 from .modules import SparseModule, SparseSequential  # noqa: F401
 from .plan import plan_indices  # noqa: F401
+from .conv import prepack  # noqa: F401
 
 __version__ = "2.1.0+toda_amd"

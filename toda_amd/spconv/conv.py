@@ -39,7 +39,8 @@ class SparseConvolution(SparseModule):
         else:
             self.register_parameter("bias", None)
         self.reset_parameters()
-        self._packed = None  # (version, data_ptr, packed forward weights)
+        self._packed = None  # ((version, data_ptr), packed forward weights)
+        self._packed_dgrad = None  # ((version, data_ptr), packed data-gradient operand) when prepack() made it
 
     def reset_parameters(self):
         # same recipe as torch's _ConvNd: kaiming_uniform(a=sqrt(5)) over fan_in = K * Cin
@@ -63,6 +64,13 @@ class SparseConvolution(SparseModule):
             with torch.no_grad():
                 self._packed = (tag, ops.pack_weight(w.detach(), False, False))
         return self._packed[1]
+
+    def _dgrad_operand(self):
+        """The dgrad operand packed together with the forward one by prepack(), if it matches the current weights."""
+        w = self.weight
+        if self._packed_dgrad is not None and self._packed_dgrad[0] == (w._version, w.data_ptr()):
+            return self._packed_dgrad[1]
+        return None
 
     def _rulebook(self, x):
         """Find or build the rulebook; returns (rulebook, out_indices, out_shape, out_grid_index)."""
@@ -99,9 +107,13 @@ class SparseConvolution(SparseModule):
         packed = self._packed_forward_weight()
         sums = None
         if want_bn_stats:
-            feats, sums = ops.sparse_conv(x.features, self.weight, self.bias, rb, packed, want_stats=True)
+            dg = self._dgrad_operand()
+            extra = {} if dg is None else {"packed_dgrad": dg}
+            feats, sums = ops.sparse_conv(x.features, self.weight, self.bias, rb, packed, want_stats=True, **extra)
         else:
-            feats = ops.sparse_conv(x.features, self.weight, self.bias, rb, packed)
+            dg = self._dgrad_operand()
+            extra = {} if dg is None else {"packed_dgrad": dg}
+            feats = ops.sparse_conv(x.features, self.weight, self.bias, rb, packed, **extra)
         out = SparseConvTensor(feats, out_idx, out_shape, x.batch_size, indice_dict=x.indice_dict)
         out.grid_index = gi
         out.bn_sums = sums
@@ -126,3 +138,32 @@ class SparseConv3d(SparseConvolution):
 class SparseInverseConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, indice_key=None, bias=True, **kw):
         super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)
+
+
+def prepack(module):
+    """Pack the forward and (when gradients will be wanted) the data-gradient operands of EVERY sparse convolution under
+    `module` whose weights changed since the last pack in one kernel launch.  Called once per forward by the backbones; a
+    convolution that is not covered (first use, weights touched later) packs for itself as before."""
+    convs = module.__dict__.get("_sparse_convs")
+    if convs is None:
+        convs = [m for m in module.modules() if isinstance(m, SparseConvolution)]
+        module.__dict__["_sparse_convs"] = convs
+    if not convs or not convs[0].weight.is_cuda:
+        return
+    want_dgrad = torch.is_grad_enabled()
+    stale = []
+    for c in convs:
+        tag = (c.weight._version, c.weight.data_ptr())
+        if c._packed is None or c._packed[0] != tag or (want_dgrad and c.weight.requires_grad and (c._packed_dgrad is None or c._packed_dgrad[0] != tag)):
+            stale.append((c, tag))
+    if len(stale) < 2:
+        return
+    with torch.no_grad():
+        items = [(c.weight.detach(), False, False) for c, _ in stale]
+        back = [(c, tag) for c, tag in stale if want_dgrad and c.weight.requires_grad]
+        items += [(c.weight.detach(), True, c.subm) for c, _ in back]       # SubM dgrad reads the forward table with reversed offsets
+        packed = ops.pack_weights_batched(items)
+    for (c, tag), wp in zip(stale, packed[:len(stale)]):
+        c._packed = (tag, wp)
+    for (c, tag), wp in zip(back, packed[len(stale):]):
+        c._packed_dgrad = (tag, wp)

@@ -146,6 +146,20 @@ int toda_rulebook_row_order(const int32_t* nbr, int n_out, int k_vol /*<= 31*/, 
 int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_gather, const float* wp,
                                     const int32_t* nbr, int n_out, int k_vol, int c_produce,
                                     const float* bias, float* out, const int32_t* order, void* stream);
+
+/* Data gradient of a STRIDED SparseConv3d (autograd backward of spconv_backbone.py:118-160's spconv2/3/4 and conv_out):
+ * an input site reaches an output only through the kernel offsets congruent to (coordinate + padding) modulo the
+ * stride on every axis, i.e. 1..8 of the 27 offsets, all of them populated.  toda_rulebook_class_order regroups the
+ * rows (= the conv's INPUT sites, in_coords [n_in][4] = b,z,y,x) by residue class inside 8192-row blocks:
+ * order[pos] = row, cls_sorted[pos] = class.  toda_spconv_gather_gemm_classed is toda_spconv_gather_gemm_ordered whose
+ * waves walk only the candidate offsets of their class (ksize / stride / padding: HOST int[3], z,y,x).  Results are
+ * bit-identical to the plain call. */
+int toda_rulebook_class_order(const int32_t* in_coords, int n_in, const int32_t* stride_host, const int32_t* padding_host,
+                              int32_t* order, unsigned char* cls_sorted, void* stream);
+int toda_spconv_gather_gemm_classed(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out,
+                                    int k_vol, int c_produce, const float* bias, float* out, const int32_t* order,
+                                    const unsigned char* cls_sorted, const int32_t* ksize_host, const int32_t* stride_host,
+                                    const int32_t* padding_host, void* stream);
 /* dw[co][k][ci] = sum_o in[nbr[k*n_out+o], ci] * dout[o, co] */
 size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout);
 int toda_spconv_wgrad(const float* in, int n_in, const float* dout, const int32_t* nbr,

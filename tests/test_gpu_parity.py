@@ -747,3 +747,42 @@ def test_batched_weight_pack_equals_single_packs():
         net[0].weight.mul_(2.0)
     assert net[0]._dgrad_operand() is None                                    # stale after an in-place update
     assert torch.equal(net[0]._packed_forward_weight(), ops.pack_weight(net[0].weight.detach(), False, False))
+
+
+@pytest.mark.parametrize("ks,st,pd", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))])
+@pytest.mark.parametrize("cin,cout", [(16, 32), (64, 64), (64, 128)])
+def test_strided_dgrad_over_class_sorted_rows_is_bit_identical(ks, st, pd, cin, cout, monkeypatch):
+    """toda_rulebook_class_order + toda_spconv_gather_gemm_classed (data gradient of a strided conv walking only the kernel
+    offsets congruent to (coordinate + padding) mod stride) against the plain gather-GEMM over all offsets: same bits; the
+    class lists cover every pair of the table; and the autograd path takes the classed kernel."""
+    from toda_amd import ops
+
+    shape, batch = [21, 96, 88], 2
+    idx, feat = H.clustered_sparse(batch, shape, 9000, cin, seed=5)
+    monkeypatch.setattr(ops, "CLASS_DGRAD_MIN_ROWS", 0)
+    _, _, rb, _ = ops.build_conv_rulebook(dev(idx), batch, shape, ks, st, pd)
+    w = dev((np.random.default_rng(1).standard_normal((cout,) + ks + (cin,)) * 0.05).astype(np.float32))
+    g = torch.randn((rb.n_out, cout), device="cuda")
+    wp_t = ops.pack_weight(w, True, False)
+    plain = ops.gather_gemm(g, wp_t, rb.nbr_bwd, cin)
+    order, cls = rb.class_order()
+    assert torch.equal(torch.sort(order.long())[0], torch.arange(rb.n_in, device="cuda"))
+    got = ops.gather_gemm_classed(g, wp_t, rb.nbr_bwd, cin, order, cls, rb.ksize, rb.geom["stride"], rb.geom["padding"])
+    assert torch.equal(got, plain)
+    # every valid pair of a row lies on one of its class's candidate offsets
+    coords = dev(idx)[order.long()].long()
+    K = rb.nbr_bwd.shape[0]
+    kz, ky, kx = np.unravel_index(np.arange(K), ks)
+    for k in range(K):
+        rows = (rb.nbr_bwd[k][order.long()] >= 0)
+        if int(rows.sum()) == 0:
+            continue
+        c = coords[rows]
+        assert bool((((c[:, 1] + pd[0]) % st[0]) == kz[k] % st[0]).all() and (((c[:, 2] + pd[1]) % st[1]) == ky[k] % st[1]).all()
+                    and (((c[:, 3] + pd[2]) % st[2]) == kx[k] % st[2]).all())
+    calls = []
+    orig = ops.gather_gemm_classed
+    monkeypatch.setattr(ops, "gather_gemm_classed", lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1])
+    x = dev(feat).requires_grad_(True)
+    ops.sparse_conv(x, w.requires_grad_(True), None, rb).backward(g)
+    assert calls and torch.equal(x.grad, plain)

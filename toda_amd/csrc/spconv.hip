@@ -141,6 +141,17 @@ __device__ __forceinline__ void gather_rows(__amdgpu_buffer_rsrc_t rsrc, int cg,
     }
 }
 
+// Data gradient of a STRIDED convolution.  Input site i reaches output o = (i + pad - k) / stride only for the kernel offsets k with
+// k = i + pad (mod stride) on every axis: a fine voxel has 1, 2, 4 or 8 CANDIDATE offsets out of 27 (27 / 8 on average - exactly
+// the pair density of these tables), fixed by the residues of its coordinates, and every candidate exists (the output set holds
+// every cell an input reaches).  Rows grouped by residue class (toda_rulebook_class_order) therefore form tiles whose work is a
+// short list of fully populated offsets; a wave whose 16 RT rows share one class walks only that list (classes and lists in
+// GatherClasses, passed by value), any other wave walks all K offsets as before.  Same sums in the same order: bit-identical.
+struct GatherClasses {
+    unsigned char count[8];       // candidate offsets per class (0 = no class information)
+    unsigned char k[8][27];       // ascending kernel-offset indices
+};
+
 // PF = software pipeline depth: with PF the neighbour ids of offset k+2 and the gathered rows of
 // offset k+1 are requested before the MFMAs of offset k issue, so a wave's HBM/L2 round trips run
 // under its own matrix work instead of relying on other waves to cover them.
@@ -148,7 +159,8 @@ template <int Q, int NT, int RT, bool PF, bool VEC>
 __global__ void __launch_bounds__(SC_BLOCK)
 gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                    const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
-                   float* __restrict__ out, int xcd_order, const int* __restrict__ order) {
+                   float* __restrict__ out, int xcd_order, const int* __restrict__ order,
+                   const unsigned char* __restrict__ cls_sorted, const GatherClasses classes) {
     const int lane = threadIdx.x & 63;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so give
     // each XCD one contiguous range of row tiles - canonical rows are spatial neighbours and gather
@@ -250,7 +262,20 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
             }
         }
     } else {
-        for (int k = 0; k < K; ++k) {
+        // class of this wave's rows (positions row0 .. row0 + 16 RT - 1 of the class-sorted order), if they all agree
+        int n_k = K;
+        const unsigned char* klist = nullptr;
+        if (cls_sorted) {
+            const int p = row0 + (lane & (16 * RT - 1) & 63);
+            const int c = cls_sorted[p < n_out ? p : n_out - 1];
+            const int c0 = __builtin_amdgcn_readfirstlane(c);
+            if (__all(c == c0 || p >= n_out) && classes.count[c0 & 7] > 0) {
+                klist = classes.k[c0 & 7];
+                n_k = classes.count[c0 & 7];
+            }
+        }
+        for (int t = 0; t < n_k; ++t) {
+            const int k = klist ? klist[t] : t;
             int src[RT];
             load_ids(k, src);
             bool hit[RT];
@@ -1240,6 +1265,115 @@ extern "C" int toda_rulebook_row_order(const int32_t* nbr, int n_out, int k_vol,
     return TODA_OK;
 }
 
+static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
+                            int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream,
+                            const unsigned char* cls_sorted = nullptr, const toda::GatherClasses* cls_table = nullptr);
+
+// ---- residue-class row order for the data gradient of strided convolutions (see GatherClasses) ------------------------------
+// Inside blocks of CLS_ROWS consecutive (spatially adjacent) rows the rows are regrouped by class with a stable counting sort:
+// one workgroup per block, a thread owns CLS_ROWS / 256 consecutive rows.
+namespace toda {
+constexpr int CLS_ROWS = 8192, CLS_PER = CLS_ROWS / 256;
+struct ClassGeom {
+    int stride[3], pad[3];
+};
+__global__ void __launch_bounds__(256)
+class_order_kernel(const int4* __restrict__ coords, int n, const ClassGeom gm, int32_t* __restrict__ order, unsigned char* __restrict__ cls_sorted) {
+    __shared__ int cnt[8][256 + 1];
+    const int base = blockIdx.x * CLS_ROWS, t = threadIdx.x;
+    unsigned char c[CLS_PER];
+    int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < CLS_PER; ++i) {
+        const int r = base + t * CLS_PER + i;
+        int cl = 0;
+        if (r < n) {
+            const int4 v = coords[r];            // (batch, z, y, x)
+            cl = (((v.y + gm.pad[0]) % gm.stride[0]) * gm.stride[1] + (v.z + gm.pad[1]) % gm.stride[1]) * gm.stride[2] + (v.w + gm.pad[2]) % gm.stride[2];
+            ++mine[cl & 7];
+        }
+        c[i] = (unsigned char)cl;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cnt[k][t] = mine[k];
+    __syncthreads();
+    if (t < 8) {          // exclusive scan of class t over the 256 threads (serial: 256 adds, once per 8192 rows)
+        int run = 0;
+        for (int j = 0; j < 256; ++j) {
+            const int v = cnt[t][j];
+            cnt[t][j] = run;
+            run += v;
+        }
+        cnt[t][256] = run;
+    }
+    __syncthreads();
+    int cls_base[8], run = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        cls_base[k] = run + cnt[k][t];
+        run += cnt[k][256];
+    }
+#pragma unroll
+    for (int i = 0; i < CLS_PER; ++i) {
+        const int r = base + t * CLS_PER + i;
+        if (r >= n) break;
+        const int k = c[i] & 7;
+        int pos = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q == k) pos = cls_base[q]++;
+        order[base + pos] = r;
+        cls_sorted[base + pos] = c[i];
+    }
+}
+
+// candidate lists of every class, ascending in the table's offset index (kz, ky, kx row-major)
+static int class_table(const int32_t* ksize, const int32_t* stride, const int32_t* pad, GatherClasses* out) {
+    const int n_class = stride[0] * stride[1] * stride[2];
+    if (n_class < 1 || n_class > 8 || ksize[0] * ksize[1] * ksize[2] > 27) return -1;
+    *out = GatherClasses{};
+    for (int rz = 0; rz < stride[0]; ++rz)
+        for (int ry = 0; ry < stride[1]; ++ry)
+            for (int rx = 0; rx < stride[2]; ++rx) {
+                const int c = (rz * stride[1] + ry) * stride[2] + rx;
+                int m = 0;
+                for (int kz = 0; kz < ksize[0]; ++kz)
+                    for (int ky = 0; ky < ksize[1]; ++ky)
+                        for (int kx = 0; kx < ksize[2]; ++kx)
+                            if (kz % stride[0] == rz && ky % stride[1] == ry && kx % stride[2] == rx)
+                                out->k[c][m++] = (unsigned char)((kz * ksize[1] + ky) * ksize[2] + kx);
+                out->count[c] = (unsigned char)m;
+            }
+    return 0;
+}
+}  // namespace toda
+
+extern "C" int toda_rulebook_class_order(const int32_t* in_coords, int n_in, const int32_t* stride, const int32_t* padding, int32_t* order,
+                                         unsigned char* cls_sorted, void* stream) {
+    TODA_CHECK_ARG(in_coords && stride && padding && order && cls_sorted && n_in >= 0, "rulebook_class_order: null argument");
+    ClassGeom gm;
+    for (int a = 0; a < 3; ++a) {
+        TODA_CHECK_ARG(stride[a] >= 1 && stride[a] <= 2 && padding[a] >= 0, "rulebook_class_order: stride 1 or 2 per axis (got %d)", stride[a]);
+        gm.stride[a] = stride[a], gm.pad[a] = padding[a];
+    }
+    if (n_in == 0) return TODA_OK;
+    hipLaunchKernelGGL(class_order_kernel, dim3(cdiv(n_in, CLS_ROWS)), dim3(256), 0, (hipStream_t)stream, (const int4*)in_coords, n_in, gm, order,
+                       cls_sorted);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_spconv_gather_gemm_classed(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
+                                               int c_produce, const float* bias, float* out, const int32_t* order,
+                                               const unsigned char* cls_sorted, const int32_t* ksize, const int32_t* stride,
+                                               const int32_t* padding, void* stream) {
+    TODA_CHECK_ARG(order && cls_sorted && ksize && stride && padding, "gather_gemm_classed: null argument");
+    TODA_CHECK_ARG(ksize[0] * ksize[1] * ksize[2] == k_vol, "gather_gemm_classed: kernel size does not match the table's %d offsets", k_vol);
+    GatherClasses table;
+    TODA_CHECK_ARG(class_table(ksize, stride, padding, &table) == 0, "gather_gemm_classed: needs <= 8 residue classes and <= 27 offsets");
+    return gather_gemm_impl(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, nullptr, stream, cls_sorted, &table);
+}
+
 // ---- optional per-launch timestamps of the gather-GEMM kernels -------------------------------
 // hipExtLaunchKernelGGL stamps a start / stop event pair on the kernel dispatch itself, so the
 // elapsed time is the kernel's own duration (what rocprofv3 --kernel-trace reports).  Events
@@ -1300,8 +1434,7 @@ static bool gg_stats_supported(int c_gather, int c_produce) {
 }
 }  // namespace toda
 
-static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
-                            int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream);
+
 
 extern "C" int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
                                                int n_out, int k_vol, int c_produce, const float* bias, float* out,
@@ -1327,7 +1460,11 @@ extern "C" int toda_spconv_gather_gemm_stats(const float* in, int n_in, int c_ga
 }
 
 static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
-                            int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream) {
+                            int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream,
+                            const unsigned char* cls_sorted, const toda::GatherClasses* cls_table) {
+    toda::GatherClasses classes = {};
+    if (cls_sorted && cls_table) classes = *cls_table;
+    else cls_sorted = nullptr;
     TODA_CHECK_ARG(c_gather >= 1 && c_gather <= 128 && c_produce >= 1 && c_produce <= 128,
                    "gather_gemm: channels must be in [1,128] (gather %d, produce %d)", c_gather, c_produce);
     TODA_CHECK_ARG(n_out >= 0 && n_in >= 0 && k_vol >= 1, "gather_gemm: bad sizes");
@@ -1349,7 +1486,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);
     const bool vec_ok = (c_gather & 3) == 0;
     static const int env_lds88 = getenv("TODA_GG_LDS88") ? atoi(getenv("TODA_GG_LDS88")) : 3;  // 1: RT=1 single-buffer LDS (0.67 ms), 2: RT=2 (0.76), 0: registers-only RT=2 (0.70) on 97.5k x 27 x 128 x 128
-    if (env_lds88 && vec_ok && Q == 8 && NT == 8) {
+    if (env_lds88 && vec_ok && Q == 8 && NT == 8 && !cls_sorted) {
         if (env_lds88 == 2)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)),
                                dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats);
@@ -1369,7 +1506,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     // OFF by default: measured 0.502 ms against 0.498 ms for the per-offset barrier kernel on the 389.5k-row level - the
     // barrier imbalance it removes is not what holds the matrix pipe at 70 %.
     static const int env_stage = getenv("TODA_GG_STAGE") ? atoi(getenv("TODA_GG_STAGE")) : 0;
-    if (env_stage && vec_ok && order == nullptr && Q == 4 && NT == 4 && c_gather == 64 && c_produce == 64 && n_out >= 8192) {
+    if (env_stage && !cls_sorted && vec_ok && order == nullptr && Q == 4 && NT == 4 && c_gather == 64 && c_produce == 64 && n_out >= 8192) {
         const int blocks = cdiv(cdiv(n_out, 32), 8);
         GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_stage_kernel<4, 4, 3, 512>), dim3(blocks), dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out,
                   k_vol, c_produce, bias, out, stats);
@@ -1388,7 +1525,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     // deep or not.  The register gathers of the 16 resident waves of gather_gemm_lds_kernel re-hit L1 for the rows that
     // neighbouring offsets share and keep more requests in flight.
     static const int env_ws = getenv("TODA_GG_WS") ? atoi(getenv("TODA_GG_WS")) : 0;
-    if (env_ws && !stats && vec_ok && order == nullptr && Q == 4 && NT == 4 && c_gather == 64 && n_out >= 8192) {
+    if (env_ws && !cls_sorted && !stats && vec_ok && order == nullptr && Q == 4 && NT == 4 && c_gather == 64 && n_out >= 8192) {
         static int n_cu_ws = 0;
         if (!n_cu_ws) {
             int dev = 0;
@@ -1405,7 +1542,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     }
     // narrow layers: all K offsets of the packed weights resident in LDS (<= 108 KiB), barrier-free offset loop
     static const int env_wres = getenv("TODA_GG_WRES") ? atoi(getenv("TODA_GG_WRES")) : 0;   // measured slower than the per-offset LDS slices (32->32 @ 682k rows 0.356 vs 0.321 ms, 16->32 0.234 vs 0.168): off
-    if (env_wres && !stats && vec_ok && order == nullptr && Q <= 2 && NT <= 2 && k_vol <= 27 && n_out >= 4096) {
+    if (env_wres && !cls_sorted && !stats && vec_ok && order == nullptr && Q <= 2 && NT <= 2 && k_vol <= 27 && n_out >= 4096) {
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -1429,7 +1566,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
         return TODA_OK;
     }
     static const int env_pfl = getenv("TODA_GG_LDS_PF") ? atoi(getenv("TODA_GG_LDS_PF")) : 0;   // 64 -> 64: register-pipelined gathers (experiment)
-    if ((env_lds || stats) && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
+    if ((env_lds || stats) && !cls_sorted && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
 #define GL(QQ, NN, RR)                                                                                                   \
     if (env_pfl && QQ == 4 && NN == 4 && RR == 2)                                                                        \
         GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<4, 4, 2, true, true, SC_BLOCK, true>),                          \
@@ -1481,7 +1618,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
 #define GGV(QQ, NN, RR, PP, VV)                                                                                       \
     GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP, VV>),                                       \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, \
-                       n_out, k_vol, c_produce, bias, out, env_xcd, order)
+                       n_out, k_vol, c_produce, bias, out, env_xcd, order, cls_sorted, classes)
 #define GG_PF(QQ, NN, RR)        \
     if (env_pf) {                \
         GG(QQ, NN, RR, true);    \

@@ -33,6 +33,8 @@ SIGNATURES = {
     "toda_spconv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_rulebook_row_order": (_i, [_vp, _i, _i, _vp, _vp]),
     "toda_spconv_gather_gemm_ordered": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "toda_rulebook_class_order": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "toda_spconv_gather_gemm_classed": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "toda_spconv_gather_gemm_stats_supported": (_i, [_i, _i]),
     "toda_spconv_gather_gemm_stats_doubles": (_sz, [_i, _i]),
     "toda_spconv_gather_gemm_stats": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),

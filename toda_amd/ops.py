@@ -130,6 +130,8 @@ class Rulebook:
         self.pair_cnt = pair_cnt  # [K] int32 on device
         self.geom = geom
         self._order = {}
+        self.in_indices = None    # strided conv: coordinates of its input sites (rows of the data-gradient table)
+        self._class_order = None
 
     def order_for(self, nbr):
         """Mask-sorted visiting order of `nbr`'s rows (built once per table, reused by every conv and dgrad on it).
@@ -140,6 +142,24 @@ class Rulebook:
         if key not in self._order:
             self._order[key] = rulebook_row_order(nbr)
         return self._order[key]
+
+    def class_order(self):
+        """(order, cls_sorted) of the data-gradient table of a strided convolution: its rows regrouped by the residue class of
+        (coordinate + padding) mod stride, which fixes the 1..8 kernel offsets a row can have (toda_rulebook_class_order).
+        None when not applicable."""
+        if (not CLASS_DGRAD or self.kind != "conv" or self.in_indices is None or self.k_vol > 27 or self.k_vol < 2
+                or self.n_in < CLASS_DGRAD_MIN_ROWS or any(int(v) not in (1, 2) for v in self.geom["stride"])):
+            return None
+        if self._class_order is None:
+            lib = L.load()
+            dev = self.in_indices.device
+            order = torch.empty((self.n_in,), dtype=torch.int32, device=dev)
+            cls = torch.empty((self.n_in,), dtype=torch.uint8, device=dev)
+            st, pd = L.host_i32(self.geom["stride"]), L.host_i32(self.geom["padding"])
+            L.check(lib.toda_rulebook_class_order(L.ptr(self.in_indices), self.n_in, L.hptr(st), L.hptr(pd), L.ptr(order), L.ptr(cls), L.stream()),
+                    "toda_rulebook_class_order")
+            self._class_order = (order, cls)
+        return self._class_order
 
     def num_pairs(self):
         return int(self.pair_cnt.sum().item())
@@ -203,6 +223,7 @@ def build_conv_rulebook(indices, batch, shape, ksize, stride, padding):
                                 L.hptr(sho), L.ptr(gi_out.buf), n_out, L.ptr(o2i), L.ptr(i2o), L.ptr(cnt), L.stream())
     L.check(rc, "toda_rulebook_conv")
     rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=st, padding=pd)
+    rb.in_indices = indices
     return idx_out, out_shape, rb, gi_out
 
 
@@ -275,6 +296,7 @@ def build_index_plan(indices, batch, shape, steps):
                                         L.ptr(cnt), L.stream())
             L.check(rc, "toda_rulebook_conv")
             rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=sd, padding=pd)
+            rb.in_indices = cur["idx"]
             out[st["key"]] = {"kind": "conv", "rb": rb, "n_in": n_in, "out_indices": nxt["idx"],
                               "out_shape": nxt["shape"], "gi": nxt["gi"]}
             li += 1
@@ -359,6 +381,18 @@ def gather_gemm(feat, wp, nbr, c_produce, bias=None, order=None):
     return out
 
 
+def gather_gemm_classed(feat, wp, nbr, c_produce, order, cls_sorted, ksize, stride, padding):
+    """Data gradient of a strided convolution over its class-sorted rows (Rulebook.class_order)."""
+    lib = L.load()
+    K, n_out = nbr.shape
+    out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
+    ks, st, pd = L.host_i32(ksize), L.host_i32(stride), L.host_i32(padding)
+    rc = lib.toda_spconv_gather_gemm_classed(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce, None,
+                                             L.ptr(out), L.ptr(order), L.ptr(cls_sorted), L.hptr(ks), L.hptr(st), L.hptr(pd), L.stream())
+    L.check(rc, "toda_spconv_gather_gemm_classed")
+    return out
+
+
 def wgrad(feat, dout, nbr, wshape):
     lib = L.load()
     K, n_out = nbr.shape
@@ -377,6 +411,9 @@ import os as _os
 # mask-sorted row order for gather-GEMM: opt-in.  Measured on C3 it LOSES on the SubM layers (64->64 @ 389k rows 0.536 ->
 # 0.562 ms, 32->32 @ 682k 0.321 -> 0.366 ms: rows of a tile are no longer x-neighbours, so their gathers stop sharing
 # input rows in L1/L2) and wins only on strided-conv dgrads (64->32 @ 682k 0.345 -> 0.274 ms); the sort costs 0.13 ms/table.
+# data gradient of strided convolutions over residue-class-sorted rows (1..8 candidate offsets per row instead of 27)
+CLASS_DGRAD = _os.environ.get("TODA_CLASS_DGRAD", "1") == "1"
+CLASS_DGRAD_MIN_ROWS = int(_os.environ.get("TODA_CLASS_DGRAD_MIN_ROWS", "4096"))
 ROW_ORDER = _os.environ.get("TODA_ROW_ORDER", "0") == "1"
 ROW_ORDER_MIN_ROWS = int(_os.environ.get("TODA_ROW_ORDER_MIN_ROWS", "4096"))
 WGRAD_ON_SIDE_STREAM = _os.environ.get("TODA_WGRAD_STREAM", "0") == "1"  # measured: no gain (each kernel already fills the chip)
@@ -434,7 +471,11 @@ class _SparseConv(torch.autograd.Function):
             need_w = False
         if need_d:
             wp_t = ctx.wp_bwd if ctx.wp_bwd is not None else pack_weight(weight, True, rb.flip_bwd)
-            gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None, order=rb.order_for(rb.nbr_bwd))
+            co = rb.class_order()
+            if co is not None:
+                gfeat = gather_gemm_classed(gout, wp_t, rb.nbr_bwd, weight.shape[-1], co[0], co[1], rb.ksize, rb.geom["stride"], rb.geom["padding"])
+            else:
+                gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None, order=rb.order_for(rb.nbr_bwd))
         if need_w:
             gw = wgrad(features, gout, rb.nbr_fwd, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -23,6 +23,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1385,9 +1386,15 @@ struct LaunchTimer {
     int used = 0;
     bool on = false;
 };
+// The one piece of process-wide state of the library (bench instrumentation only; off unless toda_timing_begin was called):
+// guarded by a mutex so that launches from several host threads each get their own event pair.  Durations are only
+// meaningful for launches that went to ONE stream between begin and end (include/toda.h says so).
 static LaunchTimer g_timer;
+static std::mutex g_timer_mu;
 static inline void timer_next(hipEvent_t* start, hipEvent_t* stop) {
     *start = *stop = nullptr;
+    if (!g_timer.on) return;      // unlocked fast path: the flag only changes in toda_timing_begin / _end
+    std::lock_guard<std::mutex> lock(g_timer_mu);
     if (!g_timer.on || 2 * (g_timer.used + 1) > (int)g_timer.ev.size()) return;
     *start = g_timer.ev[2 * g_timer.used];
     *stop = g_timer.ev[2 * g_timer.used + 1];
@@ -1404,6 +1411,7 @@ static inline void timer_next(hipEvent_t* start, hipEvent_t* stop) {
 
 extern "C" int toda_timing_begin(int capacity) {
     TODA_CHECK_ARG(capacity > 0 && capacity <= (1 << 20), "timing_begin: capacity in (0, 2^20]");
+    std::lock_guard<std::mutex> lock(toda::g_timer_mu);
     for (hipEvent_t e : g_timer.ev) (void)hipEventDestroy(e);
     g_timer.ev.assign((size_t)2 * capacity, nullptr);
     for (auto& e : g_timer.ev) TODA_HIP(hipEventCreate(&e));
@@ -1413,6 +1421,7 @@ extern "C" int toda_timing_begin(int capacity) {
 }
 
 extern "C" int toda_timing_end(float* ms_out, int cap, int* n_out) {
+    std::lock_guard<std::mutex> lock(toda::g_timer_mu);
     g_timer.on = false;
     const int n = g_timer.used < cap ? g_timer.used : cap;
     for (int i = 0; i < n; ++i) {

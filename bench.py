@@ -38,7 +38,7 @@ from toda_amd import ops  # noqa: E402
 from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file  # noqa: E402
 from toda_amd.pcdet.datasets import SyntheticLidarDataset  # noqa: E402
 from toda_amd.pcdet.models import build_network, voxelize_on_gpu  # noqa: E402
-from toda_amd.tools.train_utils.optimization import build_optimizer, build_scheduler  # noqa: E402
+from toda_amd.tools.train_utils.optimization import build_optimizer, build_scheduler, clip_grad_norm_  # noqa: E402
 
 WORKLOADS = {
     # name: (yaml, samples per GPU, description)
@@ -262,7 +262,7 @@ def run_gpu(args, rank, world, device):
             if prefetch is not None:
                 prefetch.kick()          # next batch's index work goes to the side stream now, under this step's backward
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, clip)
+        clip_grad_norm_(params, clip)
         optimizer.step()
         if not pair:
             net.update_global_step()
@@ -482,7 +482,7 @@ def cpu_baseline(cfg, workload, n_scenes=5):
                 else:
                     loss = fn(model, dict(batch)).loss
                 loss.backward()
-                torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
+                clip_grad_norm_(list(model.parameters()), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
                 optimizer.step()
             say(f"step {i + 1}/{len(batches)} done after {time.perf_counter() - t0:.1f} s")
         dt = time.perf_counter() - t0 + mix_s

@@ -240,3 +240,28 @@ def test_sync_batchnorm_is_never_taken_by_the_fused_row_path():
 
     assert not ops.bn_rows_supported(FakeCuda(), conv.bn1)
     assert ops.bn_rows_supported(FakeCuda(), torch.nn.BatchNorm1d(16, eps=1e-3, momentum=0.01))
+
+
+def test_clip_grad_norm_matches_torch():
+    """train_utils.optimization.clip_grad_norm_ against torch.nn.utils.clip_grad_norm_ (reference train_utils.py:57): same total
+    norm, same clipped gradients, with and without clipping taking effect, parameters without a gradient skipped."""
+    import copy
+
+    from toda_amd.tools.train_utils.optimization import clip_grad_norm_
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    net(torch.randn(4, 7))[:, 0].sum().backward()
+    net[3].weight.grad = None
+    for max_norm in (0.05, 1e6):
+        a, b = copy.deepcopy(net), copy.deepcopy(net)
+        for (_, p), (_, q), (_, r) in zip(net.named_parameters(), a.named_parameters(), b.named_parameters()):
+            q.grad = None if p.grad is None else p.grad.clone()
+            r.grad = None if p.grad is None else p.grad.clone()
+        ta = clip_grad_norm_(list(a.parameters()), max_norm)
+        tb = torch.nn.utils.clip_grad_norm_(b.parameters(), max_norm)
+        assert torch.equal(ta, tb)
+        for q, r in zip(a.parameters(), b.parameters()):
+            assert (q.grad is None) == (r.grad is None)
+            if q.grad is not None:
+                assert torch.equal(q.grad, r.grad)

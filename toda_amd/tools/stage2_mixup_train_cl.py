@@ -10,7 +10,7 @@ import time
 
 import torch
 import torch.nn as nn
-from torch.nn.utils import clip_grad_norm_
+from .train_utils.optimization import clip_grad_norm_
 
 from ..pcdet.config import cfg
 from ..pcdet import datasets as dataset_registry

@@ -156,3 +156,21 @@ def build_scheduler(optimizer, total_iters_each_epoch, total_epochs, last_epoch,
         return max(f, optim_cfg.LR_CLIP / optim_cfg.LR)
 
     return torch.optim.lr_scheduler.LambdaLR(optimizer, factor, last_epoch=last_epoch), None
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0):
+    """torch.nn.utils.clip_grad_norm_ (reference tools/train_utils/train_utils.py:57) for gradients that live on ONE device, in
+    four launches and no per-parameter Python work: torch's version calls `.to(device)` on each of the ~110 per-tensor norms
+    (2 ms of host time per step here).  Same operations in the same order: foreach norms -> norm of the stacked norms ->
+    coefficient max_norm / (total + 1e-6) clamped to 1 -> foreach multiply.  Returns the total norm (a 0-d tensor)."""
+    parameters = [parameters] if torch.is_tensor(parameters) else list(parameters)
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.0)
+    if any(g.device != grads[0].device or g.dtype != grads[0].dtype for g in grads):
+        return torch.nn.utils.clip_grad_norm_([p for p in parameters if p.grad is not None], max_norm, norm_type)
+    norms = torch._foreach_norm(grads, norm_type)
+    total = torch.linalg.vector_norm(torch.stack(norms), norm_type)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    torch._foreach_mul_(grads, coef)
+    return total

@@ -13,7 +13,7 @@ import time
 
 import torch
 import torch.distributed as dist
-from torch.nn.utils import clip_grad_norm_
+from .optimization import clip_grad_norm_
 
 from ...pcdet.utils import common_utils
 

@@ -134,7 +134,15 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Raw handle of torch's current HIP stream on the current device.  (torch.cuda.current_stream() builds a Stream object
+    and resolves the device through three Python layers: ~9 us per call, ~200 calls per training step.)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -773,7 +773,7 @@ def conv3x3_transform_weight(weight, mode):
 
 def _conv3x3_workspace(device):
     """Per (device, stream) scratch of the stream-K work split: zeroed once, the kernel leaves its flags zero."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, L.stream())
     ws = _WINO_CACHE.get(key)
     if ws is None:
         ws = _WINO_CACHE[key] = torch.zeros((L.load().toda_conv3x3_workspace_bytes(),), dtype=torch.uint8, device=device)

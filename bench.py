@@ -122,6 +122,14 @@ class KernelTimer:
             return self._orig_stats(feat, wp, nbr, c_produce, bias)
 
         ops.gather_gemm_with_stats = labelled_stats
+        self._orig_classed = ops.gather_gemm_classed        # data gradient of the strided convs (same dispatch-stamped launches)
+
+        def labelled_classed(feat, wp, nbr, c_produce, *rest):
+            if self._enabled and len(self.records) < self.CAPACITY:
+                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+            return self._orig_classed(feat, wp, nbr, c_produce, *rest)
+
+        ops.gather_gemm_classed = labelled_classed
 
     @property
     def enabled(self):
@@ -139,6 +147,10 @@ class KernelTimer:
             seen = ctypes.c_int(0)
             L.check(lib.toda_timing_end(ctypes.cast(buf, ctypes.c_void_p), self.CAPACITY, ctypes.cast(ctypes.pointer(seen), ctypes.c_void_p)),
                     "toda_timing_end")
+            # every dispatch the library stamped must have been labelled here, in order: a gather-GEMM entry point that is not
+            # wrapped above would shift all following durations onto the wrong shapes
+            assert min(seen.value, self.CAPACITY) == len(self.records), \
+                f"KernelTimer: {seen.value} timed launches but {len(self.records)} labelled ones"
             self.ms = list(buf[:min(seen.value, self.CAPACITY, len(self.records))])
         self._enabled = bool(on)
 

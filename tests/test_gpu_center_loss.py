@@ -90,3 +90,67 @@ def test_center_head_get_loss_fused_equals_operator_path(monkeypatch):
     for k, v in out["0"][1].items():
         assert abs(out["1"][1][k] - v) < 1e-5 * max(1.0, abs(v)), k
     assert float((out["1"][2] - out["0"][2]).abs().max()) < 1e-4 * float(out["0"][2].abs().max())
+
+
+def test_multi_group_center_head_with_velocity_branch_kernels_equal_operator_path(monkeypatch):
+    """A nuScenes-style CenterHead (two head groups, HEAD_ORDER with a `vel` branch, 64 shared channels, no conv bias before the
+    norms) through the hand-written path (Winograd shared conv, fused 64 -> 5 x 64 hidden layer, narrow output convs, GPU target
+    assignment, fused loss) and through the plain torch operators on the same weights and batch: predictions, loss, tb_dict, the
+    input gradient and every parameter gradient."""
+    import copy
+
+    import numpy as np
+
+    from toda_amd import ops
+    from toda_amd.pcdet.config import AttrDict
+    from toda_amd.pcdet.models.dense_heads import CenterHead
+
+    names = ["car", "truck", "pedestrian"]
+    order = ["center", "center_z", "dim", "rot", "vel"]
+    cfg = dict(CLASS_AGNOSTIC=False, CLASS_NAMES_EACH_HEAD=[["car", "truck"], ["pedestrian"]], SHARED_CONV_CHANNEL=64, USE_BIAS_BEFORE_NORM=False,
+               NUM_HM_CONV=2,
+               SEPARATE_HEAD_CFG=dict(HEAD_ORDER=order, HEAD_DICT=dict(center=dict(out_channels=2, num_conv=2), center_z=dict(out_channels=1, num_conv=2),
+                                                                       dim=dict(out_channels=3, num_conv=2), rot=dict(out_channels=2, num_conv=2),
+                                                                       vel=dict(out_channels=2, num_conv=2))),
+               TARGET_ASSIGNER_CONFIG=dict(FEATURE_MAP_STRIDE=8, NUM_MAX_OBJS=100, GAUSSIAN_OVERLAP=0.1, MIN_RADIUS=2),
+               LOSS_CONFIG=dict(LOSS_WEIGHTS=dict(cls_weight=1.0, loc_weight=0.25, code_weights=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2])),
+               POST_PROCESSING=dict(SCORE_THRESH=0.1, POST_CENTER_LIMIT_RANGE=[-60, -60, -10, 60, 60, 10], MAX_OBJ_PER_SAMPLE=100,
+                                    NMS_CONFIG=dict(NMS_TYPE="nms_gpu", NMS_THRESH=0.2, NMS_PRE_MAXSIZE=1000, NMS_POST_MAXSIZE=83)))
+    torch.manual_seed(7)
+    head = CenterHead(AttrDict(cfg), 96, 3, names, np.array([512, 512, 40]), [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.2, 0.2, 0.2],
+                      predict_boxes_when_training=False).cuda().train()
+    ref = copy.deepcopy(head)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 96, 64, 64), generator=g).cuda()
+    gt = torch.zeros((2, 12, 10))
+    gt[:, :, 0:2] = torch.rand((2, 12, 2), generator=g) * 90 - 45
+    gt[:, :, 2] = torch.rand((2, 12), generator=g) * 2 - 2
+    gt[:, :, 3:6] = torch.rand((2, 12, 3), generator=g) * 3 + 0.5
+    gt[:, :, 6] = torch.rand((2, 12), generator=g) * 6.28 - 3.14
+    gt[:, :, 7:9] = torch.randn((2, 12, 2), generator=g)
+    gt[:, :, 9] = torch.randint(1, 4, (2, 12), generator=g).float()
+    gt[1, 9:] = 0                                                    # padding rows
+    gt = gt.cuda()
+
+    out = {}
+    for mode, net in (("kernels", head), ("operators", ref)):
+        if mode == "operators":
+            monkeypatch.setattr(ops, "DENSE_CONV", "miopen")
+            monkeypatch.setenv("TODA_FUSED_LOSS", "0")
+        xi = x.clone().requires_grad_(True)
+        net({"spatial_features_2d": xi, "gt_boxes": gt.clone(), "batch_size": 2})
+        preds = [{k: v.detach().clone() for k, v in d.items()} for d in net.forward_ret_dict["pred_dicts"]]
+        loss, tb = net.get_loss()
+        loss.backward()
+        out[mode] = (preds, float(loss.detach()), {k: float(v) for k, v in tb.items()}, xi.grad.clone())
+    for da, db in zip(out["kernels"][0], out["operators"][0]):
+        for k in db:
+            assert float((da[k] - db[k]).abs().max()) < 2e-4 * max(1.0, float(db[k].abs().max())), k
+    assert abs(out["kernels"][1] - out["operators"][1]) < 1e-4 * max(1.0, abs(out["operators"][1]))
+    for k, v in out["operators"][2].items():
+        assert abs(out["kernels"][2][k] - v) < 1e-4 * max(1.0, abs(v)), k
+    assert float((out["kernels"][3] - out["operators"][3]).abs().max()) < 2e-3 * float(out["operators"][3].abs().max())
+    for (n, p), (_, q) in zip(head.named_parameters(), ref.named_parameters()):
+        assert float((p.grad - q.grad).abs().max()) <= 2e-3 * float(q.grad.abs().max()) + 1e-6, n
+    for (n, p), (_, q) in zip(head.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(p.float(), q.float(), rtol=1e-4, atol=1e-6), n

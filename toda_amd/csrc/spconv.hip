@@ -156,7 +156,7 @@ struct GatherClasses {
 // PF = software pipeline depth: with PF the neighbour ids of offset k+2 and the gathered rows of
 // offset k+1 are requested before the MFMAs of offset k issue, so a wave's HBM/L2 round trips run
 // under its own matrix work instead of relying on other waves to cover them.
-template <int Q, int NT, int RT, bool PF, bool VEC>
+template <int Q, int NT, int RT, bool PF, bool VEC, bool CLS = false>
 __global__ void __launch_bounds__(SC_BLOCK)
 gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                    const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
@@ -263,20 +263,7 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
             }
         }
     } else {
-        // class of this wave's rows (positions row0 .. row0 + 16 RT - 1 of the class-sorted order), if they all agree
-        int n_k = K;
-        const unsigned char* klist = nullptr;
-        if (cls_sorted) {
-            const int p = row0 + (lane & (16 * RT - 1) & 63);
-            const int c = cls_sorted[p < n_out ? p : n_out - 1];
-            const int c0 = __builtin_amdgcn_readfirstlane(c);
-            if (__all(c == c0 || p >= n_out) && classes.count[c0 & 7] > 0) {
-                klist = classes.k[c0 & 7];
-                n_k = classes.count[c0 & 7];
-            }
-        }
-        for (int t = 0; t < n_k; ++t) {
-            const int k = klist ? klist[t] : t;
+        auto offset = [&](int k) {
             int src[RT];
             load_ids(k, src);
             bool hit[RT];
@@ -286,10 +273,28 @@ gather_gemm_kernel(const float* __restrict__ in, int n_in, int cg, const float* 
                 hit[rt] = __any(src[rt] >= 0);
                 any = any || hit[rt];
             }
-            if (!any) continue;  // wave-uniform skip of an empty offset
+            if (!any) return;  // wave-uniform skip of an empty offset
             f32x4 a[RT][Q];
             gather_rows<Q, RT, VEC>(in_rsrc, cg, g, src, a);
             mma(k, a, hit);
+        };
+        // CLS (separate instantiation, so that the plain kernel compiles as it always did): class of this wave's rows (positions
+        // row0 .. row0 + 16 RT - 1 of the class-sorted order); if they all agree the wave walks that class's offset list only
+        const unsigned char* klist = nullptr;
+        int n_k = 0;
+        if constexpr (CLS) {
+            const int p = row0 + (lane & (16 * RT - 1) & 63);
+            const int c = cls_sorted[p < n_out ? p : n_out - 1];
+            const int c0 = __builtin_amdgcn_readfirstlane(c);
+            if (__all(c == c0 || p >= n_out) && classes.count[c0 & 7] > 0) {
+                klist = classes.k[c0 & 7];
+                n_k = classes.count[c0 & 7];
+            }
+        }
+        if (CLS && klist) {
+            for (int t = 0; t < n_k; ++t) offset(klist[t]);
+        } else {
+            for (int k = 0; k < K; ++k) offset(k);
         }
     }
 
@@ -1625,9 +1630,14 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
 #define GG(QQ, NN, RR, PP)                                                                                            \
     GGV(QQ, NN, RR, PP, true)
 #define GGV(QQ, NN, RR, PP, VV)                                                                                       \
-    GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP, VV>),                                       \
+    if (cls_sorted && !(PP) && (VV))                                                                                  \
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, false, true, true>),                                 \
+                  dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, \
+                  n_out, k_vol, c_produce, bias, out, env_xcd, order, cls_sorted, classes);                           \
+    else                                                                                                              \
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_kernel<QQ, NN, RR, PP, VV>),                                       \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, \
-                       n_out, k_vol, c_produce, bias, out, env_xcd, order, cls_sorted, classes)
+                       n_out, k_vol, c_produce, bias, out, env_xcd, order, nullptr, classes)
 #define GG_PF(QQ, NN, RR)        \
     if (env_pf) {                \
         GG(QQ, NN, RR, true);    \

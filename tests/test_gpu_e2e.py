@@ -34,7 +34,12 @@ def _freeze_bn(model):
 @pytest.mark.parametrize("bn_train", [True, False])
 @pytest.mark.parametrize("name,rng_xy", [("centerpoint_voxel_waymo", 16.0), ("toda_stage1_centerpoint_res", 14.4)])
 def test_detector_loss_and_grads_match_oracle_backend(name, rng_xy, bn_train):
-    """bn_train=False (BN uses running statistics): gradients must agree to 2e-3.
+    """bn_train=False (BN uses running statistics): gradients must agree to 2e-3 globally and 1e-2 per parameter.  (Per parameter
+    the comparison is at the mercy of single ReLU decisions: with the untrained mean 0 / var 1 statistics the activations shrink
+    layer by layer to ~1e-12 at the BEV neck, where a rounding difference of 1e-16 - the library's stride-2 convolution is not
+    run-to-run reproducible at that level - flips a mask bit; 2 flipped elements of 819 200 were measured to move a neck gradient by
+    1e-2 of its maximum and a bias gradient by 3e-3 of its floored norm between two runs of the SAME code.  With the statistics
+    calibrated to the batch the activations are O(1) and the whole comparison sits at the train-mode floor, 5e-3..8e-3 globally.)
     bn_train=True: the loss must agree to 1e-3, but gradients are compared loosely (3e-2): a
     train-mode BatchNorm behind the nearly constant heat-map gradient at initialisation cancels
     ~99.99 % of dy (dx = dy - mean(dy) - xhat*mean(dy*xhat)), so fp32 rounding is amplified ~1e4x.
@@ -71,6 +76,8 @@ def test_detector_loss_and_grads_match_oracle_backend(name, rng_xy, bn_train):
     tol = 3e-2 if bn_train else 2e-3
     global_err = float(d_all.norm() / g_all.norm())
     assert global_err < tol, f"global relative grad error {global_err:.2e}"
+    if not bn_train:
+        tol = 1e-2          # per parameter: see the docstring
     floor = 1e-3 * float(g_all.norm())  # parameters with (near) zero gradient are judged on the global scale
     worst = 0.0
     for n, p, q in grads:

@@ -999,7 +999,7 @@ gather_gemm_stage_kernel(const float* __restrict__ in, int n_in, int cg, const f
 // COOP (128-channel sides): the 4 waves of a block walk the SAME pairs and each owns one (MTB x NTB)-tile quarter of
 // the 8 x 8-tile weight block - operands of the quarters that share a row half hit in L1, accumulators stay at 64
 // registers (4 waves / SIMD instead of 1 for a single 8 x 8 wave) and no cross-wave fold is needed.
-template <int MTB, int NTB, bool COOP = false>
+template <int MTB, int NTB, bool COOP = false, bool EXACT = false>
 __global__ void __launch_bounds__(SC_BLOCK, (MTB * NTB <= 16) ? WG_WAVES : 1)
 wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __restrict__ dout, int cout,
              const int* __restrict__ nbr, int n_out, int K, int rows_per_chunk, int MT, int NT, int nsub_n,
@@ -1038,27 +1038,30 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
             const int pc = ok ? p : d;  // any valid queue slot
             const unsigned ia = ((unsigned)qi[pc] * (unsigned)cin + (unsigned)(MT * ii + m0)) * 4u;
             const unsigned ib = ((unsigned)qo[pc] * (unsigned)cout + (unsigned)(NT * ii + n0)) * 4u;
-            if (exact_a && MTB % 4 == 0) {
+            // EXACT (channel counts = 16 x tiles, >= 4 tiles per block: every 64 / 128-channel layer): the 16-byte path is chosen at
+            // compile time.  As a run-time branch the two load forms share destination registers and hipcc puts an
+            // s_waitcnt vmcnt(3) in front of every 16-byte load: four loads in flight per round instead of eight.
+            if (EXACT || (exact_a && MTB % 4 == 0)) {
 #pragma unroll
                 for (int m4 = 0; m4 < MTB; m4 += 4) {
                     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? ia + 4u * m4 : OOB, 0, 0));
 #pragma unroll
                     for (int m = 0; m < 4; ++m) a[t][m4 + m] = v[m];
                 }
-            } else {
+            } else if constexpr (!EXACT) {
 #pragma unroll
                 for (int m = 0; m < MTB; ++m)
                     a[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                   in_rsrc, (ok && MT * ii + m0 + m < cin) ? ia + 4u * m : OOB, 0, 0));
             }
-            if (exact_b && NTB % 4 == 0) {
+            if (EXACT || (exact_b && NTB % 4 == 0)) {
 #pragma unroll
                 for (int n4 = 0; n4 < NTB; n4 += 4) {
                     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? ib + 4u * n4 : OOB, 0, 0));
 #pragma unroll
                     for (int n = 0; n < 4; ++n) b[t][n4 + n] = v[n];
                 }
-            } else {
+            } else if constexpr (!EXACT) {
 #pragma unroll
                 for (int n = 0; n < NTB; ++n)
                     b[t][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -1162,10 +1165,14 @@ wgrad_reduce_kernel(const float* __restrict__ slab, int chunks, long long elems,
 // Row chunks per offset: every (chunk, offset) pair is a workgroup and a slab the reduce kernel reads back.  Measured on the
 // C3 / C5 levels: the >= 64-channel kernels (4 waves / SIMD resident) run best with at most 48 chunks (64x64 @ 389k rows 0.606 ->
 // 0.587 ms, @ 227k 0.373 -> 0.338 ms), the 32-channel ones (7 waves / SIMD) with up to 144 (32x32 @ 682k 0.418 -> 0.388 ms).
-static void wgrad_plan(int n_out, int cin, int cout, int* chunks, int* rows_per_chunk) {
+// The grid is (chunks, K, sub-blocks): with few offsets (conv_out's 3 x 1 x 1 kernel) 48 chunks leave most CUs without a block
+// (48 x 3 = 144 blocks); measured on the K = 3 layers (64 -> 128 @ 111 k rows / 128 -> 128 @ 91 k rows): 48 chunks 0.137 / 0.271 ms,
+// 96 0.103 / 0.165, 144 0.118 / 0.168, 216 0.141 / 0.190, 432 0.226 / 0.214 (the slab fold grows with the chunk count).
+static void wgrad_plan(int n_out, int k_vol, int cin, int cout, int* chunks, int* rows_per_chunk) {
     static const int env_chunks = getenv("TODA_WG_CHUNKS") ? atoi(getenv("TODA_WG_CHUNKS")) : 0;
-    const int max_chunks = env_chunks > 0 ? env_chunks : ((tiles_pow2(cin) * tiles_pow2(cout) >= 16) ? 48 : 144);
-    int ch = n_out / 2048;
+    int max_chunks = env_chunks > 0 ? env_chunks : ((tiles_pow2(cin) * tiles_pow2(cout) >= 16) ? 48 : 144);
+    if (env_chunks <= 0 && k_vol <= 9) max_chunks *= 2;
+    int ch = k_vol <= 9 ? n_out / 1024 : n_out / 2048;
     if (ch < 1) ch = 1;
     if (ch > max_chunks) ch = max_chunks;
     int rpc = (n_out + ch - 1) / ch;
@@ -1693,7 +1700,7 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
 
 extern "C" size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout) {
     int chunks, rpc;
-    wgrad_plan(n_out, cin, cout, &chunks, &rpc);
+    wgrad_plan(n_out, k_vol, cin, cout, &chunks, &rpc);
     return align_up((size_t)chunks * k_vol * cin * cout * sizeof(float), 256);
 }
 
@@ -1710,7 +1717,7 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
         return TODA_OK;
     }
     int chunks, rpc;
-    wgrad_plan(n_out, cin, cout, &chunks, &rpc);
+    wgrad_plan(n_out, k_vol, cin, cout, &chunks, &rpc);
     const size_t need = (size_t)chunks * elems * sizeof(float);
     if (ws_bytes < need) {
         set_error("wgrad: workspace %zu < required %zu", ws_bytes, need);
@@ -1724,15 +1731,24 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
     const int nsub_m = MT / mtb, nsub_n = NT / ntb;
     float* slab = (float*)ws;
     if (MT == 8 && NT == 8 && (env_sub & 4)) {   // cooperative quarters: 0.75 -> 0.68 ms on 97.5k x 27 x 128 x 128
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true>), dim3(chunks, k_vol, 1), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
-                           cout, nbr, n_out, k_vol, rpc, MT, NT, 2, slab);
+        if (cin == 128 && cout == 128)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true, true>), dim3(chunks, k_vol, 1), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
+                               cout, nbr, n_out, k_vol, rpc, MT, NT, 2, slab);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true>), dim3(chunks, k_vol, 1), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
+                               cout, nbr, n_out, k_vol, rpc, MT, NT, 2, slab);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slab, chunks, elems, dw);
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
     const dim3 grid(chunks, k_vol, nsub_m * nsub_n);
+    const bool exact = cin == 16 * MT && cout == 16 * NT;
 #define WG(MM, NN)                                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \
+    if (exact && (MM) % 4 == 0 && (NN) % 4 == 0)                                                                    \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN, false, ((MM) % 4 == 0 && (NN) % 4 == 0)>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \
+                           n_out, k_vol, rpc, MT, NT, nsub_n, slab);                                                \
+    else                                                                                                            \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \
                        n_out, k_vol, rpc, MT, NT, nsub_n, slab)
 #define WG_ROW(MM)             \
     switch (ntb) {             \

@@ -1038,34 +1038,34 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
             const int pc = ok ? p : d;  // any valid queue slot
             const unsigned ia = ((unsigned)qi[pc] * (unsigned)cin + (unsigned)(MT * ii + m0)) * 4u;
             const unsigned ib = ((unsigned)qo[pc] * (unsigned)cout + (unsigned)(NT * ii + n0)) * 4u;
-            // EXACT (channel counts = 16 x tiles, >= 4 tiles per block: every 64 / 128-channel layer): the 16-byte path is chosen at
-            // compile time.  As a run-time branch the two load forms share destination registers and hipcc puts an
+            // EXACT (channel counts = 16 x tiles: every layer but conv_input): the load form of each side is chosen at
+            // compile time (16-byte loads when the block holds >= 4 tiles of that side).  As a run-time branch the two load forms share destination registers and hipcc puts an
             // s_waitcnt vmcnt(3) in front of every 16-byte load: four loads in flight per round instead of eight.
-            if (EXACT || (exact_a && MTB % 4 == 0)) {
+            if ((EXACT || exact_a) && MTB % 4 == 0) {
 #pragma unroll
                 for (int m4 = 0; m4 < MTB; m4 += 4) {
                     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? ia + 4u * m4 : OOB, 0, 0));
 #pragma unroll
                     for (int m = 0; m < 4; ++m) a[t][m4 + m] = v[m];
                 }
-            } else if constexpr (!EXACT) {
+            } else {
 #pragma unroll
                 for (int m = 0; m < MTB; ++m)
                     a[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                  in_rsrc, (ok && MT * ii + m0 + m < cin) ? ia + 4u * m : OOB, 0, 0));
+                                  in_rsrc, (ok && (EXACT || MT * ii + m0 + m < cin)) ? ia + 4u * m : OOB, 0, 0));
             }
-            if (EXACT || (exact_b && NTB % 4 == 0)) {
+            if ((EXACT || exact_b) && NTB % 4 == 0) {
 #pragma unroll
                 for (int n4 = 0; n4 < NTB; n4 += 4) {
                     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? ib + 4u * n4 : OOB, 0, 0));
 #pragma unroll
                     for (int n = 0; n < 4; ++n) b[t][n4 + n] = v[n];
                 }
-            } else if constexpr (!EXACT) {
+            } else {
 #pragma unroll
                 for (int n = 0; n < NTB; ++n)
                     b[t][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                  dout_rsrc, (ok && NT * ii + n0 + n < cout) ? ib + 4u * n : OOB, 0, 0));
+                                  dout_rsrc, (ok && (EXACT || NT * ii + n0 + n < cout)) ? ib + 4u * n : OOB, 0, 0));
             }
         }
 #pragma unroll
@@ -1744,8 +1744,8 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
     const dim3 grid(chunks, k_vol, nsub_m * nsub_n);
     const bool exact = cin == 16 * MT && cout == 16 * NT;
 #define WG(MM, NN)                                                                                                  \
-    if (exact && (MM) % 4 == 0 && (NN) % 4 == 0)                                                                    \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN, false, ((MM) % 4 == 0 && (NN) % 4 == 0)>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \
+    if (exact)                                                                                                      \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN, false, true>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \
                            n_out, k_vol, rpc, MT, NT, nsub_n, slab);                                                \
     else                                                                                                            \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \

@@ -999,6 +999,7 @@ gather_gemm_stage_kernel(const float* __restrict__ in, int n_in, int cg, const f
 // COOP (128-channel sides): the 4 waves of a block walk the SAME pairs and each owns one (MTB x NTB)-tile quarter of
 // the 8 x 8-tile weight block - operands of the quarters that share a row half hit in L1, accumulators stay at 64
 // registers (4 waves / SIMD instead of 1 for a single 8 x 8 wave) and no cross-wave fold is needed.
+typedef float f32x2w __attribute__((ext_vector_type(2)));
 template <int MTB, int NTB, bool COOP = false, bool EXACT = false>
 __global__ void __launch_bounds__(SC_BLOCK, (MTB * NTB <= 16) ? WG_WAVES : 1)
 wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __restrict__ dout, int cout,
@@ -1041,7 +1042,10 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
             // EXACT (channel counts = 16 x tiles: every layer but conv_input): the load form of each side is chosen at
             // compile time (16-byte loads when the block holds >= 4 tiles of that side).  As a run-time branch the two load forms share destination registers and hipcc puts an
             // s_waitcnt vmcnt(3) in front of every 16-byte load: four loads in flight per round instead of eight.
-            if ((EXACT || exact_a) && MTB % 4 == 0) {
+            if (EXACT && MTB == 2) {          // 32 channels: the lane's two consecutive channels as one 8-byte load
+                const f32x2w v = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, ok ? ia : OOB, 0, 0));
+                a[t][0] = v[0], a[t][1] = v[1];
+            } else if ((EXACT || exact_a) && MTB % 4 == 0) {
 #pragma unroll
                 for (int m4 = 0; m4 < MTB; m4 += 4) {
                     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? ia + 4u * m4 : OOB, 0, 0));
@@ -1054,7 +1058,10 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
                     a[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                   in_rsrc, (ok && (EXACT || MT * ii + m0 + m < cin)) ? ia + 4u * m : OOB, 0, 0));
             }
-            if ((EXACT || exact_b) && NTB % 4 == 0) {
+            if (EXACT && NTB == 2) {
+                const f32x2w v = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(dout_rsrc, ok ? ib : OOB, 0, 0));
+                b[t][0] = v[0], b[t][1] = v[1];
+            } else if ((EXACT || exact_b) && NTB % 4 == 0) {
 #pragma unroll
                 for (int n4 = 0; n4 < NTB; n4 += 4) {
                     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? ib + 4u * n4 : OOB, 0, 0));

@@ -932,19 +932,44 @@ wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
 // coalesced, and enough threads even when a 64-channel layer has 4 units cut into 64 segments each)
 __global__ void __launch_bounds__(WN_BLOCK)
 wino_wgrad_reduce_kernel(const float* __restrict__ slabs, const WgradGeom wg, int G, float* __restrict__ red) {
+    // WG_SLAB_FLOATS is a multiple of the block size: a block lies inside one unit, whose segment list (which workgroups of the
+    // stream-K split touched it) thread 0 works out once - the 64-bit divisions of ws_range_lo per thread and per segment cost more
+    // than the fold itself; the loads of eight segments are then in flight together, the adds stay in workgroup order
+    static_assert(WG_SLAB_FLOATS % WN_BLOCK == 0, "a fold block must not straddle two units");
+    __shared__ int seg[WS_MAX_GRID];
+    __shared__ int n_seg;
     const long long e = (long long)blockIdx.x * WN_BLOCK + threadIdx.x;
-    if (e >= (long long)wg.n_units * WG_SLAB_FLOATS) return;
-    const int unit = (int)(e / WG_SLAB_FLOATS), off = (int)(e - (long long)unit * WG_SLAB_FLOATS);
-    const long long S = (long long)wg.n_units * wg.steps_per_unit;
-    const long long u_lo = (long long)unit * wg.steps_per_unit, u_hi = u_lo + wg.steps_per_unit;
-    int w0 = (int)(u_lo * G / S);
-    while (w0 > 0 && ws_range_lo(w0, G, S) > u_lo) --w0;
-    while (w0 + 1 < G && ws_range_lo(w0 + 1, G, S) <= u_lo) ++w0;
-    float acc = 0.0f;
-    for (int w = w0; w < G && ws_range_lo(w, G, S) < u_hi; ++w) {
-        if (ws_range_lo(w + 1, G, S) <= u_lo || ws_range_lo(w + 1, G, S) == ws_range_lo(w, G, S)) continue;
-        acc += slabs[(size_t)(w + unit) * WG_SLAB_FLOATS + off];
+    const int unit = (int)(((long long)blockIdx.x * WN_BLOCK) / WG_SLAB_FLOATS);
+    if (threadIdx.x == 0) {
+        const long long S = (long long)wg.n_units * wg.steps_per_unit;
+        const long long u_lo = (long long)unit * wg.steps_per_unit, u_hi = u_lo + wg.steps_per_unit;
+        int w0 = (int)(u_lo * G / S);
+        while (w0 > 0 && ws_range_lo(w0, G, S) > u_lo) --w0;
+        while (w0 + 1 < G && ws_range_lo(w0 + 1, G, S) <= u_lo) ++w0;
+        int n = 0;
+        long long lo = ws_range_lo(w0, G, S);
+        for (int w = w0; w < G && lo < u_hi; ++w) {
+            const long long next = ws_range_lo(w + 1, G, S);
+            if (next > u_lo && next != lo) seg[n++] = w;
+            lo = next;
+        }
+        n_seg = n;
     }
+    __syncthreads();
+    if (unit >= wg.n_units) return;
+    const int off = (int)(e - (long long)unit * WG_SLAB_FLOATS);
+    const float* p = slabs + (size_t)unit * WG_SLAB_FLOATS + off;
+    const int n = n_seg;
+    float acc = 0.0f;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(size_t)seg[i + j] * WG_SLAB_FLOATS];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += v[j];
+    }
+    for (; i < n; ++i) acc += p[(size_t)seg[i] * WG_SLAB_FLOATS];
     red[e] = acc;
 }
 

@@ -1162,10 +1162,21 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
 
 __global__ void __launch_bounds__(SC_BLOCK)
 wgrad_reduce_kernel(const float* __restrict__ slab, int chunks, long long elems, float* __restrict__ dw) {
+    // the adds stay in chunk order (fixed summation order); the loads of eight chunks are in flight together - as one dependent
+    // load per add this fold read 21 MB at 0.8 TB/s (26 us per 64 -> 64 layer)
     const long long e = (long long)blockIdx.x * SC_BLOCK + threadIdx.x;
     if (e >= elems) return;
+    const float* p = slab + e;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += slab[(size_t)c * elems + e];
+    int c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_nontemporal_load(p + (size_t)(c + i) * elems);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; c < chunks; ++c) s += p[(size_t)c * elems];
     dw[e] = s;
 }
 

@@ -734,22 +734,31 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
     } else {
     for (int k = 0; k < K; ++k) {
             const int cur = DB ? (k & 1) : 0;
+            // this offset's neighbour ids FIRST in program order: vmcnt counts in issue order, so a wait for ids that were issued
+            // behind the weight loads below would also wait for those (they are not needed before the end of the offset)
+            int src[RT];
+    #pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int v = __builtin_nontemporal_load(nbr + (size_t)k * n_out + rows[rt]);
+                src[rt] = live[rt] ? v : -1;
+            }
+            asm volatile("" ::: "memory");      // keep the id loads in front of the weight loads
             // next offset's weights: global -> registers now, registers -> LDS after this offset's math
+            // (unconditional: on the last offset the slice of offset K - 1 is fetched again and dropped - a branch around the loads
+            // makes the compiler's wait for the ids a wait for everything, see the note on wgrad_kernel's EXACT)
             f32x4 stage[PER_THREAD];
-            if (k + 1 < K) {
+            {
+                const int kn = k + 1 < K ? k + 1 : K - 1;
     #pragma unroll
                 for (int t = 0; t < PER_THREAD; ++t) {
                     const int e = t * BLK + threadIdx.x;
-                    if (e < SLICE) stage[t] = wp4[(size_t)(k + 1) * SLICE + e];
+                    if (SLICE % BLK == 0 || e < SLICE) stage[t] = wp4[(size_t)kn * SLICE + e];
                 }
             }
-            int src[RT];
             bool hit[RT];
             bool any = false;
     #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                const int v = nbr[(size_t)k * n_out + rows[rt]];
-                src[rt] = live[rt] ? v : -1;
                 hit[rt] = __any(src[rt] >= 0);
                 any = any || hit[rt];
             }

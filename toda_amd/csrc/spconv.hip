@@ -1039,19 +1039,23 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
     // one round: 4 MFMA steps over queue entries [d, d+16); entries >= limit contribute zeros.
     // Operands come through bounds-checked buffer loads (out-of-range offset -> 0), so there is no
     // branch around any load and all 8 loads of a round are in flight together.
-    auto round16 = [&](int d, int limit) {
+    // full_tag: the round holds 16 pairs (every round but a chunk's last): no per-step test around the MFMAs.  With the test the
+    // compiler sinks the loads of steps 1-3 into the conditional blocks, next to their use: load -> wait -> 16 MFMAs four times per
+    // round instead of eight loads in flight and 64 MFMAs behind them.
+    auto round16 = [&](int d, int limit, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         float a[4][MTB], b[4][NTB];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int p = d + 4 * t + g;
-            const bool ok = p < limit;
+            const bool ok = FULL || p < limit;
             const int pc = ok ? p : d;  // any valid queue slot
             const unsigned ia = ((unsigned)qi[pc] * (unsigned)cin + (unsigned)(MT * ii + m0)) * 4u;
             const unsigned ib = ((unsigned)qo[pc] * (unsigned)cout + (unsigned)(NT * ii + n0)) * 4u;
             // EXACT (channel counts = 16 x tiles: every layer but conv_input): the load form of each side is chosen at
             // compile time (16-byte loads when the block holds >= 4 tiles of that side).  As a run-time branch the two load forms share destination registers and hipcc puts an
             // s_waitcnt vmcnt(3) in front of every 16-byte load: four loads in flight per round instead of eight.
-            if (EXACT && MTB == 2) {          // 32 channels: the lane's two consecutive channels as one 8-byte load
+            if constexpr (EXACT && MTB == 2) {          // 32 channels: the lane's two consecutive channels as one 8-byte load
                 const f32x2w v = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, ok ? ia : OOB, 0, 0));
                 a[t][0] = v[0], a[t][1] = v[1];
             } else if ((EXACT || exact_a) && MTB % 4 == 0) {
@@ -1067,7 +1071,7 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
                     a[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                   in_rsrc, (ok && (EXACT || MT * ii + m0 + m < cin)) ? ia + 4u * m : OOB, 0, 0));
             }
-            if (EXACT && NTB == 2) {
+            if constexpr (EXACT && NTB == 2) {
                 const f32x2w v = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(dout_rsrc, ok ? ib : OOB, 0, 0));
                 b[t][0] = v[0], b[t][1] = v[1];
             } else if ((EXACT || exact_b) && NTB % 4 == 0) {
@@ -1086,7 +1090,7 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (d + 4 * t < limit) {  // wave-uniform
+            if (FULL || d + 4 * t < limit) {  // wave-uniform
 #pragma unroll
                 for (int m = 0; m < MTB; ++m)
 #pragma unroll
@@ -1112,7 +1116,7 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
         __builtin_amdgcn_wave_barrier();
         int done = 0;
         while (qn - done >= 16) {
-            round16(done, qn);
+            round16(done, qn, std::bool_constant<!COOP>{});     // (the cooperative 128 x 128 kernel measured 8 % slower without the per-step test)
             done += 16;
         }
         const int left = qn - done;
@@ -1131,7 +1135,7 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
         qn = left;
         __builtin_amdgcn_wave_barrier();
     }
-    if (qn > 0) round16(0, qn);
+    if (qn > 0) round16(0, qn, std::false_type{});
 
     // fold the 4 waves of the block in fixed order 0+1+2+3
     for (int src = 1; !COOP && src < SC_BLOCK / 64; ++src) {

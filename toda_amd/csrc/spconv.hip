@@ -1101,9 +1101,14 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
     };
 
     int qn = 0;  // wave-uniform queue length (< 16 between batches)
-    for (int base = row_begin + (COOP ? 0 : wv * 64); base < row_end; base += (COOP ? 64 : SC_BLOCK)) {
+    // the neighbour ids of the NEXT 64 rows are requested before this batch's rounds run, so their latency is covered by those rounds
+    constexpr int BSTEP = COOP ? 64 : SC_BLOCK;
+    const int base0 = row_begin + (COOP ? 0 : wv * 64);
+    int iv_next = nbr[(size_t)k * n_out + min(base0 + lane, n_out - 1)];  // clamped, unconditional
+    for (int base = base0; base < row_end; base += BSTEP) {
         const int o = base + lane;
-        const int iv = nbr[(size_t)k * n_out + min(o, n_out - 1)];  // clamped, unconditional
+        const int iv = iv_next;
+        iv_next = nbr[(size_t)k * n_out + min(o + BSTEP, n_out - 1)];
         const int i = o < row_end ? iv : -1;
         const unsigned long long vote = __ballot(i >= 0);
         if (vote == 0) continue;

@@ -635,6 +635,8 @@ def main(argv=None):
                 json.dump({"workload": args.workload, "gather_gemm_timed_region": rows, "kernels": res["op_rows"]}, open(args.layers_out, "w"),
                           indent=1)
         step_ms = res["step_ms"]
+        if os.environ.get("TODA_BENCH_STEP_MS"):      # every timed step's GPU time (event to event), to look at outliers
+            print("[step_ms] " + " ".join(f"{t:.2f}" for t in step_ms), file=sys.stderr)
         line = {
             "metric": "LiDAR training samples/sec" if args.workload != "c2" else "LiDAR backbone forward samples/sec", "value": round(total_samples / res["elapsed"], 3),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -55,7 +55,7 @@ def test_fused_center_loss_matches_torch_fp64(geom):
 
     assert abs(float(la.detach()) - float(ra.detach())) <= 2e-5 * max(1.0, abs(float(ra.detach())))     # fp32 element arithmetic vs fp64
     assert abs(float(lb.detach()) - float(rb.detach())) <= 2e-5 * max(1.0, abs(float(rb.detach())))
-    assert float((prob.double() - p_ref).abs().max()) < 1e-6
+    assert float((prob.double() - p_ref.detach()).abs().max()) < 1e-6
     gz, gz_ref = hm_a.grad.double(), hm_r.grad
     assert float((gz - gz_ref).abs().max()) <= 5e-5 * float(gz_ref.abs().max())
     for ga, gr in zip(regs_a, regs_r):

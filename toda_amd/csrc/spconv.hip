@@ -621,7 +621,7 @@ __device__ __forceinline__ int xcd_chunked_block(int b, int nblk) {
 // streaming it through L1 (4x less vector-memory traffic: with per-wave weight loads the CU's
 // 64 B/clk L1 path, not the MFMA pipe, sets the pace - measured 59 % matrix-pipe utilisation).
 // One barrier per offset; waves still skip the MFMAs of offsets without a neighbour in their rows.
-template <int Q, int NT, int RT, bool VEC, bool DB = true, int BLK = SC_BLOCK, bool PFL = false>
+template <int Q, int NT, int RT, bool VEC, bool DB = true, int BLK = SC_BLOCK, bool PFL = false, bool IDPF = false>
 __global__ void __launch_bounds__(BLK, PFL ? 3 : (Q * NT <= 4 && RT <= 2) ? GG_LDS_WAVES_NARROW : (Q * NT * RT <= 32 && Q * NT <= 16) ? GG_LDS_WAVES : (BLK > SC_BLOCK ? GG_LDS_WAVES_WIDE : 1))
 gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp,
                        const int* __restrict__ nbr, int n_out, int K, int cp, const float* __restrict__ bias,
@@ -732,15 +732,32 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
             body(k, sC, aB, sB, sA, aA); if (++k >= K) break;
         }
     } else {
+    int id_next[RT];
+    if constexpr (IDPF) {
+    #pragma unroll
+        for (int rt = 0; rt < RT; ++rt) id_next[rt] = __builtin_nontemporal_load(nbr + rows[rt]);
+    }
     for (int k = 0; k < K; ++k) {
             const int cur = DB ? (k & 1) : 0;
             // this offset's neighbour ids FIRST in program order: vmcnt counts in issue order, so a wait for ids that were issued
             // behind the weight loads below would also wait for those (they are not needed before the end of the offset)
             int src[RT];
+            if constexpr (IDPF) {
+                // ids one offset ahead (<= 64-channel variants with two row tiles per wave): the id -> row -> MFMA chain of an offset
+                // loses its first memory round trip.  Worth 1-4 % (32 -> 32 @ 682k rows 0.307 -> 0.303 ms, 32 -> 64 0.299 -> 0.288,
+                // 64 -> 64 0.589 -> 0.584): the chain is not what holds the matrix pipe at 62-69 %
+                const int kn = k + 1 < K ? k + 1 : K - 1;
+    #pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    src[rt] = live[rt] ? id_next[rt] : -1;
+                    id_next[rt] = __builtin_nontemporal_load(nbr + (size_t)kn * n_out + rows[rt]);
+                }
+            } else {
     #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const int v = __builtin_nontemporal_load(nbr + (size_t)k * n_out + rows[rt]);
                 src[rt] = live[rt] ? v : -1;
+            }
             }
             asm volatile("" ::: "memory");      // keep the id loads in front of the weight loads
             // next offset's weights: global -> registers now, registers -> LDS after this offset's math
@@ -1630,7 +1647,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
                   dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
                   k_vol, c_produce, bias, out, order, stats);                                                            \
     else                                                                                                                 \
-        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true>),                                             \
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<QQ, NN, RR, true, true, SC_BLOCK, false, (QQ <= 4 && NN <= 4 && RR == 2)>), \
                        dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
                        k_vol, c_produce, bias, out, order, stats)
 #define GL_RT(QQ, NN)                          \

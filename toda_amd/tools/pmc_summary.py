@@ -26,11 +26,21 @@ def main():
             kname = r["Kernel_Name"].split("(")[0]
             names.add(kname)
             acc[(kname, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):      # the dispatch's duration under the counter pass
+                acc[(kname, int(r["Grid_Size"]))]["_duration_ns:" + r["Counter_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     shapes = []
     for (kname, grid), counters in sorted(acc.items()):
         row = {"kernel": kname, "grid_threads": grid, "dispatches": max(len(v) for v in counters.values())}
+        durations = {}
         for name, vals in sorted(counters.items()):
-            row[name] = sum(vals) / len(vals)
+            if name.startswith("_duration_ns:"):
+                durations[name.split(":", 1)[1]] = sum(vals) / len(vals)
+            else:
+                row[name] = sum(vals) / len(vals)
+        # shader clock the kernel actually ran at: busy cycles of the pass that counted them over that pass's own duration
+        if "GRBM_GUI_ACTIVE" in row and durations.get("GRBM_GUI_ACTIVE"):
+            row["duration_ns_in_clock_pass"] = durations["GRBM_GUI_ACTIVE"]
+            row["sclk_ghz"] = row["GRBM_GUI_ACTIVE"] / durations["GRBM_GUI_ACTIVE"]
         if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
             row["hbm_bytes"] = int((2 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in row and "SQ_BUSY_CU_CYCLES" in row:

@@ -21,14 +21,36 @@ python3 $R/toda_amd/tools/pmc_summary.py wino_fwd_ws_kernel $O/r02_pmc_wino_fwd.
 python3 $R/toda_amd/tools/pmc_summary.py wino_wgrad_kernel $O/r02_pmc_wino_wgrad.json $CSVS > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py wgrad_kernel $O/r02_pmc_sparse_wgrad.json $CSVS > /dev/null
 cp $O/r02_pmc_gather_gemm_64x64.json $R/profiles/r02_pmc_gather_gemm_64x64.json
+echo "== where the waves wait (SQ / TA / TCP / TCC counters, one pass per set) and the shader clock (GRBM_GUI_ACTIVE over the dispatch's duration, 8 XCDs)"
+i=0
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+         "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+         "TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCP_LATENCY TA_BUSY TA_TOTAL_WAVEFRONTS" \
+         "TCC_HIT TCC_MISS TCC_REQ TCP_PENDING_STALL_CYCLES TCP_READ_TAGCONFLICT_STALL_CYCLES" \
+         "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" \
+         "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rm -rf /tmp/r02_st_$i
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r02_st_$i -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/r02_st_$i.log 2>&1
+  echo "  set $i done"
+done
+ST=$(find /tmp/r02_st_* /tmp/r02_pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv")
+python3 $R/toda_amd/tools/pmc_summary.py gather_gemm_lds_kernel $O/r02_pmc_stall_gather_gemm.json $ST > /dev/null
+python3 $R/toda_amd/tools/pmc_summary.py wgrad_kernel $O/r02_pmc_stall_sparse_wgrad.json $ST > /dev/null
 cd $R
 echo "== bench lines"
-timeout -k 10 400 python bench.py --steps 50 --warmup 10 --layers --layers-out $O/r02_layers_c3.json > $O/r02_bench_c3.json 2> $O/r02_bench_c3.err
+# 40 warm-up steps: on these boxes a power-management transient 0.6-0.7 s after the first step (steps 33-35 of a run) costs 3-12 ms on
+# 3-8 consecutive steps (per-step times in the .err files, TODA_BENCH_STEP_MS); the *_driver_shape line is the driver's K / W
+export TODA_BENCH_STEP_MS=1
+timeout -k 10 400 python bench.py --steps 50 --warmup 40 --layers --layers-out $O/r02_layers_c3.json > $O/r02_bench_c3.json 2> $O/r02_bench_c3.err
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r02_bench_c3_driver_shape.json 2> $O/r02_bench_c3_driver_shape.err
 for w in c2 c5 c5mix c5cl; do
-  timeout -k 10 400 python bench.py --workload $w --steps 50 --warmup 10 > $O/r02_bench_$w.json 2> $O/r02_bench_$w.err
+  timeout -k 10 400 python bench.py --workload $w --steps 50 --warmup 40 > $O/r02_bench_$w.json 2> $O/r02_bench_$w.err
   echo "  $w done"
 done
 timeout -k 10 400 python bench.py --workload c5 --steps 20 --warmup 8 --no-cpu-baseline --layers --layers-out $O/r02_layers_c5.json > /dev/null 2> $O/r02_layers_c5.err
+timeout -k 10 400 python bench.py --steps 300 --warmup 40 --no-cpu-baseline > $O/r02_soak_c3.json 2> $O/r02_soak_c3.err
+unset TODA_BENCH_STEP_MS
 echo "== dense convolutions per layer"
 PYTHONPATH=$R timeout -k 10 300 python -m toda_amd.tools.bench_conv2d --config c3 > $O/r02_conv2d_c3.jsonl
 PYTHONPATH=$R timeout -k 10 300 python -m toda_amd.tools.bench_conv2d --config c5 > $O/r02_conv2d_c5.jsonl

@@ -1030,16 +1030,37 @@ template <int MTB, int NTB, bool COOP = false, bool EXACT = false>
 __global__ void __launch_bounds__(SC_BLOCK, (MTB * NTB <= 16) ? WG_WAVES : 1)
 wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __restrict__ dout, int cout,
              const int* __restrict__ nbr, int n_out, int K, int rows_per_chunk, int MT, int NT, int nsub_n,
-             float* __restrict__ slab) {
+             float* __restrict__ slab, int xcd_chunks) {
     constexpr int QCAP = 64 + 16;
     __shared__ float red[MTB * NTB * 4 * 64];
     __shared__ int q_in[SC_BLOCK / 64][QCAP], q_out[SC_BLOCK / 64][QCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ii = lane & 15, g = lane >> 4;
-    const int chunk = blockIdx.x, k = blockIdx.y;
-    const int sub = COOP ? wv : (int)blockIdx.z;
+    // 1-D grid over (row chunk, offset, channel sub-block).  The K offset-blocks of a chunk read the same dout rows and neighbouring
+    // input rows: they are given consecutive slots of ONE XCD (workgroup ids are dealt round-robin over the 8 XCDs, so XCD x owns
+    // ids x, x + 8, ...) and run side by side out of that XCD's L2.  With the offset as the slow grid axis (round 1) the blocks
+    // of a chunk were on one XCD too, but a whole grid pass apart in time: PMC 1.50 GB from HBM per launch of the 32 -> 32
+    // layer at 682 k rows against 0.27 GB algorithmic.  xcd_chunks < 0 (TODA_WG_XCD=0): plain order.  The launch pads the chunk count to a multiple of 8.
+    const int n_chunks = xcd_chunks < 0 ? -xcd_chunks : xcd_chunks;
+    const int nsub_blk = (int)gridDim.x / (n_chunks * K);
+    int chunk, k, sub_blk;
+    {
+        const int b = blockIdx.x;
+        if (xcd_chunks > 0) {
+            const int xcd = b & 7, t = (b >> 3) / K;
+            k = (b >> 3) - t * K;
+            sub_blk = t % nsub_blk;
+            chunk = (t / nsub_blk) * 8 + xcd;
+        } else {
+            chunk = b % n_chunks;
+            k = (b / n_chunks) % K;
+            sub_blk = b / (n_chunks * K);
+        }
+    }
+    const int sub = COOP ? wv : sub_blk;
     const int m0 = (sub / nsub_n) * MTB, n0 = (sub % nsub_n) * NTB;
     const int row_begin = chunk * rows_per_chunk;
+    if (row_begin >= n_out) return;      // a padding chunk of the XCD-ordered grid (whole block, before any barrier)
     const int row_end = min(n_out, row_begin + rows_per_chunk);
     const bool exact_a = cin == 16 * MT, exact_b = cout == 16 * NT;
     int* qi = q_in[wv];
@@ -1228,6 +1249,11 @@ static void wgrad_plan(int n_out, int k_vol, int cin, int cout, int* chunks, int
     int ch = k_vol <= 9 ? n_out / 1024 : n_out / 2048;
     if (ch < 1) ch = 1;
     if (ch > max_chunks) ch = max_chunks;
+    // with the chunk's K offset-blocks side by side on one XCD (wgrad_kernel's grid order) the big levels take smaller chunks:
+    // about 4 k rows each, at most 96 (64 -> 64 @ 389 k rows: 48 chunks 0.531 ms, 96 0.505, 192 0.509, 288 0.52; @ 117 k rows 48
+    // chunks 0.187, 96 0.196)
+    if (env_chunks <= 0 && k_vol > 9 && max_chunks == 48 && n_out / 4096 > 48) ch = n_out / 4096 < 96 ? n_out / 4096 : 96;
+    if (ch >= 8) ch = (ch + 7) / 8 * 8;      // whole rounds of the 8 XCDs (55 chunks = 56 launched with one XCD a chunk short: 0.313 ms, 48: 0.304, 96: 0.296 on 64 -> 64 @ 227 k rows)
     int rpc = (n_out + ch - 1) / ch;
     rpc = (rpc + 15) / 16 * 16;
     if (rpc < 16) rpc = 16;
@@ -1783,26 +1809,29 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
     if (NT == 8 && (env_sub & 2)) ntb = 8;
     const int nsub_m = MT / mtb, nsub_n = NT / ntb;
     float* slab = (float*)ws;
+    static const int env_wg_xcd = getenv("TODA_WG_XCD") ? atoi(getenv("TODA_WG_XCD")) : 1;
+    const int chunks_launch = env_wg_xcd ? (chunks + 7) / 8 * 8 : chunks;      // padded to whole rounds of the 8 XCDs: blocks of the padding chunks leave at once
+    const int xcd_chunks = env_wg_xcd ? chunks_launch : -chunks;
     if (MT == 8 && NT == 8 && (env_sub & 4)) {   // cooperative quarters: 0.75 -> 0.68 ms on 97.5k x 27 x 128 x 128
         if (cin == 128 && cout == 128)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true, true>), dim3(chunks, k_vol, 1), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
-                               cout, nbr, n_out, k_vol, rpc, MT, NT, 2, slab);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true, true>), dim3(chunks_launch * k_vol), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
+                               cout, nbr, n_out, k_vol, rpc, MT, NT, 2, slab, xcd_chunks);
         else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true>), dim3(chunks, k_vol, 1), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
-                               cout, nbr, n_out, k_vol, rpc, MT, NT, 2, slab);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true>), dim3(chunks_launch * k_vol), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
+                               cout, nbr, n_out, k_vol, rpc, MT, NT, 2, slab, xcd_chunks);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slab, chunks, elems, dw);
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
-    const dim3 grid(chunks, k_vol, nsub_m * nsub_n);
+    const dim3 grid(chunks_launch * k_vol * nsub_m * nsub_n);
     const bool exact = cin == 16 * MT && cout == 16 * NT;
 #define WG(MM, NN)                                                                                                  \
     if (exact)                                                                                                      \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN, false, true>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \
-                           n_out, k_vol, rpc, MT, NT, nsub_n, slab);                                                \
+                           n_out, k_vol, rpc, MT, NT, nsub_n, slab, xcd_chunks);                                    \
     else                                                                                                            \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<MM, NN>), grid, dim3(SC_BLOCK), 0, s, in, n_in, cin, dout, cout, nbr, \
-                       n_out, k_vol, rpc, MT, NT, nsub_n, slab)
+                       n_out, k_vol, rpc, MT, NT, nsub_n, slab, xcd_chunks)
 #define WG_ROW(MM)             \
     switch (ntb) {             \
         case 1: WG(MM, 1); break; \

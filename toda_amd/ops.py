@@ -820,9 +820,6 @@ class _Conv3x3(torch.autograd.Function):
 
 def conv3x3_wgrad(x, gy, wshape):
     lib = L.load()
-    if not hasattr(lib, "toda_conv3x3_wgrad"):
-        return torch.ops.aten.convolution_backward(gy, x, torch.empty(wshape, device=x.device), None, (1, 1), (1, 1), (1, 1), False,
-                                                   (0, 0), 1, (False, True, False))[1]
     b, cin, h, w = x.shape
     cout = gy.shape[1]
     dw = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)

@@ -233,13 +233,26 @@ def run_gpu(args, rank, world, device):
     # voxelisation + index build (the one for the next step).  Opt-in (TODA_PREFETCH=1): measured 22.5-23.0 ms/step with it
     # against 22.3-22.5 without - the step is GPU-bound, the two host syncs of the index build cost nothing to hide.
     prefetch = None
-    if os.environ.get("TODA_PREFETCH", "0") == "1" and not (fwd_only or pair or mixed):
+
+    def mixed_batch(it):
+        # the whole input path of a TODA stage-1 step: mix -> range mask -> shuffle -> collate, all on the device
+        base = ((it * world + rank) * per_gpu) % len(dataset)
+        batch = dataset.collate_batch([dataset[(base + i) % len(dataset)] for i in range(per_gpu)])
+        batch["gt_boxes"] = torch.from_numpy(batch["gt_boxes"]).float().to(device)
+        return {k: batch[k] for k in ("points", "points_per_sample", "gt_boxes", "batch_size")}
+
+    # c5mix with the mix -> mask -> shuffle -> collate chain on the side stream as well: 67.5 / 67.1 samples/s against 69.1 / 66.9
+    # without (the spread of its step times, p10 / p90 26-33 ms, is the size of the mixed clouds, not host stalls).
+    if os.environ.get("TODA_PREFETCH", "0") == "1" and not (fwd_only or pair):
         from toda_amd.pcdet.models import InputPrefetcher
 
         def batch_stream():
             it = 0
             while True:
-                yield dict(batches[it % len(batches)])
+                if mixed:
+                    yield mixed_batch(it)
+                else:
+                    yield dict(batches[it % len(batches)])
                 it += 1
 
         prefetch = InputPrefetcher(batch_stream(), net, device)
@@ -258,13 +271,10 @@ def run_gpu(args, rank, world, device):
             adv, org = batches[it % len(batches)]
             loss = cl_fn(model, dict(adv), dict(org), world > 1).loss
         else:
-            if mixed:   # the whole input path of a TODA stage-1 step: mix -> range mask -> shuffle -> collate, all on the device
-                base = ((it * world + rank) * per_gpu) % len(dataset)
-                batch = dataset.collate_batch([dataset[(base + i) % len(dataset)] for i in range(per_gpu)])
-                batch["gt_boxes"] = torch.from_numpy(batch["gt_boxes"]).float().to(device)
-                batch = {k: batch[k] for k in ("points", "points_per_sample", "gt_boxes", "batch_size")}
-            elif prefetch is not None:
+            if prefetch is not None:
                 batch = prefetch.next()
+            elif mixed:
+                batch = mixed_batch(it)
             else:
                 batch = dict(batches[it % len(batches)])
             if prefetch is None:

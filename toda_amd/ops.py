@@ -227,8 +227,15 @@ def build_conv_rulebook(indices, batch, shape, ksize, stride, padding):
     return idx_out, out_shape, rb, gi_out
 
 
-def build_index_plan(indices, batch, shape, steps):
+_PLAN_PINNED = {}
+
+
+def build_index_plan(indices, batch, shape, steps, while_waiting=None):
     """All rulebooks of a sequential sparse backbone with ONE host sync.
+
+    while_waiting: optional callable run between the request for the level counts and the wait for them - work that does not
+    depend on the plan (operand packing) is queued there, so the GPU has something to run while the host reads the counts and
+    gets its launch lead back (the wait is for the copy's event, not for the stream).
 
     steps (forward order): {'kind': 'subm', 'key', 'ksize', 'dilation'} or
     {'kind': 'conv', 'key', 'ksize', 'stride', 'padding'}.  The output index sets of the strided
@@ -264,7 +271,18 @@ def build_index_plan(indices, batch, shape, steps):
         conv_steps.append((st, cur, nxt, hs))
         levels.append(nxt)
     if conv_steps:
-        counts = torch.cat([c[2]["n_dev"] for c in conv_steps]).tolist()  # the one sync
+        counts_dev = torch.cat([c[2]["n_dev"] for c in conv_steps])
+        key = (dev.index, counts_dev.numel())
+        ent = _PLAN_PINNED.get(key)
+        if ent is None:
+            ent = _PLAN_PINNED[key] = (torch.empty((counts_dev.numel(),), dtype=torch.int32).pin_memory(), torch.cuda.Event())
+        host, ev = ent
+        host.copy_(counts_dev, non_blocking=True)
+        ev.record()
+        if while_waiting is not None:
+            while_waiting()
+        ev.synchronize()  # the one sync
+        counts = host.tolist()
         for (st, cur, nxt, hs), n_out in zip(conv_steps, counts):
             if n_out > nxt["cap"]:
                 raise RuntimeError(f"strided rulebook {st['key']}: {n_out} outputs exceed the bound {nxt['cap']}")

@@ -95,11 +95,11 @@ class InputPrefetcher:
     def kick(self):
         if self.pending is not None:
             return
-        try:
-            batch = next(self.it)
-        except StopIteration:
-            return
         with torch.cuda.stream(self.side):
+            try:
+                batch = next(self.it)        # inside the side-stream context: a source that mixes / collates on the device runs there too
+            except StopIteration:
+                return
             batch = prepare_batch_on_gpu(batch, self.net)
             ev = torch.cuda.Event()
             ev.record(self.side)

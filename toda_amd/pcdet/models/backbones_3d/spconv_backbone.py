@@ -97,10 +97,11 @@ class _Backbone8xBase(nn.Module):
             x.indice_dict.update(ready[0])
             x.grid_index = ready[1]
         elif hasattr(spconv, "plan_indices"):
-            # all 8/9 rulebooks with one host sync instead of one per strided conv
-            spconv.plan_indices(x, self)
+            # all 8/9 rulebooks with one host sync instead of one per strided conv; the operand packing of this backbone is queued
+            # behind the plan's kernels before the host waits for the counts, so the GPU has work while the host catches up
+            spconv.plan_indices(x, self, lambda: spconv.prepack(self))
         if hasattr(spconv, "prepack"):
-            spconv.prepack(self)      # every conv's forward + dgrad operand in one launch (46 small launches per step otherwise)
+            spconv.prepack(self)      # every conv's forward + dgrad operand in one launch (46 small launches per step otherwise); a no-op when the plan's wait already did it
         x = self.conv_input(x)
         stages = []
         for stage in (self.conv1, self.conv2, self.conv3, self.conv4):

@@ -25,8 +25,9 @@ def conv_steps(module):
     return steps
 
 
-def plan_indices(x, module):
-    """Populate x.indice_dict for every sparse convolution under `module` (sequential topology)."""
+def plan_indices(x, module, while_waiting=None):
+    """Populate x.indice_dict for every sparse convolution under `module` (sequential topology).  while_waiting: see
+    ops.build_index_plan."""
     steps = conv_steps(module)
     if not steps or not x.indices.is_cuda:
         return x
@@ -37,6 +38,6 @@ def plan_indices(x, module):
         if st["kind"] == "conv" or st["key"] not in seen:
             ordered.append(st)
         seen.add(st["key"])
-    plan = ops.build_index_plan(x.indices, x.batch_size, x.spatial_shape, ordered)
+    plan = ops.build_index_plan(x.indices, x.batch_size, x.spatial_shape, ordered, while_waiting)
     x.indice_dict.update(plan)
     return x

@@ -218,16 +218,19 @@ int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual 
                          const float* gamma, int n, int c, int relu, double* sums, float* dx,
                          float* dres /*nullable*/, void* stream);
 
-/* nn.BatchNorm2d(+ReLU) of the BEV neck and heads (base_bev_backbone.py:37-58, center_head.py:20-28, 73-80) on NCHW
- * tensors x[batch][c][hw]: the same sweeps as the row variant (moments -> toda_bn_finalize with n = batch*hw -> affine
- * (+ReLU); backward reduce + apply with the ReLU mask recomputed from x).  sums / stats as for the row variant, `sums`
- * sized by toda_planes_reduce_doubles. */
-size_t toda_planes_reduce_doubles(int batch, int c, int hw);
-int toda_planes_moments(const float* x, int batch, int c, int hw, double* sums, void* stream);
-int toda_planes_affine_act(const float* x, const float* scale, const float* shift, int batch, int c, int hw,
-                           int relu, float* y, void* stream);
-int toda_planes_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int batch, int c,
-                       int hw, int relu, double* sums, float* dx, void* stream);
+/* Single-pass training-mode nn.BatchNorm2d (+ nn.ReLU) of the BEV neck and heads (base_bev_backbone.py:37-58,
+ * center_head.py:20-28, 73-80; replaces torch's batch_norm + relu_ pair and their backward): one workgroup holds a
+ * channel's batch*hw values in registers, so the tensor is read once and written once forward; backward reads x twice,
+ * dy once.  toda_bn2d_supported: hw % 4 == 0 and batch*hw small enough for the register image (batch 1 / 2: hw <= 36864,
+ * batch 4: hw <= 16384).  save = [2][c] floats (mean, 1/sqrt(var + eps)) from forward for backward.  running_mean /
+ * running_var (nullable together) are updated in place like nn.BatchNorm2d does (momentum, unbiased variance).
+ * relu != 0: y = max(bn(x), 0); backward recomputes the mask from x with the forward's expression. */
+int toda_bn2d_supported(int batch, int c, int hw);
+int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const float* gamma, const float* beta,
+                  float* running_mean /*nullable*/, float* running_var /*nullable*/, float momentum, float eps, int relu,
+                  float* y, float* save, void* stream);
+int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, int hw, const float* gamma, const float* beta,
+                  const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------
  * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,

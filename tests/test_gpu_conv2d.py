@@ -177,3 +177,45 @@ def test_separate_head_fused_hidden_layer_matches_branchwise_modules():
         getattr(ref, name)(x)
     for (k, p), (_, q) in zip(head.named_buffers(), ref.named_buffers()):
         assert torch.allclose(p.float(), q.float(), rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 128, 188, 188), (2, 256, 94, 94), (1, 64, 180, 180), (4, 32, 64, 64), (2, 320, 36, 20), (2, 7, 2, 2)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_single_pass_batchnorm2d_matches_torch(shape, relu):
+    """toda_bn2d_fwd / _bwd against nn.BatchNorm2d (+ReLU) in fp64 on the same tensors: output, running statistics, input / weight /
+    bias gradients (reference base_bev_backbone.py:37-58: BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU)."""
+    from toda_amd import ops
+    torch.manual_seed(3)
+    b, c, h, w = shape
+    bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+    ref = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).cuda().double().train()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v.clone() for k, v in bn.state_dict().items()})
+    x = (torch.randn(shape, device="cuda") * 2.0 + 0.7).requires_grad_(True)
+    xr = x.detach().double().requires_grad_(True)
+    assert ops.bn2d_supported(x, bn)
+    y = ops.bn2d(x, bn, relu)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yr.backward(gy.double())
+    tol = 2e-5
+    assert float((y.double() - yr).abs().max()) <= tol * max(1.0, float(yr.abs().max()))
+    assert int(bn.num_batches_tracked) == 1
+    assert torch.allclose(bn.running_mean.double(), ref.running_mean, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(bn.running_var.double(), ref.running_var, rtol=1e-5, atol=1e-6)
+    # elements whose pre-activation is within rounding of zero may take the other side of the ReLU: compare away from it
+    if relu:
+        safe = (ref(xr.detach()).abs() > 1e-4)
+    else:
+        safe = torch.ones_like(yr, dtype=torch.bool)
+    gx, gxr = x.grad.double(), xr.grad
+    assert float(((gx - gxr) * safe).abs().max()) <= 2e-4 * max(1e-3, float(gxr.abs().max()))
+    assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, rtol=2e-4, atol=2e-3)
+    assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=2e-4, atol=2e-3)

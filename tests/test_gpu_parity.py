@@ -482,12 +482,12 @@ def test_fused_bn_shortcut_relu_matches_torch(c, train):
 
 @pytest.mark.parametrize("shape,relu,train", [((2, 128, 188, 188), True, True), ((2, 64, 47, 45), True, True),
                                                 ((3, 256, 94, 94), False, True), ((2, 32, 20, 20), True, False)])
-def test_fused_bn_planes_matches_torch_batchnorm2d(shape, relu, train):
-    """toda_planes_moments / _affine_act / _bn_bwd (BatchNorm2d + ReLU of the BEV neck and heads) against nn.BatchNorm2d in
-    fp64: output, input gradient, affine gradients, running statistics; hw % 4 != 0 takes the scalar path."""
+def test_dense_sequential_batchnorm2d_matches_torch(shape, relu, train):
+    """BatchNorm2d + ReLU of the BEV neck and heads through ops.run_dense_sequential against nn.BatchNorm2d in fp64: output, input
+    gradient, affine gradients, running statistics.  The first case runs the single-pass kernel (toda_bn2d_*); hw % 4 != 0, a
+    batch of 3 and eval mode stay on torch - same results either way."""
     from toda_amd import ops
 
-    ops.PLANES_BN = True          # opt-in path (TODA_PLANES_BN=1)
     b, c, h, w = shape
     rng = np.random.default_rng(c + h)
     x = (rng.standard_normal(shape) * 1.5 + 0.2).astype(np.float32)
@@ -507,7 +507,7 @@ def test_fused_bn_planes_matches_torch_batchnorm2d(shape, relu, train):
     yr = torch.relu(pre) if relu else pre
     yr.backward(torch.from_numpy(g).double())
     xm = dev(x).requires_grad_(True)
-    assert ops.bn_planes_supported(xm, mine)
+    assert ops.bn2d_supported(xm, mine) == (train and b in (1, 2, 4) and (h * w) % 4 == 0)
     seq = torch.nn.Sequential(mine, torch.nn.ReLU()) if relu else torch.nn.Sequential(mine)
     ym = ops.run_dense_sequential(seq, xm)
     ym.backward(dev(g))

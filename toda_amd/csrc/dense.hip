@@ -289,146 +289,6 @@ bn_finalize_kernel(const double* __restrict__ sums, int n, int c, const float* _
     shift_out[ch] = b - mean * g * invstd;
 }
 
-// ---- BatchNorm2d(+ReLU) over NCHW planes (BEV neck and heads) -----------------------------------
-// Same three / five sweeps as the row variant, for x[b][c][i] with HW contiguous floats per plane.
-// Reductions: grid (chunks, C); a block reduces PL_CHUNK elements of channel c's B*HW values
-// (fp32 in a thread, fp64 across threads), writes its two partial sums, fold_partials_kernel adds
-// them in fixed order.  No atomics.
-constexpr int PL_CHUNK = 8192;  // floats of one channel per block
-
-template <bool VEC, class Load>
-__device__ __forceinline__ void planes_reduce2(int batch, int c, int hw, Load load, double* __restrict__ sums) {
-    __shared__ double sh[2][DN_BLOCK];
-    const int ch = blockIdx.y;
-    const long long total = (long long)batch * hw;                 // elements of this channel
-    const long long begin = (long long)blockIdx.x * PL_CHUNK;
-    const long long end = begin + PL_CHUNK < total ? begin + PL_CHUNK : total;
-    float s0 = 0.f, t0 = 0.f, s1 = 0.f, t1 = 0.f;
-    constexpr int W = VEC ? 4 : 1;
-    for (long long e = begin + (long long)threadIdx.x * W; e < end; e += 2ll * DN_BLOCK * W) {
-        const long long e2 = e + (long long)DN_BLOCK * W;
-        {
-            const long long b = e / hw, i = e % hw;                // VEC: hw % 4 == 0, so a float4 never straddles planes
-            float a[4], q[4];
-            load((size_t)(b * c + ch) * hw + i, a, q);
-#pragma unroll
-            for (int j = 0; j < W; ++j) s0 += a[j], t0 += q[j];
-        }
-        if (e2 < end) {
-            const long long b = e2 / hw, i = e2 % hw;
-            float a[4], q[4];
-            load((size_t)(b * c + ch) * hw + i, a, q);
-#pragma unroll
-            for (int j = 0; j < W; ++j) s1 += a[j], t1 += q[j];
-        }
-    }
-    sh[0][threadIdx.x] = (double)s0 + (double)s1;
-    sh[1][threadIdx.x] = (double)t0 + (double)t1;
-    __syncthreads();
-    for (int w = DN_BLOCK / 2; w > 0; w >>= 1) {
-        if (threadIdx.x < w) {
-            sh[0][threadIdx.x] += sh[0][threadIdx.x + w];
-            sh[1][threadIdx.x] += sh[1][threadIdx.x + w];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 2) sums[2 * c + (size_t)(threadIdx.x * c + ch) * gridDim.x + blockIdx.x] = sh[threadIdx.x][0];
-}
-
-template <bool VEC>
-__global__ void __launch_bounds__(DN_BLOCK)
-planes_moments_kernel(const float* __restrict__ x, int batch, int c, int hw, double* __restrict__ sums) {
-    planes_reduce2<VEC>(batch, c, hw, [&](size_t off, float (&a)[4], float (&q)[4]) {
-        if (VEC) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = v[j], q[j] = v[j] * v[j];
-        } else {
-            a[0] = x[off];
-            q[0] = a[0] * a[0];
-        }
-    }, sums);
-}
-
-template <bool VEC>
-__global__ void __launch_bounds__(DN_BLOCK)
-planes_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                            int batch, int c, int hw, int relu, double* __restrict__ sums) {
-    const int ch = blockIdx.y;
-    const float mu = stats[ch], is = stats[c + ch], sc = stats[2 * c + ch], sf = stats[3 * c + ch];
-    planes_reduce2<VEC>(batch, c, hw, [&](size_t off, float (&a)[4], float (&q)[4]) {
-        float g[4], xv[4];
-        if (VEC) {
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off), xx = *reinterpret_cast<const f32x4*>(x + off);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = gv[j], xv[j] = xx[j];
-        } else {
-            g[0] = dy[off];
-            xv[0] = x[off];
-        }
-#pragma unroll
-        for (int j = 0; j < (VEC ? 4 : 1); ++j) {
-            const float dz = (relu && !(xv[j] * sc + sf > 0.f)) ? 0.f : g[j];
-            a[j] = dz;
-            q[j] = dz * ((xv[j] - mu) * is);
-        }
-    }, sums);
-}
-
-// y = relu?(x * scale[ch] + shift[ch]); one float4 (or float) per thread and iteration
-template <bool VEC>
-__global__ void __launch_bounds__(DN_BLOCK)
-planes_affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                         long long total, int c, int hw, int relu, float* __restrict__ y) {
-    constexpr int W = VEC ? 4 : 1;
-    const long long stride = (long long)gridDim.x * DN_BLOCK * W;
-    for (long long e = ((long long)blockIdx.x * DN_BLOCK + threadIdx.x) * W; e < total; e += stride) {
-        const int ch = (int)((e / hw) % c);
-        const float sc = scale[ch], sf = shift[ch];
-        if (VEC) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(x + e);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = v[j] * sc + sf;
-                if (relu) v[j] = fmaxf(v[j], 0.f);
-            }
-            *reinterpret_cast<f32x4*>(y + e) = v;
-        } else {
-            float v = x[e] * sc + sf;
-            y[e] = relu ? fmaxf(v, 0.f) : v;
-        }
-    }
-}
-
-template <bool VEC>
-__global__ void __launch_bounds__(DN_BLOCK)
-planes_bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                           const float* __restrict__ gamma, const double* __restrict__ sums, long long total, int c, int hw,
-                           long long n, int relu, float* __restrict__ dx) {
-    constexpr int W = VEC ? 4 : 1;
-    const long long stride = (long long)gridDim.x * DN_BLOCK * W;
-    const double inv_n = 1.0 / (double)n;
-    for (long long e = ((long long)blockIdx.x * DN_BLOCK + threadIdx.x) * W; e < total; e += stride) {
-        const int ch = (int)((e / hw) % c);
-        const float mu = stats[ch], is = stats[c + ch], sc = stats[2 * c + ch], sf = stats[3 * c + ch];
-        const float m1 = (float)(sums[ch] * inv_n), m2 = (float)(sums[c + ch] * inv_n);
-        const float k1 = gamma[ch] * is, k2 = is * m2;
-        if (VEC) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + e), xv = *reinterpret_cast<const f32x4*>(x + e);
-            f32x4 out;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float dz = (relu && !(xv[j] * sc + sf > 0.f)) ? 0.f : g[j];
-                out[j] = k1 * (dz - m1 - (xv[j] - mu) * k2);
-            }
-            *reinterpret_cast<f32x4*>(dx + e) = out;
-        } else {
-            const float dz = (relu && !(x[e] * sc + sf > 0.f)) ? 0.f : dy[e];
-            dx[e] = k1 * (dz - m1 - (x[e] - mu) * k2);
-        }
-    }
-}
-
 // grid for the grid-stride elementwise kernels: <= EW_BLOCKS blocks and (blocks * 256 * 4) % c == 0
 static int ew_grid(long long n4, int c) {
     long long blocks = (n4 + DN_BLOCK - 1) / DN_BLOCK;
@@ -546,59 +406,6 @@ extern "C" int toda_bn_finalize(const double* sums, int n, int c, const float* g
     TODA_CHECK_ARG(training || (running_mean && running_var), "bn_finalize: eval mode needs running statistics");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(DN_BLOCK), 0, (hipStream_t)stream, sums, n, c, gamma, beta,
                        running_mean, running_var, momentum, eps, training, mean, invstd, scale, shift);
-    TODA_LAUNCH_CHECK();
-    return TODA_OK;
-}
-
-// ---- BatchNorm2d(+ReLU) over NCHW planes ---------------------------------------------------------
-static int planes_chunks(int batch, int hw) { return cdiv((long long)batch * hw, PL_CHUNK); }
-
-extern "C" size_t toda_planes_reduce_doubles(int batch, int c, int hw) {
-    return (size_t)2 * c * (1 + (size_t)planes_chunks(batch > 0 ? batch : 1, hw > 0 ? hw : 1));
-}
-
-#define PLANES_CHECK(name)                                                                                         \
-    TODA_CHECK_ARG(batch >= 1 && c >= 1 && c <= DN_BLOCK && hw >= 1, name ": need batch >= 1, 1 <= channels <= 256, hw >= 1"); \
-    hipStream_t s = (hipStream_t)stream;                                                                           \
-    const bool vec = (hw & 3) == 0;                                                                                \
-    const long long total = (long long)batch * c * hw
-
-extern "C" int toda_planes_moments(const float* x, int batch, int c, int hw, double* sums, void* stream) {
-    PLANES_CHECK("planes_moments");
-    (void)total;
-    const dim3 grid(planes_chunks(batch, hw), c);
-    if (vec) hipLaunchKernelGGL(planes_moments_kernel<true>, grid, dim3(DN_BLOCK), 0, s, x, batch, c, hw, sums);
-    else hipLaunchKernelGGL(planes_moments_kernel<false>, grid, dim3(DN_BLOCK), 0, s, x, batch, c, hw, sums);
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c), dim3(DN_BLOCK), 0, s, sums, (int)grid.x, 2 * c);
-    TODA_LAUNCH_CHECK();
-    return TODA_OK;
-}
-
-extern "C" int toda_planes_affine_act(const float* x, const float* scale, const float* shift, int batch, int c, int hw, int relu,
-                                      float* y, void* stream) {
-    PLANES_CHECK("planes_affine_act");
-    const int w = vec ? 4 : 1;
-    long long blocks = (total / w + DN_BLOCK - 1) / DN_BLOCK;
-    if (blocks > 4096) blocks = 4096;
-    if (vec) hipLaunchKernelGGL(planes_affine_act_kernel<true>, dim3((int)blocks), dim3(DN_BLOCK), 0, s, x, scale, shift, total, c, hw, relu, y);
-    else hipLaunchKernelGGL(planes_affine_act_kernel<false>, dim3((int)blocks), dim3(DN_BLOCK), 0, s, x, scale, shift, total, c, hw, relu, y);
-    TODA_LAUNCH_CHECK();
-    return TODA_OK;
-}
-
-extern "C" int toda_planes_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int batch, int c,
-                                  int hw, int relu, double* sums, float* dx, void* stream) {
-    PLANES_CHECK("planes_bn_bwd");
-    const dim3 grid(planes_chunks(batch, hw), c);
-    if (vec) hipLaunchKernelGGL(planes_bn_bwd_reduce_kernel<true>, grid, dim3(DN_BLOCK), 0, s, dy, x, stats, batch, c, hw, relu, sums);
-    else hipLaunchKernelGGL(planes_bn_bwd_reduce_kernel<false>, grid, dim3(DN_BLOCK), 0, s, dy, x, stats, batch, c, hw, relu, sums);
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c), dim3(DN_BLOCK), 0, s, sums, (int)grid.x, 2 * c);
-    const int w = vec ? 4 : 1;
-    long long blocks = (total / w + DN_BLOCK - 1) / DN_BLOCK;
-    if (blocks > 4096) blocks = 4096;
-    const long long n = (long long)batch * hw;
-    if (vec) hipLaunchKernelGGL(planes_bn_bwd_apply_kernel<true>, dim3((int)blocks), dim3(DN_BLOCK), 0, s, dy, x, stats, gamma, sums, total, c, hw, n, relu, dx);
-    else hipLaunchKernelGGL(planes_bn_bwd_apply_kernel<false>, dim3((int)blocks), dim3(DN_BLOCK), 0, s, dy, x, stats, gamma, sums, total, c, hw, n, relu, dx);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

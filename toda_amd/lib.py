@@ -50,10 +50,9 @@ SIGNATURES = {
     "toda_bn_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp, _vp, _vp]),
     "toda_rows_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_rows_bn_bwd_res": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "toda_planes_reduce_doubles": (_sz, [_i, _i, _i]),
-    "toda_planes_moments": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "toda_planes_affine_act": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "toda_planes_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "toda_bn2d_supported": (_i, [_i, _i, _i]),
+    "toda_bn2d_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp]),
+    "toda_bn2d_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "toda_boxes_iou_bev": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "toda_boxes_overlap_bev": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "toda_nms_workspace_bytes": (_sz, [_i]),

@@ -667,71 +667,62 @@ def bn_rows_supported(x, bn):
             and x.shape[0] > 1)
 
 
-class _BNPlanes(torch.autograd.Function):
-    """nn.BatchNorm2d(+ReLU) on NCHW tensors with the library's plane kernels (toda_planes_moments -> toda_bn_finalize ->
-    toda_planes_affine_act; backward toda_planes_bn_bwd with the ReLU mask recomputed from x)."""
+class _BN2d(torch.autograd.Function):
+    """Training-mode nn.BatchNorm2d (+ nn.ReLU) in one pass per direction (toda_bn2d_fwd / _bwd): a workgroup keeps a channel's
+    values in registers, so forward reads x once and writes y once; the running statistics are updated by the kernel like
+    nn.BatchNorm2d does; backward recomputes the ReLU mask from x (reference base_bev_backbone.py:37-58, center_head.py:20-28)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
         lib = L.load()
         x = x.contiguous()
         b, c, h, w = x.shape
-        hw = h * w
-        stats = torch.empty((4, c), dtype=torch.float32, device=x.device)
-        sums = torch.empty((lib.toda_planes_reduce_doubles(b, c, hw),), dtype=torch.float64, device=x.device)
-        if training:
-            L.check(lib.toda_planes_moments(L.ptr(x), b, c, hw, L.ptr(sums), L.stream()), "toda_planes_moments")
-        rc = lib.toda_bn_finalize(L.ptr(sums), b * hw, c, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
-                                  float(momentum), float(eps), int(bool(training)), L.ptr(stats[0]), L.ptr(stats[1]),
-                                  L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
-        L.check(rc, "toda_bn_finalize")
         y = torch.empty_like(x)
-        rc = lib.toda_planes_affine_act(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), b, c, hw, int(bool(relu)), L.ptr(y), L.stream())
-        L.check(rc, "toda_planes_affine_act")
-        ctx.save_for_backward(x, stats, weight)
-        ctx.meta = (b, c, hw, bool(relu), bool(training))
+        save = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        rc = lib.toda_bn2d_fwd(L.ptr(x), b, c, h * w, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var), float(momentum),
+                               float(eps), int(bool(relu)), L.ptr(y), L.ptr(save), L.stream())
+        L.check(rc, "toda_bn2d_fwd")
+        ctx.save_for_backward(x, weight, bias, save)
+        ctx.relu = bool(relu)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, stats, weight = ctx.saved_tensors
-        b, c, hw, relu, training = ctx.meta
-        gy = gy.contiguous()
-        if not training:
-            sc, sf = stats[2].view(1, c, 1, 1), stats[3].view(1, c, 1, 1)
-            dz = gy * (x * sc + sf > 0) if relu else gy
-            xhat = (x - stats[0].view(1, c, 1, 1)) * stats[1].view(1, c, 1, 1)
-            return dz * sc, (dz * xhat).sum((0, 2, 3)), dz.sum((0, 2, 3)), None, None, None, None, None, None
+        x, weight, bias, save = ctx.saved_tensors
         lib = L.load()
-        sums = torch.empty((lib.toda_planes_reduce_doubles(b, c, hw),), dtype=torch.float64, device=x.device)
+        b, c, h, w = x.shape
+        gy = gy.contiguous()
         gx = torch.empty_like(x)
-        rc = lib.toda_planes_bn_bwd(L.ptr(gy), L.ptr(x), L.ptr(stats), L.ptr(weight), b, c, hw, int(relu), L.ptr(sums), L.ptr(gx),
-                                    L.stream())
-        L.check(rc, "toda_planes_bn_bwd")
-        gs = sums[:2 * c].to(torch.float32)
-        return gx, gs[c:], gs[:c], None, None, None, None, None, None
+        gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        rc = lib.toda_bn2d_bwd(L.ptr(x), L.ptr(gy), b, c, h * w, L.ptr(weight), L.ptr(bias), L.ptr(save), int(ctx.relu), L.ptr(gx),
+                               L.ptr(gwb[0]), L.ptr(gwb[1]), L.stream())
+        L.check(rc, "toda_bn2d_bwd")
+        return gx, gwb[0], gwb[1], None, None, None, None, None
 
 
-# Opt-in (TODA_PLANES_BN=1).  Isolated, BN + ReLU of a 2 x 128 x 188 x 188 map takes 26 us forward / 32 us backward here against
-# 41 / 55 us for torch's MIOpen BatchNorm + ReLU pair, but inside the full C3 step the difference stays within the run-to-run
-# noise (27.8 vs 27.8 ms over three alternations), so the library path stays the default.
-PLANES_BN = _os.environ.get("TODA_PLANES_BN", "0") == "1"
+FUSED_BN2D = _os.environ.get("TODA_BN2D", "1") == "1"
 
 
-def bn_planes_supported(x, bn):
-    return (PLANES_BN and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 256 and bn.affine
-            and bn.momentum is not None and bn.track_running_stats and x.is_contiguous())
+def bn2d_supported(x, bn):
+    """Training-mode nn.BatchNorm2d modules (exactly that class: SyncBatchNorm keeps its own path) on contiguous fp32 NCHW GPU
+    tensors whose channel fits the kernel's register image."""
+    if not (FUSED_BN2D and type(bn) is torch.nn.BatchNorm2d and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    return bool(L.load().toda_bn2d_supported(x.shape[0], x.shape[1], x.shape[2] * x.shape[3]))
 
 
-def bn_planes(x, bn, relu):
-    """Apply an nn.BatchNorm2d module (parameters, buffers, train / eval state) to an NCHW tensor, fused with a following ReLU."""
+def bn2d(x, bn, relu):
+    """Apply a training-mode nn.BatchNorm2d module (parameters, running statistics, step counter) fused with a following ReLU."""
     bump_bn_counter(bn)
-    return _BNPlanes.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, relu)
+    return _BN2d.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu)
 
 
 def run_dense_sequential(seq, x):
-    """nn.Sequential forward that sends every BatchNorm2d (+ the ReLU after it) through bn_planes on the GPU; any other
-    module, and everything on the CPU, runs as is.  Module tree and state_dict are untouched."""
+    """nn.Sequential forward that sends the 3x3 convolutions to the Winograd kernels and every training-mode BatchNorm2d (+ the ReLU
+    after it) to the single-pass kernel (bn2d) on the GPU; any other module, and everything on the CPU, runs as is.  Module tree
+    and state_dict are untouched."""
     mods = list(seq)
     i = 0
     while i < len(mods):
@@ -745,9 +736,9 @@ def run_dense_sequential(seq, x):
             continue
         elif type(m) is torch.nn.Conv2d and m.padding == (1, 1) and conv3x3_supported(x, m):
             x = conv3x3(x, m.weight, m.bias)
-        elif type(m) is torch.nn.BatchNorm2d and bn_planes_supported(x, m):
+        elif type(m) is torch.nn.BatchNorm2d and bn2d_supported(x, m):
             relu = i + 1 < len(mods) and type(mods[i + 1]) is torch.nn.ReLU
-            x = bn_planes(x, m, relu)
+            x = bn2d(x, m, relu)
             i += 2 if relu else 1
             continue
         elif type(m) is torch.nn.BatchNorm2d and x.is_cuda and m.track_running_stats and m.momentum is not None:
@@ -1028,8 +1019,11 @@ def fused_branch_hidden(owner, x, blocks):
     rm, rv = _aliased_running_stats(owner, bns)
     for bn in bns:
         bump_bn_counter(bn)
-    y = torch.nn.functional.batch_norm(y, rm, rv, torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns]),
-                                       bns[0].training, bns[0].momentum, bns[0].eps)
+    gamma, beta = torch.cat([bn.weight for bn in bns]), torch.cat([bn.bias for bn in bns])
+    if (FUSED_BN2D and bns[0].training and all(type(bn) is torch.nn.BatchNorm2d for bn in bns) and y.is_contiguous()
+            and L.load().toda_bn2d_supported(y.shape[0], y.shape[1], y.shape[2] * y.shape[3])):
+        return _BN2d.apply(y, gamma, beta, rm, rv, bns[0].momentum, bns[0].eps, True)
+    y = torch.nn.functional.batch_norm(y, rm, rv, gamma, beta, bns[0].training, bns[0].momentum, bns[0].eps)
     return torch.relu_(y)
 
 

@@ -27,7 +27,7 @@ class OpTable:
         self._orig = {}
         for name in ("toda_voxelize_hard", "toda_mean_vfe_fwd", "toda_mean_vfe_bwd", "toda_gridindex_from_coords", "toda_gridindex_from_conv",
                      "toda_rulebook_subm", "toda_rulebook_conv", "toda_sparse_to_dense_fwd", "toda_sparse_to_dense_bwd", "toda_rows_moments",
-                     "toda_rows_affine_act", "toda_rows_bn_bwd_res", "toda_spconv_pack_weight", "toda_conv3x3_transform_weight",
+                     "toda_rows_affine_act", "toda_rows_bn_bwd_res", "toda_bn2d_fwd", "toda_bn2d_bwd", "toda_spconv_pack_weight", "toda_conv3x3_transform_weight",
                      "toda_center_assign"):
             self._wrap_c(name)
         self._wrap_py("gather_gemm", self._cost_gather_gemm)
@@ -170,6 +170,16 @@ class OpTable:
     def _c_toda_rows_bn_bwd_res(a):
         n, c = a[5], a[6]
         return (n, c), ("fixed", 20.0 * n * c, 0.0, "")
+
+    @staticmethod
+    def _c_toda_bn2d_fwd(a):
+        b, c, hw = a[1], a[2], a[3]
+        return (b, c, hw), ("fixed", 8.0 * b * c * hw, 0.0, "x read once, y written once")
+
+    @staticmethod
+    def _c_toda_bn2d_bwd(a):
+        b, c, hw = a[2], a[3], a[4]
+        return (b, c, hw), ("fixed", 16.0 * b * c * hw, 0.0, "x twice (second time from the caches), dy once, dx once")
 
     @staticmethod
     def _c_toda_spconv_pack_weight(a):

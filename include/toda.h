@@ -221,8 +221,8 @@ int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual 
 /* Single-pass training-mode nn.BatchNorm2d (+ nn.ReLU) of the BEV neck and heads (base_bev_backbone.py:37-58,
  * center_head.py:20-28, 73-80; replaces torch's batch_norm + relu_ pair and their backward): one workgroup holds a
  * channel's batch*hw values in registers, so the tensor is read once and written once forward; backward reads x twice,
- * dy once.  toda_bn2d_supported: hw % 4 == 0 and batch*hw small enough for the register image (batch 1 / 2: hw <= 36864,
- * batch 4: hw <= 16384).  save = [2][c] floats (mean, 1/sqrt(var + eps)) from forward for backward.  running_mean /
+ * dy once.  toda_bn2d_supported: batch 1, 2 or 4 and batch*hw small enough for the register image (72 floats per thread:
+ * batch 1 / 2: hw <= 36864, batch 4: hw <= 16384); hw % 4 == 0 uses 16-byte accesses, any other hw dword accesses.  save = [2][c] floats (mean, 1/sqrt(var + eps)) from forward for backward.  running_mean /
  * running_var (nullable together) are updated in place like nn.BatchNorm2d does (momentum, unbiased variance).
  * relu != 0: y = max(bn(x), 0); backward recomputes the mask from x with the forward's expression. */
 int toda_bn2d_supported(int batch, int c, int hw);

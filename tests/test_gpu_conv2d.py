@@ -180,7 +180,8 @@ def test_separate_head_fused_hidden_layer_matches_branchwise_modules():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 128, 188, 188), (2, 256, 94, 94), (1, 64, 180, 180), (4, 32, 64, 64), (2, 320, 36, 20), (2, 7, 2, 2)])
+@pytest.mark.parametrize("shape", [(2, 128, 188, 188), (2, 256, 94, 94), (1, 64, 180, 180), (4, 32, 64, 64), (2, 320, 36, 20), (2, 7, 2, 2),
+                                   (2, 64, 47, 45), (1, 5, 191, 193), (4, 3, 7, 9)])
 @pytest.mark.parametrize("relu", [True, False])
 def test_single_pass_batchnorm2d_matches_torch(shape, relu):
     """toda_bn2d_fwd / _bwd against nn.BatchNorm2d (+ReLU) in fp64 on the same tensors: output, running statistics, input / weight /

@@ -484,8 +484,9 @@ def test_fused_bn_shortcut_relu_matches_torch(c, train):
                                                 ((3, 256, 94, 94), False, True), ((2, 32, 20, 20), True, False)])
 def test_dense_sequential_batchnorm2d_matches_torch(shape, relu, train):
     """BatchNorm2d + ReLU of the BEV neck and heads through ops.run_dense_sequential against nn.BatchNorm2d in fp64: output, input
-    gradient, affine gradients, running statistics.  The first case runs the single-pass kernel (toda_bn2d_*); hw % 4 != 0, a
-    batch of 3 and eval mode stay on torch - same results either way."""
+    gradient, affine gradients, running statistics.  The first two cases run the single-pass kernel (toda_bn2d_*; hw % 4 != 0
+    with dword accesses - torch's own BatchNorm2d backward on this ROCm build is off by up to 35 % in dgamma on that
+    2 x 64 x 47 x 45 input, which is why the kernel covers it); a batch of 3 and eval mode stay on torch."""
     from toda_amd import ops
 
     b, c, h, w = shape
@@ -507,15 +508,13 @@ def test_dense_sequential_batchnorm2d_matches_torch(shape, relu, train):
     yr = torch.relu(pre) if relu else pre
     yr.backward(torch.from_numpy(g).double())
     xm = dev(x).requires_grad_(True)
-    assert ops.bn2d_supported(xm, mine) == (train and b in (1, 2, 4) and (h * w) % 4 == 0)
+    assert ops.bn2d_supported(xm, mine) == (train and b in (1, 2, 4))
     seq = torch.nn.Sequential(mine, torch.nn.ReLU()) if relu else torch.nn.Sequential(mine)
     ym = ops.run_dense_sequential(seq, xm)
     ym.backward(dev(g))
     np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=2e-5)
     safe = (pre.detach().abs() > 1e-5).numpy() if relu else np.ones(shape, bool)
-    ours = ops.bn2d_supported(xm, mine)
-    # (torch's own BatchNorm2d backward on the GPU is only good to a few 1e-3 absolute against fp64 on the odd-sized case)
-    np.testing.assert_allclose(xm.grad.cpu().numpy()[safe], xr.grad.numpy()[safe], rtol=2e-3, atol=1e-5 if ours else 6e-3)
+    np.testing.assert_allclose(xm.grad.cpu().numpy()[safe], xr.grad.numpy()[safe], rtol=2e-3, atol=1e-5)
     np.testing.assert_allclose(mine.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=1e-4, atol=2e-2)
     np.testing.assert_allclose(mine.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=1e-4, atol=2e-2)
     np.testing.assert_allclose(mine.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)

@@ -37,41 +37,61 @@ __device__ __forceinline__ double bn2_block_sum(double v, double* sh) {
 // A plane (one channel of one sample) as a bounds-checked buffer: lanes past its end read zeros and their stores are dropped,
 // so neither kernel has a branch (or an address select) around a memory instruction.  The whole offset goes into the VECTOR
 // offset: the range check of a raw buffer covers vector + immediate offset only, a scalar offset would walk into the next plane.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t bn2_plane(const float* base, size_t plane, int hw4) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + plane * (size_t)hw4 * 4), 0, hw4 * 16, 0x00020000);
+template <int V>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bn2_plane(const float* base, size_t plane, int hwv) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + plane * (size_t)hwv * V), 0, hwv * V * 4, 0x00020000);
 }
-template <int AUX>
-__device__ __forceinline__ f32x4 bn2_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, int k) {
+// V = 4: planes whose size is a multiple of 4 floats (16-byte loads); V = 1: any size, dword loads (a plane then starts at any
+// 4-byte boundary).  Same code for both: a "vector" of V floats per load.
+template <int V> struct bn2_vec { typedef f32x4 type; };
+template <> struct bn2_vec<1> { typedef float type; };
+__device__ __forceinline__ float bn2_get(const f32x4& v, int j) { return v[j]; }
+__device__ __forceinline__ float bn2_get(const float& v, int) { return v; }
+__device__ __forceinline__ void bn2_set(f32x4& v, int j, float a) { v[j] = a; }
+__device__ __forceinline__ void bn2_set(float& v, int, float a) { v = a; }
+template <int V, int AUX>
+__device__ __forceinline__ typename bn2_vec<V>::type bn2_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, int k) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    return __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)k * (BN2_BLOCK * 16u), 0, AUX));
+    if constexpr (V == 4)
+        return __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, voff + (unsigned)k * (BN2_BLOCK * 16u), 0, AUX));
+    else
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + (unsigned)k * (BN2_BLOCK * 4u), 0, AUX));
 }
-__device__ __forceinline__ void bn2_store(__amdgpu_buffer_rsrc_t rs, unsigned voff, int k, f32x4 v) {
+template <int V>
+__device__ __forceinline__ void bn2_store(__amdgpu_buffer_rsrc_t rs, unsigned voff, int k, typename bn2_vec<V>::type v) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff + (unsigned)k * (BN2_BLOCK * 16u), 0, 0);
+    if constexpr (V == 4)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff + (unsigned)k * (BN2_BLOCK * 16u), 0, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff + (unsigned)k * (BN2_BLOCK * 4u), 0, 0);
 }
 constexpr int BN2_NT = 2;      // aux bit 1 (slc / nt): streamed once
 
-template <int BB, int K, bool RELU>
+template <int V, int BB, int K, bool RELU>
 __global__ void __launch_bounds__(BN2_BLOCK)
-bn2d_fwd_kernel(const float* __restrict__ x, int C, int hw4, const float* __restrict__ gamma, const float* __restrict__ beta,
+bn2d_fwd_kernel(const float* __restrict__ x, int C, int hwv, const float* __restrict__ gamma, const float* __restrict__ beta,
                 float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
                 float* __restrict__ y, float* __restrict__ save) {
     __shared__ double sh[BN2_BLOCK / 64];
     const int c = blockIdx.x, t = threadIdx.x;
-    const unsigned voff = (unsigned)t * 16u;
-    f32x4 r[BB][K];
+    const unsigned voff = (unsigned)t * (V * 4u);
+    typedef typename bn2_vec<V>::type vec_t;
+    vec_t r[BB][K];
 #pragma unroll
     for (int b = 0; b < BB; ++b) {
-        const __amdgpu_buffer_rsrc_t rs = bn2_plane(x, (size_t)b * C + c, hw4);
+        const __amdgpu_buffer_rsrc_t rs = bn2_plane<V>(x, (size_t)b * C + c, hwv);
 #pragma unroll
-        for (int k = 0; k < K; ++k) r[b][k] = bn2_load<BN2_NT>(rs, voff, k);
+        for (int k = 0; k < K; ++k) r[b][k] = bn2_load<V, BN2_NT>(rs, voff, k);
     }
-    const double n = (double)BB * hw4 * 4.0;
+    const double n = (double)BB * hwv * V;
     float s = 0.f;
 #pragma unroll
     for (int b = 0; b < BB; ++b)
 #pragma unroll
-        for (int k = 0; k < K; ++k) s += (r[b][k][0] + r[b][k][1]) + (r[b][k][2] + r[b][k][3]);
+        for (int k = 0; k < K; ++k) {
+            if constexpr (V == 4) s += (r[b][k][0] + r[b][k][1]) + (r[b][k][2] + r[b][k][3]);
+            else s += r[b][k];
+        }
     const double mean_d = bn2_block_sum((double)s, sh) / n;
     const float mean = (float)mean_d;
     float q = 0.f;
@@ -79,10 +99,10 @@ bn2d_fwd_kernel(const float* __restrict__ x, int C, int hw4, const float* __rest
     for (int b = 0; b < BB; ++b)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const bool ok = t + k * BN2_BLOCK < hw4;
+            const bool ok = t + k * BN2_BLOCK < hwv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = ok ? r[b][k][j] - mean : 0.f;
+            for (int j = 0; j < V; ++j) {
+                const float d = ok ? bn2_get(r[b][k], j) - mean : 0.f;
                 q += d * d;
             }
         }
@@ -95,16 +115,16 @@ bn2d_fwd_kernel(const float* __restrict__ x, int C, int hw4, const float* __rest
     const float shift = beta[c] - mean * scale;
 #pragma unroll
     for (int b = 0; b < BB; ++b) {
-        const __amdgpu_buffer_rsrc_t rs = bn2_plane(y, (size_t)b * C + c, hw4);
+        const __amdgpu_buffer_rsrc_t rs = bn2_plane<V>(y, (size_t)b * C + c, hwv);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            f32x4 o;
+            vec_t o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float z = r[b][k][j] * scale + shift;
-                o[j] = RELU ? (z > 0.f ? z : 0.f) : z;
+            for (int j = 0; j < V; ++j) {
+                const float z = bn2_get(r[b][k], j) * scale + shift;
+                bn2_set(o, j, RELU ? (z > 0.f ? z : 0.f) : z);
             }
-            bn2_store(rs, voff, k, o);
+            bn2_store<V>(rs, voff, k, o);
         }
     }
     if (t == 0) {
@@ -118,51 +138,54 @@ bn2d_fwd_kernel(const float* __restrict__ x, int C, int hw4, const float* __rest
     }
 }
 
-template <int BB, int K, bool RELU>
+template <int V, int BB, int K, bool RELU>
 __global__ void __launch_bounds__(BN2_BLOCK)
-bn2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C, int hw4, const float* __restrict__ gamma,
+bn2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C, int hwv, const float* __restrict__ gamma,
                 const float* __restrict__ beta, const float* __restrict__ save, float* __restrict__ dx,
                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ double sh[BN2_BLOCK / 64];
     const int c = blockIdx.x, t = threadIdx.x;
-    const unsigned voff = (unsigned)t * 16u;
+    const unsigned voff = (unsigned)t * (V * 4u);
     const float mean = save[c], invstd = save[C + c];
     const float scale = gamma[c] * invstd;
     const float shift = beta[c] - mean * scale;
-    f32x4 g[BB][K];
+    typedef typename bn2_vec<V>::type vec_t;
+    vec_t g[BB][K];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int b = 0; b < BB; ++b) {
-        const __amdgpu_buffer_rsrc_t rx = bn2_plane(x, (size_t)b * C + c, hw4), rg = bn2_plane(dy, (size_t)b * C + c, hw4);
+        const __amdgpu_buffer_rsrc_t rx = bn2_plane<V>(x, (size_t)b * C + c, hwv), rg = bn2_plane<V>(dy, (size_t)b * C + c, hwv);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const f32x4 xv = bn2_load<0>(rx, voff, k);                  // kept in the caches for the second sweep
-            f32x4 gv = bn2_load<BN2_NT>(rg, voff, k);                   // past the end of the plane: zeros
+            vec_t xv = bn2_load<V, 0>(rx, voff, k);                     // kept in the caches for the second sweep
+            vec_t gv = bn2_load<V, BN2_NT>(rg, voff, k);                // past the end of the plane: zeros
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (RELU) gv[j] = xv[j] * scale + shift > 0.f ? gv[j] : 0.f;      // the forward's expression, bit for bit
-                s1 += gv[j];
-                s2 += gv[j] * ((xv[j] - mean) * invstd);
+            for (int j = 0; j < V; ++j) {
+                const float xj = bn2_get(xv, j);
+                const float gj = (!RELU || xj * scale + shift > 0.f) ? bn2_get(gv, j) : 0.f;      // the forward's expression, bit for bit
+                bn2_set(gv, j, gj);
+                s1 += gj;
+                s2 += gj * ((xj - mean) * invstd);
             }
             g[b][k] = gv;
             // at most three (x, dy) pairs in flight on top of the g image (128 registers at 16 waves per workgroup)
             if ((b * K + k) % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    const double n = (double)BB * hw4 * 4.0;
+    const double n = (double)BB * hwv * V;
     const double sum_g = bn2_block_sum((double)s1, sh);
     const double sum_gx = bn2_block_sum((double)s2, sh);
     const float m1 = (float)(sum_g / n), m2 = (float)(sum_gx / n);
 #pragma unroll
     for (int b = 0; b < BB; ++b) {
-        const __amdgpu_buffer_rsrc_t rx = bn2_plane(x, (size_t)b * C + c, hw4), rd = bn2_plane(dx, (size_t)b * C + c, hw4);
+        const __amdgpu_buffer_rsrc_t rx = bn2_plane<V>(x, (size_t)b * C + c, hwv), rd = bn2_plane<V>(dx, (size_t)b * C + c, hwv);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const f32x4 xv = bn2_load<BN2_NT>(rx, voff, k);
-            f32x4 o;
+            vec_t xv = bn2_load<V, BN2_NT>(rx, voff, k);
+            vec_t o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = scale * (g[b][k][j] - m1 - (xv[j] - mean) * invstd * m2);
-            bn2_store(rd, voff, k, o);
+            for (int j = 0; j < V; ++j) bn2_set(o, j, scale * (bn2_get(g[b][k], j) - m1 - (bn2_get(xv, j) - mean) * invstd * m2));
+            bn2_store<V>(rd, voff, k, o);
             if ((b * K + k) % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -172,55 +195,77 @@ bn2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C
     }
 }
 
-// smallest instantiated K >= float4 per plane and thread
-static int bn2_pick_k(int hw4) {
-    const int need = cdiv(hw4, BN2_BLOCK);
-    for (int k : {1, 2, 3, 4, 8, 9})
-        if (k >= need) return k;
+// smallest instantiated K >= vectors per plane and thread (0: none).  V = 4: K in {1, 2, 3, 4, 8, 9}; V = 1: {4, 9, 18, 36}
+static int bn2_pick_k(int hwv, int v) {
+    const int need = cdiv(hwv, BN2_BLOCK);
+    if (v == 4) {
+        for (int k : {1, 2, 3, 4, 8, 9})
+            if (k >= need) return k;
+    } else {
+        for (int k : {4, 9, 18, 36})
+            if (k >= need) return k;
+    }
     return 0;
+}
+static int bn2_floats_per_thread(int batch, int hw) {      // 0: unsupported
+    if (batch < 1 || hw < 1) return 0;
+    const int v = (hw & 3) ? 1 : 4;
+    const int k = bn2_pick_k(hw / v, v);
+    if (!k || !(batch == 1 || batch == 2 || batch == 4)) return 0;
+    return batch * k * v <= 72 ? batch * k * v : 0;            // the register image: 72 floats per thread
 }
 }  // namespace toda
 
 using namespace toda;
 
 extern "C" int toda_bn2d_supported(int batch, int c, int hw) {
-    if (batch < 1 || c < 1 || hw < 4 || (hw & 3)) return 0;
-    const int k = bn2_pick_k(hw / 4);
-    if (!k) return 0;
-    if (batch == 1 || batch == 2) return 1;
-    return batch == 4 && k <= 4 ? 1 : 0;
+    return c >= 1 && bn2_floats_per_thread(batch, hw) > 0 ? 1 : 0;
 }
 
-#define BN2_DISPATCH(KERNEL, ...)                                                                                          \
-    do {                                                                                                                   \
-        const int k = bn2_pick_k(hw / 4);                                                                                  \
-        const dim3 grid(c), block(BN2_BLOCK);                                                                              \
-        hipStream_t s = (hipStream_t)stream;                                                                               \
-        bool done = true;                                                                                                  \
-        auto go = [&](auto bb, auto kk) {                                                                                  \
-            if (relu)                                                                                                      \
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<decltype(bb)::value, decltype(kk)::value, true>), grid, block, 0, s, __VA_ARGS__);  \
-            else                                                                                                           \
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<decltype(bb)::value, decltype(kk)::value, false>), grid, block, 0, s, __VA_ARGS__); \
-        };                                                                                                                 \
-        auto by_k = [&](auto bb) {                                                                                         \
-            switch (k) {                                                                                                   \
-                case 1: go(bb, std::integral_constant<int, 1>{}); break;                                                  \
-                case 2: go(bb, std::integral_constant<int, 2>{}); break;                                                  \
-                case 3: go(bb, std::integral_constant<int, 3>{}); break;                                                  \
-                case 4: go(bb, std::integral_constant<int, 4>{}); break;                                                  \
-                case 8: if constexpr (decltype(bb)::value <= 2) go(bb, std::integral_constant<int, 8>{}); else done = false; break; \
-                case 9: if constexpr (decltype(bb)::value <= 2) go(bb, std::integral_constant<int, 9>{}); else done = false; break; \
-                default: done = false;                                                                                     \
-            }                                                                                                              \
-        };                                                                                                                 \
-        switch (batch) {                                                                                                   \
-            case 1: by_k(std::integral_constant<int, 1>{}); break;                                                         \
-            case 2: by_k(std::integral_constant<int, 2>{}); break;                                                         \
-            case 4: by_k(std::integral_constant<int, 4>{}); break;                                                         \
-            default: done = false;                                                                                         \
-        }                                                                                                                  \
-        TODA_CHECK_ARG(done, "bn2d: no instantiation for batch %d, hw %d", batch, hw);                                     \
+template <int V, int BB, int K>
+static void bn2_launch_fwd(bool relu, dim3 grid, hipStream_t s, const float* x, int c, int hwv, const float* gamma, const float* beta, float* rm,
+                           float* rv, float momentum, float eps, float* y, float* save) {
+    if constexpr (BB * K * V <= 72) {
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_kernel<V, BB, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, c, hwv, gamma, beta, rm, rv, momentum, eps, y, save);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_kernel<V, BB, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, c, hwv, gamma, beta, rm, rv, momentum, eps, y, save);
+    }
+}
+template <int V, int BB, int K>
+static void bn2_launch_bwd(bool relu, dim3 grid, hipStream_t s, const float* x, const float* dy, int c, int hwv, const float* gamma,
+                           const float* beta, const float* save, float* dx, float* dgamma, float* dbeta) {
+    if constexpr (BB * K * V <= 72) {
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_kernel<V, BB, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_kernel<V, BB, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
+    }
+}
+
+// (V, batch, K) -> instantiation; LAUNCH is bn2_launch_fwd / bn2_launch_bwd
+#define BN2_BY_K(LAUNCH, VV, BBV, ...)                                      \
+    switch (k) {                                                            \
+        case 1: LAUNCH<VV, BBV, 1>(__VA_ARGS__); break;                     \
+        case 2: LAUNCH<VV, BBV, 2>(__VA_ARGS__); break;                     \
+        case 3: LAUNCH<VV, BBV, 3>(__VA_ARGS__); break;                     \
+        case 4: LAUNCH<VV, BBV, 4>(__VA_ARGS__); break;                     \
+        case 8: LAUNCH<VV, BBV, 8>(__VA_ARGS__); break;                     \
+        case 9: LAUNCH<VV, BBV, 9>(__VA_ARGS__); break;                     \
+        case 18: LAUNCH<VV, BBV, 18>(__VA_ARGS__); break;                   \
+        default: LAUNCH<VV, BBV, 36>(__VA_ARGS__); break;                   \
+    }
+#define BN2_DISPATCH(LAUNCH, ...)                                           \
+    do {                                                                    \
+        const int v = (hw & 3) ? 1 : 4, hwv = hw / v;                       \
+        const int k = bn2_pick_k(hwv, v);                                   \
+        const dim3 grid(c);                                                 \
+        hipStream_t s = (hipStream_t)stream;                                \
+        if (v == 4) {                                                       \
+            if (batch == 1) { BN2_BY_K(LAUNCH, 4, 1, relu != 0, grid, s, __VA_ARGS__) }       \
+            else if (batch == 2) { BN2_BY_K(LAUNCH, 4, 2, relu != 0, grid, s, __VA_ARGS__) }  \
+            else { BN2_BY_K(LAUNCH, 4, 4, relu != 0, grid, s, __VA_ARGS__) }                  \
+        } else {                                                            \
+            if (batch == 1) { BN2_BY_K(LAUNCH, 1, 1, relu != 0, grid, s, __VA_ARGS__) }       \
+            else if (batch == 2) { BN2_BY_K(LAUNCH, 1, 2, relu != 0, grid, s, __VA_ARGS__) }  \
+            else { BN2_BY_K(LAUNCH, 1, 4, relu != 0, grid, s, __VA_ARGS__) }                  \
+        }                                                                   \
     } while (0)
 
 extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const float* gamma, const float* beta, float* running_mean,
@@ -228,7 +273,7 @@ extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const flo
     TODA_CHECK_ARG(x && gamma && beta && y && save, "bn2d_fwd: null argument");
     TODA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn2d_fwd: running_mean and running_var go together");
     TODA_CHECK_ARG(toda_bn2d_supported(batch, c, hw), "bn2d_fwd: unsupported shape (batch %d, channels %d, hw %d)", batch, c, hw);
-    BN2_DISPATCH(bn2d_fwd_kernel, x, c, hw / 4, gamma, beta, running_mean, running_var, momentum, eps, y, save);
+    BN2_DISPATCH(bn2_launch_fwd, x, c, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }
@@ -237,7 +282,7 @@ extern "C" int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, 
                              const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* stream) {
     TODA_CHECK_ARG(x && dy && gamma && beta && save && dx && dgamma && dbeta, "bn2d_bwd: null argument");
     TODA_CHECK_ARG(toda_bn2d_supported(batch, c, hw), "bn2d_bwd: unsupported shape (batch %d, channels %d, hw %d)", batch, c, hw);
-    BN2_DISPATCH(bn2d_bwd_kernel, x, dy, c, hw / 4, gamma, beta, save, dx, dgamma, dbeta);
+    BN2_DISPATCH(bn2_launch_bwd, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

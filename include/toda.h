@@ -219,18 +219,25 @@ int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual 
                          float* dres /*nullable*/, void* stream);
 
 /* Single-pass training-mode nn.BatchNorm2d (+ nn.ReLU) of the BEV neck and heads (base_bev_backbone.py:37-58,
- * center_head.py:20-28, 73-80; replaces torch's batch_norm + relu_ pair and their backward): one workgroup holds a
- * channel's batch*hw values in registers, so the tensor is read once and written once forward; backward reads x twice,
- * dy once.  toda_bn2d_supported: batch 1, 2 or 4 and batch*hw small enough for the register image (72 floats per thread:
- * batch 1 / 2: hw <= 36864, batch 4: hw <= 16384); hw % 4 == 0 uses 16-byte accesses, any other hw dword accesses.  save = [2][c] floats (mean, 1/sqrt(var + eps)) from forward for backward.  running_mean /
- * running_var (nullable together) are updated in place like nn.BatchNorm2d does (momentum, unbiased variance).
- * relu != 0: y = max(bn(x), 0); backward recomputes the mask from x with the forward's expression. */
+ * center_head.py:20-28, 73-80; replaces torch's batch_norm + relu_ pair and their backward): the values of a channel sit in
+ * registers between the statistics and the normalisation, so forward reads x once and writes y once and backward reads x
+ * and dy once and writes dx once.  batch 2 / 4 with a `sync` workspace: one workgroup per (channel, sample) plane, the
+ * workgroups of a channel exchange two fp64 partial results through `sync` (hw <= 36864); otherwise one workgroup per
+ * channel (batch 1 / 2: hw <= 36864, batch 4: hw <= 16384; backward then reads x a second time).  hw % 4 == 0 uses 16-byte
+ * accesses, any other hw dword accesses.
+ * sync: toda_bn2d_sync_bytes() bytes, zeroed ONCE by the caller, used by one stream at a time, channels <= 4096; epoch:
+ * a non-zero number the caller does not repeat on that workspace (increment per call) - nothing is reset between launches.
+ * save = [2][c] floats (mean, 1/sqrt(var + eps)) from forward for backward.  running_mean / running_var (nullable
+ * together) are updated in place like nn.BatchNorm2d does (momentum, unbiased variance).  relu != 0: y = max(bn(x), 0);
+ * backward recomputes the mask from x with the forward's expression.  Deterministic (fixed summation order). */
 int toda_bn2d_supported(int batch, int c, int hw);
+size_t toda_bn2d_sync_bytes(void);
 int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const float* gamma, const float* beta,
                   float* running_mean /*nullable*/, float* running_var /*nullable*/, float momentum, float eps, int relu,
-                  float* y, float* save, void* stream);
+                  float* y, float* save, void* sync /*nullable*/, unsigned epoch, void* stream);
 int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, int hw, const float* gamma, const float* beta,
-                  const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* stream);
+                  const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* sync /*nullable*/,
+                  unsigned epoch, void* stream);
 
 /* ------------------------------------------------------------------------
  * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,

@@ -181,12 +181,18 @@ def test_separate_head_fused_hidden_layer_matches_branchwise_modules():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(2, 128, 188, 188), (2, 256, 94, 94), (1, 64, 180, 180), (4, 32, 64, 64), (2, 320, 36, 20), (2, 7, 2, 2),
-                                   (2, 64, 47, 45), (1, 5, 191, 193), (4, 3, 7, 9)])
+                                   (2, 64, 47, 45), (1, 5, 191, 193), (4, 3, 7, 9), (4, 16, 180, 180), (2, 12, 190, 194)])
 @pytest.mark.parametrize("relu", [True, False])
-def test_single_pass_batchnorm2d_matches_torch(shape, relu):
+@pytest.mark.parametrize("split", [True, False])
+def test_single_pass_batchnorm2d_matches_torch(shape, relu, split, monkeypatch):
     """toda_bn2d_fwd / _bwd against nn.BatchNorm2d (+ReLU) in fp64 on the same tensors: output, running statistics, input / weight /
-    bias gradients (reference base_bev_backbone.py:37-58: BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU)."""
+    bias gradients (reference base_bev_backbone.py:37-58: BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU).  split: one workgroup
+    per (channel, sample) plane with the partner exchange (what ops passes a workspace for); otherwise one workgroup per channel."""
     from toda_amd import ops
+    if not split:
+        if shape[0] == 4 and shape[2] * shape[3] > 16384:
+            pytest.skip("batch 4 above 128 x 128 needs the partner exchange")
+        monkeypatch.setattr(ops, "_bn2d_sync", lambda device: (None, 0))
     torch.manual_seed(3)
     b, c, h, w = shape
     bn = torch.nn.BatchNorm2d(c, eps=1e-3, momentum=0.01).cuda().train()

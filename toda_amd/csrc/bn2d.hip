@@ -195,6 +195,179 @@ bn2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C
     }
 }
 
+// ---- one workgroup per (channel, sample) plane, partners exchange their partial sums ------------------------------------
+// With one workgroup per channel a 128-channel layer occupies half of the 256 CUs and a thread carries batch x K vectors (the
+// backward kernel spills at 2 x 188 x 188).  Here the P = batch workgroups of a channel each hold ONE plane, publish two fp64
+// partial results to a small workspace (agent-scope atomics: partners may sit on different XCDs whose L2s are not coherent
+// for plain accesses) and wait for each other on per-workgroup epoch flags - `epoch` is a number the caller never repeats on a
+// workspace, so nothing has to be reset between launches and launches with different channel counts can share it.  Partners
+// get neighbouring workgroup ids (same XCD when the channel count is a multiple of 8): dispatch is in id order, so a waiting
+// workgroup's partners are resident or next in line - no deadlock however full the GPU is.  Every partner adds the P
+// partials in the same order: identical statistics in all of them, run-to-run deterministic.
+constexpr int BN2_MAX_SYNC_C = 4096, BN2_MAX_P = 4;
+struct Bn2Sync {
+    unsigned long long val[BN2_MAX_SYNC_C * BN2_MAX_P][2];
+    unsigned flag[BN2_MAX_SYNC_C * BN2_MAX_P];
+};
+
+__device__ __forceinline__ void bn2_plane_of_block(int C, int P, int* c, int* b) {
+    const int id = blockIdx.x;
+    if ((C & 7) == 0) {
+        const int slot = id >> 3;
+        *b = slot % P;
+        *c = (slot / P) * 8 + (id & 7);
+    } else {
+        *c = id / P;
+        *b = id - *c * P;
+    }
+}
+
+// thread 0 of the block publishes (v0, v1) for (c, b), waits for the P - 1 partners and returns all P pairs through `sh` (LDS, 2 P doubles)
+__device__ __forceinline__ void bn2_exchange(Bn2Sync* sy, int c, int b, int P, unsigned epoch, double v0, double v1, double* sh) {
+    if (threadIdx.x == 0) {
+        const int me = c * P + b;
+        __hip_atomic_store(&sy->val[me][0], (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sy->val[me][1], (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sy->flag[me], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (int p = 0; p < P; ++p) {
+            const int o = c * P + p;
+            if (p != b)
+                while (__hip_atomic_load(&sy->flag[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+            sh[2 * p] = __longlong_as_double((long long)__hip_atomic_load(&sy->val[o][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            sh[2 * p + 1] = __longlong_as_double((long long)__hip_atomic_load(&sy->val[o][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
+    __syncthreads();
+}
+
+template <int V, int K, bool RELU>
+__global__ void __launch_bounds__(BN2_BLOCK)
+bn2d_fwd_split_kernel(const float* __restrict__ x, int C, int P, int hwv, const float* __restrict__ gamma, const float* __restrict__ beta,
+                      float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                      float* __restrict__ y, float* __restrict__ save, Bn2Sync* __restrict__ sy, unsigned epoch) {
+    __shared__ double sh[BN2_BLOCK / 64];
+    __shared__ double part[2 * BN2_MAX_P];
+    int c, b;
+    bn2_plane_of_block(C, P, &c, &b);
+    const int t = threadIdx.x;
+    const unsigned voff = (unsigned)t * (V * 4u);
+    typedef typename bn2_vec<V>::type vec_t;
+    vec_t r[K];
+    const __amdgpu_buffer_rsrc_t rs = bn2_plane<V>(x, (size_t)b * C + c, hwv);
+#pragma unroll
+    for (int k = 0; k < K; ++k) r[k] = bn2_load<V, BN2_NT>(rs, voff, k);
+    const double n_b = (double)hwv * V;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if constexpr (V == 4) s += (r[k][0] + r[k][1]) + (r[k][2] + r[k][3]);
+        else s += r[k];
+    }
+    const double mean_b_d = bn2_block_sum((double)s, sh) / n_b;
+    const float mean_b = (float)mean_b_d;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool ok = t + k * BN2_BLOCK < hwv;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float d = ok ? bn2_get(r[k], j) - mean_b : 0.f;
+            q += d * d;
+        }
+    }
+    const double dmb = mean_b_d - (double)mean_b;
+    const double m2_b = bn2_block_sum((double)q, sh) - n_b * dmb * dmb;        // sum (x - mean_b)^2 of this plane
+    // planes -> channel (Chan et al.): mean = sum n_b mean_b / n, M2 = sum M2_b + sum n_b (mean_b - mean)^2; all n_b are equal
+    bn2_exchange(sy, c, b, P, epoch, mean_b_d, m2_b, part);
+    double mean_d = 0.0;
+    for (int p = 0; p < P; ++p) mean_d += part[2 * p];
+    mean_d /= P;
+    double m2 = 0.0;
+    for (int p = 0; p < P; ++p) m2 += part[2 * p + 1] + n_b * (part[2 * p] - mean_d) * (part[2 * p] - mean_d);
+    const double n = n_b * P;
+    const double var_d = m2 > 0.0 ? m2 / n : 0.0;
+    const float mean = (float)mean_d;
+    const float invstd = 1.0f / sqrtf((float)var_d + eps);
+    const float scale = gamma[c] * invstd;
+    const float shift = beta[c] - mean * scale;
+    const __amdgpu_buffer_rsrc_t ry = bn2_plane<V>(y, (size_t)b * C + c, hwv);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        vec_t o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float z = bn2_get(r[k], j) * scale + shift;
+            bn2_set(o, j, RELU ? (z > 0.f ? z : 0.f) : z);
+        }
+        bn2_store<V>(ry, voff, k, o);
+    }
+    if (t == 0 && b == 0) {
+        save[c] = mean;
+        save[C + c] = invstd;
+        if (running_mean) {
+            const double unbiased = n > 1.0 ? var_d * n / (n - 1.0) : 0.0;
+            running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+template <int V, int K, bool RELU>
+__global__ void __launch_bounds__(BN2_BLOCK)
+bn2d_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C, int P, int hwv, const float* __restrict__ gamma,
+                      const float* __restrict__ beta, const float* __restrict__ save, float* __restrict__ dx,
+                      float* __restrict__ dgamma, float* __restrict__ dbeta, Bn2Sync* __restrict__ sy, unsigned epoch) {
+    __shared__ double sh[BN2_BLOCK / 64];
+    __shared__ double part[2 * BN2_MAX_P];
+    int c, b;
+    bn2_plane_of_block(C, P, &c, &b);
+    const int t = threadIdx.x;
+    const unsigned voff = (unsigned)t * (V * 4u);
+    const float mean = save[c], invstd = save[C + c];
+    const float scale = gamma[c] * invstd;
+    const float shift = beta[c] - mean * scale;
+    typedef typename bn2_vec<V>::type vec_t;
+    vec_t g[K], xh[K];         // masked dy and the normalised x of this plane: nothing is read twice
+    float s1 = 0.f, s2 = 0.f;
+    const __amdgpu_buffer_rsrc_t rx = bn2_plane<V>(x, (size_t)b * C + c, hwv), rg = bn2_plane<V>(dy, (size_t)b * C + c, hwv);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        vec_t xv = bn2_load<V, BN2_NT>(rx, voff, k);
+        vec_t gv = bn2_load<V, BN2_NT>(rg, voff, k);                // past the end of the plane: zeros
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float xj = bn2_get(xv, j);
+            const float gj = (!RELU || xj * scale + shift > 0.f) ? bn2_get(gv, j) : 0.f;      // the forward's expression, bit for bit
+            const float hj = (xj - mean) * invstd;
+            bn2_set(gv, j, gj);
+            bn2_set(xv, j, hj);
+            s1 += gj;
+            s2 += gj * hj;
+        }
+        g[k] = gv;
+        xh[k] = xv;
+    }
+    const double p1 = bn2_block_sum((double)s1, sh);
+    const double p2 = bn2_block_sum((double)s2, sh);
+    bn2_exchange(sy, c, b, P, epoch, p1, p2, part);
+    double sum_g = 0.0, sum_gx = 0.0;
+    for (int p = 0; p < P; ++p) sum_g += part[2 * p], sum_gx += part[2 * p + 1];
+    const double n = (double)hwv * V * P;
+    const float m1 = (float)(sum_g / n), m2 = (float)(sum_gx / n);
+    const __amdgpu_buffer_rsrc_t rd = bn2_plane<V>(dx, (size_t)b * C + c, hwv);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        vec_t o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) bn2_set(o, j, scale * (bn2_get(g[k], j) - m1 - bn2_get(xh[k], j) * m2));
+        bn2_store<V>(rd, voff, k, o);
+    }
+    if (t == 0 && b == 0) {
+        dgamma[c] = (float)sum_gx;
+        dbeta[c] = (float)sum_g;
+    }
+}
+
 // smallest instantiated K >= vectors per plane and thread (0: none).  V = 4: K in {1, 2, 3, 4, 8, 9}; V = 1: {4, 9, 18, 36}
 static int bn2_pick_k(int hwv, int v) {
     const int need = cdiv(hwv, BN2_BLOCK);
@@ -207,19 +380,27 @@ static int bn2_pick_k(int hwv, int v) {
     }
     return 0;
 }
-static int bn2_floats_per_thread(int batch, int hw) {      // 0: unsupported
+static int bn2_floats_per_thread(int batch, int hw) {      // one workgroup per channel; 0: unsupported
     if (batch < 1 || hw < 1) return 0;
     const int v = (hw & 3) ? 1 : 4;
     const int k = bn2_pick_k(hw / v, v);
     if (!k || !(batch == 1 || batch == 2 || batch == 4)) return 0;
     return batch * k * v <= 72 ? batch * k * v : 0;            // the register image: 72 floats per thread
 }
+static bool bn2_split_ok(int batch, int c, int hw) {          // one workgroup per plane: 36 floats of x (and of dy) per thread
+    if (!(batch == 2 || batch == 4) || c < 1 || c > BN2_MAX_SYNC_C || hw < 1) return false;
+    const int v = (hw & 3) ? 1 : 4;
+    const int k = bn2_pick_k(hw / v, v);
+    return k > 0 && k * v <= 36;
+}
 }  // namespace toda
 
 using namespace toda;
 
+extern "C" size_t toda_bn2d_sync_bytes(void) { return sizeof(Bn2Sync); }
+
 extern "C" int toda_bn2d_supported(int batch, int c, int hw) {
-    return c >= 1 && bn2_floats_per_thread(batch, hw) > 0 ? 1 : 0;
+    return c >= 1 && (bn2_floats_per_thread(batch, hw) > 0 || bn2_split_ok(batch, c, hw)) ? 1 : 0;
 }
 
 template <int V, int BB, int K>
@@ -238,8 +419,25 @@ static void bn2_launch_bwd(bool relu, dim3 grid, hipStream_t s, const float* x, 
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_kernel<V, BB, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
     }
 }
+// split kernels: BB is the dummy 0 so that the same BN2_BY_K switch serves them; the trailing arguments carry P, sync, epoch
+template <int V, int BB, int K>
+static void bn2_launch_fwd_split(bool relu, dim3 grid, hipStream_t s, const float* x, int c, int P, int hwv, const float* gamma, const float* beta,
+                                 float* rm, float* rv, float momentum, float eps, float* y, float* save, Bn2Sync* sy, unsigned epoch) {
+    if constexpr (K * V <= 36) {
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, save, sy, epoch);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, save, sy, epoch);
+    }
+}
+template <int V, int BB, int K>
+static void bn2_launch_bwd_split(bool relu, dim3 grid, hipStream_t s, const float* x, const float* dy, int c, int P, int hwv, const float* gamma,
+                                 const float* beta, const float* save, float* dx, float* dgamma, float* dbeta, Bn2Sync* sy, unsigned epoch) {
+    if constexpr (K * V <= 36) {
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch);
+    }
+}
 
-// (V, batch, K) -> instantiation; LAUNCH is bn2_launch_fwd / bn2_launch_bwd
+// (V, batch, K) -> instantiation; LAUNCH is one of the four launchers above
 #define BN2_BY_K(LAUNCH, VV, BBV, ...)                                      \
     switch (k) {                                                            \
         case 1: LAUNCH<VV, BBV, 1>(__VA_ARGS__); break;                     \
@@ -253,10 +451,7 @@ static void bn2_launch_bwd(bool relu, dim3 grid, hipStream_t s, const float* x, 
     }
 #define BN2_DISPATCH(LAUNCH, ...)                                           \
     do {                                                                    \
-        const int v = (hw & 3) ? 1 : 4, hwv = hw / v;                       \
-        const int k = bn2_pick_k(hwv, v);                                   \
         const dim3 grid(c);                                                 \
-        hipStream_t s = (hipStream_t)stream;                                \
         if (v == 4) {                                                       \
             if (batch == 1) { BN2_BY_K(LAUNCH, 4, 1, relu != 0, grid, s, __VA_ARGS__) }       \
             else if (batch == 2) { BN2_BY_K(LAUNCH, 4, 2, relu != 0, grid, s, __VA_ARGS__) }  \
@@ -267,22 +462,41 @@ static void bn2_launch_bwd(bool relu, dim3 grid, hipStream_t s, const float* x, 
             else { BN2_BY_K(LAUNCH, 1, 4, relu != 0, grid, s, __VA_ARGS__) }                  \
         }                                                                   \
     } while (0)
+#define BN2_DISPATCH_SPLIT(LAUNCH, ...)                                     \
+    do {                                                                    \
+        const dim3 grid(c * batch);                                         \
+        if (v == 4) { BN2_BY_K(LAUNCH, 4, 0, relu != 0, grid, s, __VA_ARGS__) }               \
+        else { BN2_BY_K(LAUNCH, 1, 0, relu != 0, grid, s, __VA_ARGS__) }                      \
+    } while (0)
 
 extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const float* gamma, const float* beta, float* running_mean,
-                             float* running_var, float momentum, float eps, int relu, float* y, float* save, void* stream) {
+                             float* running_var, float momentum, float eps, int relu, float* y, float* save, void* sync, unsigned epoch,
+                             void* stream) {
     TODA_CHECK_ARG(x && gamma && beta && y && save, "bn2d_fwd: null argument");
     TODA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn2d_fwd: running_mean and running_var go together");
-    TODA_CHECK_ARG(toda_bn2d_supported(batch, c, hw), "bn2d_fwd: unsupported shape (batch %d, channels %d, hw %d)", batch, c, hw);
-    BN2_DISPATCH(bn2_launch_fwd, x, c, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save);
+    const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw);
+    TODA_CHECK_ARG(split || bn2_floats_per_thread(batch, hw) > 0, "bn2d_fwd: unsupported shape (batch %d, channels %d, hw %d)%s", batch, c, hw,
+                   sync ? "" : " without a sync workspace");
+    const int v = (hw & 3) ? 1 : 4, hwv = hw / v;
+    const int k = bn2_pick_k(hwv, v);
+    hipStream_t s = (hipStream_t)stream;
+    if (split) BN2_DISPATCH_SPLIT(bn2_launch_fwd_split, x, c, batch, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save, (Bn2Sync*)sync, epoch);
+    else BN2_DISPATCH(bn2_launch_fwd, x, c, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }
 
 extern "C" int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, int hw, const float* gamma, const float* beta,
-                             const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* stream) {
+                             const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* sync, unsigned epoch, void* stream) {
     TODA_CHECK_ARG(x && dy && gamma && beta && save && dx && dgamma && dbeta, "bn2d_bwd: null argument");
-    TODA_CHECK_ARG(toda_bn2d_supported(batch, c, hw), "bn2d_bwd: unsupported shape (batch %d, channels %d, hw %d)", batch, c, hw);
-    BN2_DISPATCH(bn2_launch_bwd, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
+    const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw);
+    TODA_CHECK_ARG(split || bn2_floats_per_thread(batch, hw) > 0, "bn2d_bwd: unsupported shape (batch %d, channels %d, hw %d)%s", batch, c, hw,
+                   sync ? "" : " without a sync workspace");
+    const int v = (hw & 3) ? 1 : 4, hwv = hw / v;
+    const int k = bn2_pick_k(hwv, v);
+    hipStream_t s = (hipStream_t)stream;
+    if (split) BN2_DISPATCH_SPLIT(bn2_launch_bwd_split, x, dy, c, batch, hwv, gamma, beta, save, dx, dgamma, dbeta, (Bn2Sync*)sync, epoch);
+    else BN2_DISPATCH(bn2_launch_bwd, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

@@ -667,10 +667,24 @@ def bn_rows_supported(x, bn):
             and x.shape[0] > 1)
 
 
+_BN2D_SYNC = {}      # (device, stream) -> [workspace, epoch]
+
+
+def _bn2d_sync(device):
+    """The partner workgroups' exchange area of toda_bn2d_*: zeroed once per (device, stream); every call takes the next epoch."""
+    key = (device.index, L.stream())
+    ent = _BN2D_SYNC.get(key)
+    if ent is None:
+        ent = _BN2D_SYNC[key] = [torch.zeros((L.load().toda_bn2d_sync_bytes(),), dtype=torch.uint8, device=device), 0]
+    ent[1] = ent[1] % 0xFFFFFFF0 + 1
+    return ent[0], ent[1]
+
+
 class _BN2d(torch.autograd.Function):
-    """Training-mode nn.BatchNorm2d (+ nn.ReLU) in one pass per direction (toda_bn2d_fwd / _bwd): a workgroup keeps a channel's
-    values in registers, so forward reads x once and writes y once; the running statistics are updated by the kernel like
-    nn.BatchNorm2d does; backward recomputes the ReLU mask from x (reference base_bev_backbone.py:37-58, center_head.py:20-28)."""
+    """Training-mode nn.BatchNorm2d (+ nn.ReLU) in one pass per direction (toda_bn2d_fwd / _bwd): a channel's values stay in
+    registers between the statistics and the normalisation, so forward reads x once and writes y once; the running statistics
+    are updated by the kernel like nn.BatchNorm2d does; backward recomputes the ReLU mask from x (reference
+    base_bev_backbone.py:37-58, center_head.py:20-28)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
@@ -679,8 +693,9 @@ class _BN2d(torch.autograd.Function):
         b, c, h, w = x.shape
         y = torch.empty_like(x)
         save = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws, epoch = _bn2d_sync(x.device)
         rc = lib.toda_bn2d_fwd(L.ptr(x), b, c, h * w, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var), float(momentum),
-                               float(eps), int(bool(relu)), L.ptr(y), L.ptr(save), L.stream())
+                               float(eps), int(bool(relu)), L.ptr(y), L.ptr(save), L.ptr(ws), epoch, L.stream())
         L.check(rc, "toda_bn2d_fwd")
         ctx.save_for_backward(x, weight, bias, save)
         ctx.relu = bool(relu)
@@ -694,8 +709,9 @@ class _BN2d(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(x)
         gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        ws, epoch = _bn2d_sync(x.device)
         rc = lib.toda_bn2d_bwd(L.ptr(x), L.ptr(gy), b, c, h * w, L.ptr(weight), L.ptr(bias), L.ptr(save), int(ctx.relu), L.ptr(gx),
-                               L.ptr(gwb[0]), L.ptr(gwb[1]), L.stream())
+                               L.ptr(gwb[0]), L.ptr(gwb[1]), L.ptr(ws), epoch, L.stream())
         L.check(rc, "toda_bn2d_bwd")
         return gx, gwb[0], gwb[1], None, None, None, None, None
 

@@ -179,7 +179,7 @@ class OpTable:
     @staticmethod
     def _c_toda_bn2d_bwd(a):
         b, c, hw = a[2], a[3], a[4]
-        return (b, c, hw), ("fixed", 16.0 * b * c * hw, 0.0, "x twice (second time from the caches), dy once, dx once")
+        return (b, c, hw), ("fixed", 12.0 * b * c * hw, 0.0, "x once, dy once, dx once")
 
     @staticmethod
     def _c_toda_spconv_pack_weight(a):

@@ -7,6 +7,19 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
+echo "== bench lines"
+# 40 warm-up steps: on these boxes a power-management transient 0.6-0.7 s after the first step (steps 33-35 of a run) costs 3-12 ms on
+# 3-8 consecutive steps (per-step times in the .err files, TODA_BENCH_STEP_MS); the *_driver_shape line is the driver's K / W
+export TODA_BENCH_STEP_MS=1
+timeout -k 10 400 python bench.py --steps 50 --warmup 40 --layers --layers-out $O/r02_layers_c3.json > $O/r02_bench_c3.json 2> $O/r02_bench_c3.err
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r02_bench_c3_driver_shape.json 2> $O/r02_bench_c3_driver_shape.err
+for w in c2 c5 c5mix c5cl; do
+  timeout -k 10 400 python bench.py --workload $w --steps 50 --warmup 40 > $O/r02_bench_$w.json 2> $O/r02_bench_$w.err
+  echo "  $w done"
+done
+timeout -k 10 400 python bench.py --workload c5 --steps 20 --warmup 8 --no-cpu-baseline --layers --layers-out $O/r02_layers_c5.json > /dev/null 2> $O/r02_layers_c5.err
+timeout -k 10 400 python bench.py --steps 300 --warmup 40 --no-cpu-baseline > $O/r02_soak_c3.json 2> $O/r02_soak_c3.err
+unset TODA_BENCH_STEP_MS
 cd /tmp && export TMPDIR=/tmp
 echo "== counters (one pass per set, kernel trace only)"
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"; do
@@ -38,19 +51,6 @@ ST=$(find /tmp/r02_st_* /tmp/r02_pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_co
 python3 $R/toda_amd/tools/pmc_summary.py gather_gemm_lds_kernel $O/r02_pmc_stall_gather_gemm.json $ST > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py wgrad_kernel $O/r02_pmc_stall_sparse_wgrad.json $ST > /dev/null
 cd $R
-echo "== bench lines"
-# 40 warm-up steps: on these boxes a power-management transient 0.6-0.7 s after the first step (steps 33-35 of a run) costs 3-12 ms on
-# 3-8 consecutive steps (per-step times in the .err files, TODA_BENCH_STEP_MS); the *_driver_shape line is the driver's K / W
-export TODA_BENCH_STEP_MS=1
-timeout -k 10 400 python bench.py --steps 50 --warmup 40 --layers --layers-out $O/r02_layers_c3.json > $O/r02_bench_c3.json 2> $O/r02_bench_c3.err
-timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r02_bench_c3_driver_shape.json 2> $O/r02_bench_c3_driver_shape.err
-for w in c2 c5 c5mix c5cl; do
-  timeout -k 10 400 python bench.py --workload $w --steps 50 --warmup 40 > $O/r02_bench_$w.json 2> $O/r02_bench_$w.err
-  echo "  $w done"
-done
-timeout -k 10 400 python bench.py --workload c5 --steps 20 --warmup 8 --no-cpu-baseline --layers --layers-out $O/r02_layers_c5.json > /dev/null 2> $O/r02_layers_c5.err
-timeout -k 10 400 python bench.py --steps 300 --warmup 40 --no-cpu-baseline > $O/r02_soak_c3.json 2> $O/r02_soak_c3.err
-unset TODA_BENCH_STEP_MS
 echo "== dense convolutions per layer"
 PYTHONPATH=$R timeout -k 10 300 python -m toda_amd.tools.bench_conv2d --config c3 > $O/r02_conv2d_c3.jsonl
 PYTHONPATH=$R timeout -k 10 300 python -m toda_amd.tools.bench_conv2d --config c5 > $O/r02_conv2d_c5.jsonl
@@ -68,5 +68,8 @@ F5=$(find /tmp/r02_kt_c5 -name "*kernel_trace.csv" | head -1)
 python3 $R/toda_amd/tools/trace_summary.py $F5 5 $O/r02_bench_c5_timed_steps.csv > $O/r02_bench_c5_groups.txt
 python3 $R/toda_amd/tools/trace_gaps.py $F5 5 > $O/r02_gaps_c5.txt
 cd $R
+# the same C3 line once more behind the nine profiler passes (on two boxes the first runs after rocprofv3 threw a 22-28 ms step
+# every fourth or fifth step; both lines are kept)
+TODA_BENCH_STEP_MS=1 timeout -k 10 400 python bench.py --steps 50 --warmup 40 --no-cpu-baseline > $O/r02_bench_c3_after_profiler.json 2> $O/r02_bench_c3_after_profiler.err
 cut -c1-300 $O/r02_bench_c3.json
 echo "== done"

@@ -226,13 +226,17 @@ __device__ __forceinline__ void bn2_plane_of_block(int C, int P, int* c, int* b)
 __device__ __forceinline__ void bn2_exchange(Bn2Sync* sy, int c, int b, int P, unsigned epoch, double v0, double v1, double* sh) {
     if (threadIdx.x == 0) {
         const int me = c * P + b;
+        // relaxed agent-scope atomics only (they go through to memory past the XCD-private caches): a release / acquire pair
+        // here means writing back and invalidating the whole L2 around the exchange - measured 8-10 us per kernel
         __hip_atomic_store(&sy->val[me][0], (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&sy->val[me][1], (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&sy->flag[me], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the two values have left before the flag goes up
+        __hip_atomic_store(&sy->flag[me], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int p = 0; p < P; ++p) {
             const int o = c * P + p;
             if (p != b)
-                while (__hip_atomic_load(&sy->flag[o], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(4);
+                while (__hip_atomic_load(&sy->flag[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
             sh[2 * p] = __longlong_as_double((long long)__hip_atomic_load(&sy->val[o][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             sh[2 * p + 1] = __longlong_as_double((long long)__hip_atomic_load(&sy->val[o][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
@@ -474,7 +478,9 @@ extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const flo
                              void* stream) {
     TODA_CHECK_ARG(x && gamma && beta && y && save, "bn2d_fwd: null argument");
     TODA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn2d_fwd: running_mean and running_var go together");
-    const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw);
+    // forward: the exchange costs 2-3 us, the single workgroup per channel only half-fills the GPU on <= 128 channels - measured
+    // 19.1 vs 21.3 us at 2 x 128 x 188 x 188, 9.9 vs 12.6 at 2 x 256 x 94 x 94: one workgroup per channel wherever it fits
+    const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw) && bn2_floats_per_thread(batch, hw) == 0;
     TODA_CHECK_ARG(split || bn2_floats_per_thread(batch, hw) > 0, "bn2d_fwd: unsupported shape (batch %d, channels %d, hw %d)%s", batch, c, hw,
                    sync ? "" : " without a sync workspace");
     const int v = (hw & 3) ? 1 : 4, hwv = hw / v;
@@ -489,8 +495,11 @@ extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const flo
 extern "C" int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, int hw, const float* gamma, const float* beta,
                              const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* sync, unsigned epoch, void* stream) {
     TODA_CHECK_ARG(x && dy && gamma && beta && save && dx && dgamma && dbeta, "bn2d_bwd: null argument");
-    const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw);
-    TODA_CHECK_ARG(split || bn2_floats_per_thread(batch, hw) > 0, "bn2d_bwd: unsupported shape (batch %d, channels %d, hw %d)%s", batch, c, hw,
+    // backward: per plane when a channel's dy no longer leaves room for anything else in the registers (the channel kernel then
+    // spills and reads x twice: 51.6 vs 28.5 us at 2 x 128 x 188 x 188; at 2 x 256 x 94 x 94 it is 12.8 vs 17.7 the other way)
+    const int per_channel = bn2_floats_per_thread(batch, hw);
+    const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw) && (per_channel == 0 || per_channel > 36);
+    TODA_CHECK_ARG(split || per_channel > 0, "bn2d_bwd: unsupported shape (batch %d, channels %d, hw %d)%s", batch, c, hw,
                    sync ? "" : " without a sync workspace");
     const int v = (hw & 3) ? 1 : 4, hwv = hw / v;
     const int k = bn2_pick_k(hwv, v);

@@ -221,9 +221,10 @@ int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual 
 /* Single-pass training-mode nn.BatchNorm2d (+ nn.ReLU) of the BEV neck and heads (base_bev_backbone.py:37-58,
  * center_head.py:20-28, 73-80; replaces torch's batch_norm + relu_ pair and their backward): the values of a channel sit in
  * registers between the statistics and the normalisation, so forward reads x once and writes y once and backward reads x
- * and dy once and writes dx once.  batch 2 / 4 with a `sync` workspace: one workgroup per (channel, sample) plane, the
- * workgroups of a channel exchange two fp64 partial results through `sync` (hw <= 36864); otherwise one workgroup per
- * channel (batch 1 / 2: hw <= 36864, batch 4: hw <= 16384; backward then reads x a second time).  hw % 4 == 0 uses 16-byte
+ * and dy once and writes dx once.  Two forms: one workgroup per channel (batch 1 / 2: hw <= 36864, batch 4: hw <= 16384;
+ * backward then reads x a second time), or - batch 2 / 4 with a `sync` workspace, hw <= 36864 - one workgroup per (channel,
+ * sample) plane, the workgroups of a channel exchanging two fp64 partial results through `sync`; the library takes the
+ * per-plane form where the per-channel one does not fit or measured slower (large backward planes).  hw % 4 == 0 uses 16-byte
  * accesses, any other hw dword accesses.
  * sync: toda_bn2d_sync_bytes() bytes, zeroed ONCE by the caller, used by one stream at a time, channels <= 4096; epoch:
  * a non-zero number the caller does not repeat on that workspace (increment per call) - nothing is reset between launches.

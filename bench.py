@@ -368,7 +368,10 @@ def run_gpu(args, rank, world, device):
             "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows, "issue_s": t_issued, "cpu_s": cpu_busy}
 
 
-PMC_FILE = "r02_pmc_gather_gemm_64x64.json"
+# (gathered channels, produced channels, K) of a dominant launch shape -> (PMC summary under profiles/, kernel instantiation,
+# threads per output row of that instantiation, slack of the grid in threads)
+PMC_FILES = {(64, 64, 27): ("r02_pmc_gather_gemm_64x64.json", "<4, 4, 2", 2, 1024),        # C3: 64 lanes per 32-row tile
+             (128, 128, 27): ("r02_pmc_gather_gemm_128x128.json", "<8, 8, 1", 4, 2048)}   # C5: 512 threads per 128 rows
 
 
 def _sha256(path):
@@ -381,20 +384,22 @@ def pmc_traffic(d):
     passes of this same command; PMC counters cannot be read from inside bench.py).  The summary records the SHA-256 of the
     kernel source it was collected on: when toda_amd/csrc/spconv.hip has changed since, or no profiled launch shape matches,
     the traffic is reported as null instead of a stale number.  Returns (bytes or None, where it came from)."""
-    path = os.path.join(ROOT, "profiles", PMC_FILE)
+    ent = PMC_FILES.get((d["c_gather"], d["c_produce"], d["K"]))
+    if ent is None:
+        return None, "dominant launch shape is not one of the profiled kernels (64->64, 128->128 at K=27)"
+    name, inst, per_row, slack = ent
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return None, "no PMC summary committed"
-    if (d["c_gather"], d["c_produce"], d["K"]) != (64, 64, 27):
-        return None, "dominant launch shape is not the profiled 64->64 K=27 kernel"
+        return None, f"no PMC summary profiles/{name} committed"
     pmc = json.load(open(path))
     src = os.path.join(ROOT, "toda_amd", "csrc", "spconv.hip")
     if pmc.get("source_sha256", {}).get("toda_amd/csrc/spconv.hip") != _sha256(src):
-        return None, f"profiles/{PMC_FILE} was collected on another version of spconv.hip (stale)"
+        return None, f"profiles/{name} was collected on another version of spconv.hip (stale)"
     for shape in pmc["launch_shapes"]:
-        if "<4, 4, 2" not in shape.get("kernel", ""):                # the 64 -> 64 instantiation only
+        if inst not in shape.get("kernel", "") or "hbm_bytes" not in shape:
             continue
-        if 0 <= shape["grid_threads"] // 2 - d["n_out"] < 1024:      # 64 lanes per 32-row tile -> 2 threads per row
-            return shape["hbm_bytes"], (f"profiles/{PMC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2*FETCH + WRITE), "
+        if 0 <= shape["grid_threads"] // per_row - d["n_out"] < slack // per_row:
+            return shape["hbm_bytes"], (f"profiles/{name}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (2*FETCH + WRITE), "
                                         f"{shape['kernel']}, grid {shape['grid_threads']}, {shape['dispatches']} dispatches")
     return None, "no profiled launch shape matches"
 

@@ -34,6 +34,13 @@ python3 $R/toda_amd/tools/pmc_summary.py wino_fwd_ws_kernel $O/r02_pmc_wino_fwd.
 python3 $R/toda_amd/tools/pmc_summary.py wino_wgrad_kernel $O/r02_pmc_wino_wgrad.json $CSVS > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py wgrad_kernel $O/r02_pmc_sparse_wgrad.json $CSVS > /dev/null
 cp $O/r02_pmc_gather_gemm_64x64.json $R/profiles/r02_pmc_gather_gemm_64x64.json
+# the C5 workload's dominant kernel (128 -> 128) for that line's roofline.traffic
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/r02_pmc5_$c
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r02_pmc5_$c -- python3 $R/bench.py --workload c5 --steps 2 --warmup 2 --no-cpu-baseline > $O/r02_pmc5_$c.log 2>&1
+done
+python3 $R/toda_amd/tools/pmc_summary.py "gather_gemm_lds_kernel<8, 8, 1" $O/r02_pmc_gather_gemm_128x128.json $(find /tmp/r02_pmc5_FETCH_SIZE /tmp/r02_pmc5_WRITE_SIZE -name "*counter_collection.csv") > /dev/null
+cp $O/r02_pmc_gather_gemm_128x128.json $R/profiles/r02_pmc_gather_gemm_128x128.json
 echo "== where the waves wait (SQ / TA / TCP / TCC counters, one pass per set) and the shader clock (GRBM_GUI_ACTIVE over the dispatch's duration, 8 XCDs)"
 i=0
 for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \

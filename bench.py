@@ -204,15 +204,20 @@ def run_gpu(args, rank, world, device):
         # 23-31 MB of fp32 gradients: 8 MB buckets let the all-reduce of the dense part's gradients (ready first) run over
         # xGMI while the sparse backbone is still in backward; the default 25 MB would make it one bucket at the very end
         ddp_kw = dict(gradient_as_bucket_view=True, bucket_cap_mb=8)
-        # broadcast_buffers stays at torch's default (True) as in the reference (tools/train.py:143): rank 0's BN running
-        # statistics are broadcast at every forward, so all ranks hold the buffers that get checkpointed
-        if os.environ.get("TODA_DDP_BCAST_BUFFERS", "1") == "0":
-            ddp_kw["broadcast_buffers"] = False
+        # buffers: rank 0's BN running statistics reach every rank before each forward, as with the reference's
+        # DistributedDataParallel default (tools/train.py:143) - done by wrap_ddp as one flat broadcast per dtype (DDP's own
+        # per-tensor buffer sync costs 0.85 ms of a 19 ms step; TODA_DDP_BCAST_BUFFERS=torch selects it, =0 none at all)
+        bcast = os.environ.get("TODA_DDP_BCAST_BUFFERS", "1")
+        if bcast == "0":
+            ddp_kw.update(broadcast_buffers=False, coalesced_buffer_broadcast=False)
+        elif bcast == "torch":
+            ddp_kw.update(broadcast_buffers=True, coalesced_buffer_broadcast=False)
         if os.environ.get("TODA_DDP_STATIC", "0") == "1":
             ddp_kw["static_graph"] = True
         if os.environ.get("TODA_DDP_BUCKET_MB"):
             ddp_kw["bucket_cap_mb"] = int(os.environ["TODA_DDP_BUCKET_MB"])
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], **ddp_kw)
+        from toda_amd.pcdet.utils.common_utils import wrap_ddp
+        model = wrap_ddp(model, device_ids=[device.index], **ddp_kw)
     if pair:
         batches = make_device_pair_batches(dataset, per_gpu, args.batches, rank, device)
         cl_fn = model_fn_decorator_cl()

@@ -63,8 +63,7 @@ def main(argv=None):
     optimizer = build_optimizer(model, cfg.OPTIMIZATION)
     wrapped = DistModel(model)
     if dist_train:
-        wrapped = nn.parallel.DistributedDataParallel(wrapped, device_ids=[cfg.LOCAL_RANK % torch.cuda.device_count()],
-                                                    gradient_as_bucket_view=True, bucket_cap_mb=8)  # broadcast_buffers = torch default (True), as the reference
+        wrapped = common_utils.wrap_ddp(wrapped, device_ids=[cfg.LOCAL_RANK % torch.cuda.device_count()])   # buffers broadcast from rank 0 each forward, as the reference's default
     scheduler, _ = build_scheduler(optimizer, len(loader), epochs, -1, cfg.OPTIMIZATION)
     fn = model_fn_decorator_cl()
     it = 0

@@ -104,8 +104,9 @@ def main(argv=None):
             last_epoch = start_epoch + 1
     model.train()
     if dist_train:
-        model = nn.parallel.DistributedDataParallel(model, device_ids=[cfg.LOCAL_RANK % torch.cuda.device_count()],
-                                                    gradient_as_bucket_view=True, bucket_cap_mb=8)  # broadcast_buffers = default True as the reference (tools/train.py:143): rank 0's BN running stats reach every rank each forward
+        # reference tools/train.py:143: DistributedDataParallel with broadcast_buffers at its default (True) - rank 0's BN running
+        # statistics reach every rank before each forward; wrap_ddp does that broadcast as one flat tensor per dtype
+        model = common_utils.wrap_ddp(model, device_ids=[cfg.LOCAL_RANK % torch.cuda.device_count()])
     logger.info(model)
     lr_scheduler, lr_warmup_scheduler = build_scheduler(optimizer, total_iters_each_epoch=len(train_loader),
                                                         total_epochs=args.epochs, last_epoch=last_epoch,

@@ -81,8 +81,10 @@ def _worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_gloo_ddp_equals_single_process(tmp_path):
+@pytest.mark.parametrize("reducer", ["own", "torch"])      # common_utils.DataParallel (flat-bucket reducer) / torch's DistributedDataParallel
+def test_two_rank_gloo_ddp_equals_single_process(tmp_path, reducer, monkeypatch):
     out = str(tmp_path / "rank0.pt")
+    monkeypatch.setenv("TODA_DDP", reducer)                 # inherited by the spawned ranks (wrap_ddp reads it)
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     got = torch.load(out)
     assert got["buffer_digests"][0] == got["buffer_digests"][1]        # rank 1 holds rank 0's BatchNorm buffers (it started 3 off)

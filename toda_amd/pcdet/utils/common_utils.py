@@ -185,16 +185,146 @@ class BufferBroadcaster:
                         torch._foreach_copy_(dst, src)
 
 
+class GradBucketReducer:
+    """The gradient all-reduce of data-parallel training (reference tools/train.py:143: DistributedDataParallel) over a few
+    flat buckets, without a kernel per parameter.  Why: optimizer.zero_grad() drops the gradients every step, so DDP's reducer
+    finds fresh gradient tensors in every backward and copies each of them into its bucket with its own scaled-copy kernel -
+    109 launches and 0.5 ms of a 19 ms CenterPoint step on one MI355X even at world size 1.  Here the parameters are bucketed
+    in reverse registration order (the order backward produces them); when the last gradient of a bucket has been accumulated
+    (post-accumulate hook) ONE torch.cat gathers the bucket's gradients into its flat buffer and one asynchronous all-reduce
+    starts, overlapping the rest of backward; a callback at the end of the backward pass waits for the buckets, scales them by
+    1 / world and re-points every .grad at its slice of the flat buffer (no copy back).  Same averaged gradients as DDP
+    (tests/test_ddp_gloo.py).  no_sync(): gradients stay local, as DDP.no_sync()."""
+
+    def __init__(self, params, bucket_bytes=8 << 20, process_group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.enabled = True
+        params = [p for p in params if p.requires_grad]
+        self.buckets = []
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            key = (p.dtype, p.device)
+            if cur and (cur_bytes >= bucket_bytes or key != (cur[0].dtype, cur[0].device)):
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [torch.empty((sum(p.numel() for p in b),), dtype=b[0].dtype, device=b[0].device) for b in self.buckets]
+        self.where = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self.where[p] = bi
+                p.register_post_accumulate_grad_hook(self._ready)
+        self._reset()
+
+    def _reset(self):
+        self.pending = [len(b) for b in self.buckets]
+        self.seen = [set() for _ in self.buckets]
+        self.work = [None] * len(self.buckets)
+        self.armed = False
+
+    def _launch(self, bi):
+        b, flat = self.buckets[bi], self.flat[bi]
+        grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros((p.numel(),), dtype=p.dtype, device=p.device) for p in b]
+        torch.cat(grads, out=flat)
+        self.work[bi] = self.dist.all_reduce(flat, group=self.group, async_op=True)
+
+    def _ready(self, p):
+        if not self.enabled:
+            return
+        if not self.armed:          # first gradient of this backward pass: finish() runs when the pass ends
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+        bi = self.where[p]
+        if id(p) in self.seen[bi]:
+            return
+        self.seen[bi].add(id(p))
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0:
+            self._launch(bi)
+
+    def finish(self):
+        if not self.enabled:
+            self._reset()
+            return
+        for bi, b in enumerate(self.buckets):
+            if self.work[bi] is None:          # a parameter without a gradient in this pass: reduce what there is (zeros for it)
+                self._launch(bi)
+        scale = 1.0 / self.world
+        for bi, b in enumerate(self.buckets):
+            self.work[bi].wait()
+            flat = self.flat[bi]
+            if self.world > 1:
+                flat.mul_(scale)
+            off = 0
+            for p in b:
+                n = p.numel()
+                p.grad = flat[off:off + n].view(p.shape)
+                off += n
+        self._reset()
+
+
+class DataParallel(torch.nn.Module):
+    """One replica per process: forward = the wrapped module's (after the buffer broadcast), gradients averaged over the ranks by
+    GradBucketReducer during backward, parameters of all ranks set to rank 0's at construction - the surface of
+    torch.nn.parallel.DistributedDataParallel that the trainers use (.module, no_sync(), state_dict of the wrapped module under
+    the same `module.` prefix)."""
+
+    def __init__(self, module, bucket_cap_mb=8, process_group=None):
+        super().__init__()
+        import torch.distributed as dist
+        self.module = module
+        self.broadcaster = BufferBroadcaster(module, process_group)
+        self.toda_buffer_broadcaster = self.broadcaster
+        with torch.no_grad():        # every rank starts from rank 0's parameters (DDP does this in its constructor)
+            groups = {}
+            for p in module.parameters():
+                groups.setdefault((p.dtype, p.device), []).append(p)
+            for ps in groups.values():
+                flat = torch.cat([p.detach().reshape(-1) for p in ps])
+                dist.broadcast(flat, 0, group=process_group)
+                if dist.get_rank(process_group) != 0:
+                    torch._foreach_copy_([p.detach().view(-1) if p.is_contiguous() else p.detach() for p in ps],
+                                         [piece if p.is_contiguous() else piece.view(p.shape) for p, piece in zip(ps, flat.split([p.numel() for p in ps]))])
+        self.reducer = GradBucketReducer(list(module.parameters()), int(bucket_cap_mb) << 20, process_group)
+
+    def forward(self, *args, **kwargs):
+        self.broadcaster.sync()
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            old = self.reducer.enabled
+            self.reducer.enabled = False
+            try:
+                yield
+            finally:
+                self.reducer.enabled = old
+        return ctx()
+
+
 def wrap_ddp(model, device_ids=None, **kw):
-    """DistributedDataParallel as the trainers use it (8 MB gradient buckets as bucket views) with the buffer broadcast of
-    torch's default broadcast_buffers=True done by BufferBroadcaster before each forward."""
+    """Data-parallel wrapper of the trainers and bench.py.  Default: DataParallel above (flat-bucket gradient reducer + coalesced
+    buffer broadcast).  TODA_DDP=torch (or reducer="torch"): torch's DistributedDataParallel with 8 MB bucket views, its buffer
+    sync replaced by BufferBroadcaster unless coalesced_buffer_broadcast=False."""
+    reducer = kw.pop("reducer", os.environ.get("TODA_DDP", "own"))
+    own_bcast = kw.pop("coalesced_buffer_broadcast", True)
+    if reducer != "torch" and not kw.get("static_graph") and own_bcast:
+        return DataParallel(model, bucket_cap_mb=kw.get("bucket_cap_mb", 8))
     kw.setdefault("gradient_as_bucket_view", True)
     kw.setdefault("bucket_cap_mb", 8)
-    own = kw.pop("coalesced_buffer_broadcast", True)
-    if own:
+    if own_bcast:
         kw["broadcast_buffers"] = False
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=device_ids, **kw)
-    if own:
+    if own_bcast:
         bb = BufferBroadcaster(model)
         ddp.register_forward_pre_hook(lambda m, args: bb.sync())
         ddp.toda_buffer_broadcaster = bb

@@ -113,7 +113,7 @@ def checkpoint_state(model=None, optimizer=None, epoch=None, it=None):
     optim_state = optimizer.state_dict() if optimizer is not None else None
     model_state = None
     if model is not None:
-        net = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+        net = model.module if hasattr(model, "module") and hasattr(model, "no_sync") else model
         model_state = model_state_to_cpu(net.state_dict())
     from ... import pcdet
 

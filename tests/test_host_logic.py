@@ -265,3 +265,40 @@ def test_clip_grad_norm_matches_torch():
             assert (q.grad is None) == (r.grad is None)
             if q.grad is not None:
                 assert torch.equal(q.grad, r.grad)
+
+
+def test_grad_bucket_reducer_single_rank_keeps_gradients_and_views(tmp_path):
+    """GradBucketReducer at world size 1 (gloo): after backward every .grad is a slice of its bucket's flat buffer holding the
+    plain gradient; a second backward without dropping the gradients accumulates in place and is reduced without a gather."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from toda_amd.pcdet.utils.common_utils import GradBucketReducer
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29641"
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        red = GradBucketReducer(list(net.parameters()), bucket_bytes=64)       # several tiny buckets
+        x = torch.randn(4, 7)
+        net(x).sum().backward()
+        g1 = [p.grad.clone() for p in net.parameters()]
+        spans = [(f.data_ptr(), f.data_ptr() + f.numel() * 4) for f in red.flat]
+        assert all(any(lo <= p.grad.data_ptr() < hi for lo, hi in spans) for p in net.parameters())
+        plain = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+        plain.load_state_dict(net.state_dict())
+        plain(x).sum().backward()
+        for a, b in zip(g1, [p.grad for p in plain.parameters()]):
+            assert torch.equal(a, b)
+        net(x).sum().backward()                  # gradients kept: accumulated in place, reduced in place
+        for p, a in zip(net.parameters(), g1):
+            assert torch.allclose(p.grad, 2 * a)
+        with_off = [p.grad.clone() for p in net.parameters()]
+        red.enabled = False                      # no_sync: hooks stand aside
+        net(x).sum().backward()
+        for p, a, b in zip(net.parameters(), with_off, g1):
+            assert torch.allclose(p.grad, a + b)
+    finally:
+        dist.destroy_process_group()

@@ -230,8 +230,19 @@ class GradBucketReducer:
 
     def _launch(self, bi):
         b, flat = self.buckets[bi], self.flat[bi]
-        grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros((p.numel(),), dtype=p.dtype, device=p.device) for p in b]
-        torch.cat(grads, out=flat)
+        # a trainer that keeps its gradients (zero_grad(set_to_none=False)) accumulates straight into the slices handed out by
+        # finish(): nothing to gather then (and cat must not read what it writes)
+        base, size, off, in_place = flat.data_ptr(), flat.element_size(), 0, True
+        for p in b:
+            if p.grad is None or p.grad.data_ptr() != base + off * size or not p.grad.is_contiguous():
+                in_place = False
+                break
+            off += p.numel()
+        if not in_place:
+            grads = [p.grad.reshape(-1) if p.grad is not None else torch.zeros((p.numel(),), dtype=p.dtype, device=p.device) for p in b]
+            if any(g.data_ptr() >= base and g.data_ptr() < base + flat.numel() * size for g in grads):
+                grads = [g.clone() for g in grads]          # some still alias the buffer, some do not: gather from copies
+            torch.cat(grads, out=flat)
         self.work[bi] = self.dist.all_reduce(flat, group=self.group, async_op=True)
 
     def _ready(self, p):

@@ -14,9 +14,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     out = sys.argv[1]
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    backend = os.environ.get("TODA_TEST_DDP_BACKEND", "nccl")
+    if backend == "gloo":          # one-GPU rehearsal: both ranks on cuda:0, collectives over gloo (staged through the host)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if backend == "gloo":
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from test_ddp_gloo import _freeze_bn, _tiny_cfg
     from toda_amd.pcdet.datasets import SyntheticLidarDataset
     from toda_amd.pcdet.models import build_network, model_fn_decorator

@@ -233,10 +233,10 @@ def run_gpu(args, rank, world, device):
     timer = KernelTimer()
 
     fwd_only = args.workload == "c2"
-    # device-side input pipeline (the reference voxelises in DataLoader workers, concurrently with training): step t + 1's
-    # voxelisation and rulebooks run on a side stream while step t's backward runs.  Every timed step still contains one
-    # voxelisation + index build (the one for the next step).  Opt-in (TODA_PREFETCH=1): measured 22.5-23.0 ms/step with it
-    # against 22.3-22.5 without - the step is GPU-bound, the two host syncs of the index build cost nothing to hide.
+    # device-side input pipeline as in tools/train_utils/train_utils.py (the reference voxelises in DataLoader workers, concurrently
+    # with training): step t + 1's voxelisation and rulebooks run on a side stream while step t's backward runs.  Every timed step
+    # still contains one voxelisation + index build (the one for the next step).  C3 18.1-18.2 ms/step with it, 18.8-19.0 without
+    # (TODA_PREFETCH=0); C5 25.7-26.0 against 26.4-26.7.
     prefetch = None
 
     def mixed_batch(it):
@@ -246,9 +246,9 @@ def run_gpu(args, rank, world, device):
         batch["gt_boxes"] = torch.from_numpy(batch["gt_boxes"]).float().to(device)
         return {k: batch[k] for k in ("points", "points_per_sample", "gt_boxes", "batch_size")}
 
-    # c5mix with the mix -> mask -> shuffle -> collate chain on the side stream as well: 67.5 / 67.1 samples/s against 69.1 / 66.9
-    # without (the spread of its step times, p10 / p90 26-33 ms, is the size of the mixed clouds, not host stalls).
-    if os.environ.get("TODA_PREFETCH", "0") == "1" and not (fwd_only or pair):
+    # c5mix: the mix -> mask -> shuffle -> collate chain (small kernels with host decisions and syncs between them) rides on the side
+    # stream as well: 75.5-75.9 samples/s against 69.9-70.2 on the training stream.
+    if os.environ.get("TODA_PREFETCH", "1") == "1" and not (fwd_only or pair):
         from toda_amd.pcdet.models import InputPrefetcher
 
         def batch_stream():
@@ -286,11 +286,14 @@ def run_gpu(args, rank, world, device):
                 voxelize_on_gpu(batch, dataset.voxel_cfg)
             ret, tb, _ = model(batch)
             loss = ret["loss"].mean()
-            if prefetch is not None:
-                prefetch.kick()          # next batch's index work goes to the side stream now, under this step's backward
         loss.backward()
         clip_grad_norm_(params, clip)
         optimizer.step()
+        if prefetch is not None and not pair:
+            # next batch's index work goes to the side stream once this step's backward + optimizer are ENQUEUED: the host then
+            # sits in the side stream's two syncs while the GPU still has the whole backward to run (kicking before backward() -
+            # the first version - parked the host there with nothing queued behind the forward)
+            prefetch.kick()
         if not pair:
             net.update_global_step()
         return loss

@@ -83,14 +83,17 @@ class InputPrefetcher:
     """Device-side input pipeline: batch t + 1 is voxelised and its rulebooks are built on a side HIP stream while the main
     stream still runs step t, so the two host syncs of the index building (voxel counts, output-set sizes) and the ~1 ms of
     small index kernels leave the critical path.  next() hands out a prepared batch (the main stream waits for its event);
-    kick() starts the preparation of the following one - call it once the forward pass of the current step is enqueued."""
+    kick() starts the preparation of the following one - call it once the backward pass and the optimizer step of the current
+    iteration are ENQUEUED: the host then waits in the side stream's syncs while the GPU has the whole backward to run (kicked
+    right behind the forward, the host waits with nothing queued behind it and the GPU runs dry: measured no gain)."""
 
-    def __init__(self, batches, net, device):
+    def __init__(self, batches, net, device, eager=True):
         self.it = iter(batches)
         self.net = net
         self.side = torch.cuda.Stream(device=device)
         self.pending = None
-        self.kick()
+        if eager:
+            self.kick()
 
     def kick(self):
         if self.pending is not None:

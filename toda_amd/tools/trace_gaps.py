@@ -4,7 +4,10 @@
 Lists, per (previous kernel -> next kernel) pair, how often and for how long the device sat idle between them."""
 import collections
 import csv
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
@@ -17,11 +20,9 @@ def main():
     min_gap = float(sys.argv[3]) if len(sys.argv) > 3 else 20.0
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [int(r["Start_Timestamp"]) for r in rows if "vox_insert" in r["Kernel_Name"]]
-    t0 = marks[-steps * 2]
-    adam = [int(r["End_Timestamp"]) for r in rows if "FusedOptimizerTensorListMetadata" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower()]
-    t_end = max(adam) if adam else int(rows[-1]["End_Timestamp"])
-    sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) <= t_end]
+    from trace_summary import timed_window
+    t0, t_end = timed_window(rows, steps)
+    sel = [r for r in rows if t0 < int(r["End_Timestamp"]) <= t_end]
     agg = collections.defaultdict(lambda: [0.0, 0])
     end = int(sel[0]["End_Timestamp"])
     total = 0.0

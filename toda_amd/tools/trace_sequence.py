@@ -5,7 +5,10 @@ One line per dispatch: start offset (us), duration (us), idle gap in front of it
 which module a run of small torch kernels belongs to (the hand-written kernels on either side name the place)."""
 import csv
 import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
@@ -18,8 +21,9 @@ def short(name):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "vox_insert" in r["Kernel_Name"]]
-    sel = rows[marks[-2]:]          # bs 2: the last step starts at its first voxelise call
+    from trace_summary import timed_window
+    lo, hi = timed_window(rows, 1)          # the last step: from the end of the optimizer step before it
+    sel = [r for r in rows if lo < int(r["End_Timestamp"]) <= hi]
     t0 = int(sel[0]["Start_Timestamp"])
     end = t0
     out = []

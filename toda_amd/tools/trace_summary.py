@@ -1,22 +1,38 @@
 #!/usr/bin/env python
-"""Summarise a rocprofv3 --kernel-trace CSV of bench.py over its TIMED steps only (the warm-up
-holds MIOpen find-mode kernels).  Usage: trace_summary.py <kernel_trace.csv> <timed_steps> [out.csv]"""
+"""Summarise a rocprofv3 --kernel-trace CSV of bench.py over its last <timed_steps> training steps only (the warm-up
+holds MIOpen find-mode kernels).  Steps are delimited by their optimizer kernels (timed_window).
+Usage: trace_summary.py <kernel_trace.csv> <timed_steps> [out.csv]"""
 import collections
 import csv
 import sys
+
+
+def timed_window(rows, steps):
+    """[t0, t_end] of the last `steps` training steps of a bench.py kernel trace (rows sorted by start time).  A step ends with
+    the last kernel of its optimizer launch cluster (FusedOptimizer multi-tensor kernels less than 1 ms apart); the window
+    runs from the end of the step before the first counted one to the end of the last - whatever the step does in between
+    (its own voxelisation, or with the input pipeline the NEXT step's on the side stream) is inside."""
+    adam = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows
+                  if "FusedOptimizerTensorListMetadata" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower())
+    if not adam:
+        raise SystemExit("no optimizer kernels in the trace: cannot find the step boundaries")
+    ends = []
+    for s, e in adam:
+        if ends and s - ends[-1] < 1_000_000:
+            ends[-1] = max(ends[-1], e)
+        else:
+            ends.append(e)
+    if len(ends) <= steps:
+        raise SystemExit(f"only {len(ends)} optimizer steps in the trace, need more than {steps}")
+    return ends[-steps - 1], ends[-1]
 
 
 def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [int(r["Start_Timestamp"]) for r in rows if "vox_insert" in r["Kernel_Name"]]
-    per_step = 2  # bs 2 -> two voxelise calls per step
-    t0 = marks[-steps * per_step]
-    # the timed region ends with the last optimizer kernel: what follows (pair counting for the roofline, --layers) is not a step
-    adam = [int(r["End_Timestamp"]) for r in rows if "FusedOptimizerTensorListMetadata" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower()]
-    t_end = max(adam) if adam else int(rows[-1]["End_Timestamp"])
-    sel = [r for r in rows if t0 <= int(r["Start_Timestamp"]) <= t_end]
+    t0, t_end = timed_window(rows, steps)
+    sel = [r for r in rows if t0 < int(r["End_Timestamp"]) <= t_end]
     agg = collections.defaultdict(lambda: [0, 0])
     for r in sel:
         agg[r["Kernel_Name"]][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])

@@ -248,13 +248,16 @@ def run_gpu(args, rank, world, device):
 
     # c5mix: the mix -> mask -> shuffle -> collate chain (small kernels with host decisions and syncs between them) rides on the side
     # stream as well: 75.5-75.9 samples/s against 69.9-70.2 on the training stream.
-    if os.environ.get("TODA_PREFETCH", "1") == "1" and not (fwd_only or pair):
+    if os.environ.get("TODA_PREFETCH", "1") == "1" and not fwd_only:
         from toda_amd.pcdet.models import InputPrefetcher
 
         def batch_stream():
             it = 0
             while True:
-                if mixed:
+                if pair:
+                    adv, org = batches[it % len(batches)]
+                    yield dict(adv), dict(org)
+                elif mixed:
                     yield mixed_batch(it)
                 else:
                     yield dict(batches[it % len(batches)])
@@ -273,7 +276,7 @@ def run_gpu(args, rank, world, device):
         scheduler.step(it)
         optimizer.zero_grad()
         if pair:
-            adv, org = batches[it % len(batches)]
+            adv, org = prefetch.next() if prefetch is not None else batches[it % len(batches)]
             loss = cl_fn(model, dict(adv), dict(org), world > 1).loss
         else:
             if prefetch is not None:
@@ -289,7 +292,7 @@ def run_gpu(args, rank, world, device):
         loss.backward()
         clip_grad_norm_(params, clip)
         optimizer.step()
-        if prefetch is not None and not pair:
+        if prefetch is not None:
             # next batch's index work goes to the side stream once this step's backward + optimizer are ENQUEUED: the host then
             # sits in the side stream's two syncs while the GPU still has the whole backward to run (kicking before backward() -
             # the first version - parked the host there with nothing queued behind the forward)

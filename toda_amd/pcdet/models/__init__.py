@@ -103,7 +103,10 @@ class InputPrefetcher:
                 batch = next(self.it)        # inside the side-stream context: a source that mixes / collates on the device runs there too
             except StopIteration:
                 return
-            batch = prepare_batch_on_gpu(batch, self.net)
+            if isinstance(batch, (tuple, list)):      # the (adversarial, original) pair of the stage-2 consistency step
+                batch = tuple(prepare_batch_on_gpu(b, self.net) for b in batch)
+            else:
+                batch = prepare_batch_on_gpu(batch, self.net)
             ev = torch.cuda.Event()
             ev.record(self.side)
         self.pending = (batch, ev)

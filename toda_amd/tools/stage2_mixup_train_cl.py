@@ -6,6 +6,7 @@ the loop below is written from model_fn_decorator_cl, pcdet/models/__init__.py:8
     python -m toda_amd.tools.stage2_mixup_train_cl --cfg_file toda_amd/tools/cfgs/models/toda_stage1_centerpoint_res.yaml
 
 Both passes run inside one DistModel.forward so DDP issues one gradient all-reduce per step."""
+import os
 import time
 
 import torch
@@ -23,9 +24,20 @@ from .train_utils.optimization import build_optimizer, build_scheduler
 
 def train_one_epoch_cl(model, optimizer, loader, model_func, lr_scheduler, accumulated_iter, optim_cfg, rank, dist_train,
                        logger=None, log_interval=10, max_iters=None):
-    for it, (adv, org) in enumerate(loader):
-        if max_iters is not None and it >= max_iters:
-            break
+    # device-side input pipeline as in tools/train_utils/train_utils.py: the next (adv, org) pair is uploaded, voxelised and
+    # indexed on a side stream while this pair's backward runs (TODA_PREFETCH=0: on the training stream)
+    n_iters = len(loader) if max_iters is None else min(len(loader), max_iters)
+    source = iter(loader)
+    prefetch = None
+    first = next(model.parameters(), None)
+    if os.environ.get("TODA_PREFETCH", "1") == "1" and first is not None and first.is_cuda:
+        from ..pcdet.models import InputPrefetcher
+        net = model.module if hasattr(model, "module") and hasattr(model, "no_sync") else model
+        net = getattr(net, "onepass", net)
+        if hasattr(net, "dataset"):
+            prefetch = InputPrefetcher(source, net, first.device, eager=False)
+    for it in range(n_iters):
+        adv, org = prefetch.next() if prefetch is not None else next(source)
         lr_scheduler.step(accumulated_iter)
         model.train()
         optimizer.zero_grad()
@@ -33,6 +45,8 @@ def train_one_epoch_cl(model, optimizer, loader, model_func, lr_scheduler, accum
         loss.backward()
         clip_grad_norm_(model.parameters(), optim_cfg.GRAD_NORM_CLIP)
         optimizer.step()
+        if prefetch is not None and it + 1 < n_iters:
+            prefetch.kick()
         accumulated_iter += 1
         if rank == 0 and logger is not None and accumulated_iter % log_interval == 0:
             logger.info(f"it {accumulated_iter}: loss={float(loss):.4f} " +

@@ -248,7 +248,7 @@ def run_gpu(args, rank, world, device):
 
     # c5mix: the mix -> mask -> shuffle -> collate chain (small kernels with host decisions and syncs between them) rides on the side
     # stream as well: 75.5-75.9 samples/s against 69.9-70.2 on the training stream.
-    if os.environ.get("TODA_PREFETCH", "1") == "1" and not fwd_only:
+    if os.environ.get("TODA_PREFETCH", "1") == "1":
         from toda_amd.pcdet.models import InputPrefetcher
 
         def batch_stream():
@@ -268,11 +268,17 @@ def run_gpu(args, rank, world, device):
     def step(it):
         if fwd_only:  # BASELINE config 2: inference through the sparse backbone only
             with torch.no_grad():
-                batch = dict(batches[it % len(batches)])
-                voxelize_on_gpu(batch, dataset.voxel_cfg)
+                if prefetch is not None:
+                    batch = prefetch.next()
+                else:
+                    batch = dict(batches[it % len(batches)])
+                    voxelize_on_gpu(batch, dataset.voxel_cfg)
                 for m in (net.vfe, net.backbone_3d, net.map_to_bev_module):
                     batch = m(batch)
-            return batch["spatial_features"].sum()
+                out = batch["spatial_features"].sum()
+                if prefetch is not None:
+                    prefetch.kick()          # the next batch's voxelisation + rulebooks on the side stream, under this forward
+            return out
         scheduler.step(it)
         optimizer.zero_grad()
         if pair:

@@ -1,6 +1,7 @@
 """Evaluation loop (reference tools/eval_utils/eval_utils.py:22-121): eval-mode forward over a dataloader, recall
 statistics from the detectors' recall record, per-frame annotation dicts, result.pkl, dataset.evaluation()."""
 import pickle
+import os
 import time
 
 import torch
@@ -23,6 +24,24 @@ def run_inference(model, dataloader, on_batch=None):
     on the device exactly as in training."""
     dataset = dataloader.dataset
     model.eval()
+    first = next(model.parameters(), None)
+    net = model.module if hasattr(model, "module") and hasattr(model, "no_sync") else model
+    if os.environ.get("TODA_PREFETCH", "1") == "1" and first is not None and first.is_cuda and hasattr(net, "dataset"):
+        # device-side input pipeline (pcdet.models.InputPrefetcher): the next batch is uploaded, voxelised and indexed on a side
+        # stream while this batch's forward and its host-side decoding run
+        from toda_amd.pcdet.models import InputPrefetcher
+        with torch.no_grad():
+            pre = InputPrefetcher(iter(dataloader), net, first.device, eager=False)
+        while True:
+            try:
+                with torch.no_grad():
+                    batch_dict = pre.next()
+            except StopIteration:
+                return
+            with torch.no_grad():
+                pred_dicts, ret_dict = model(batch_dict)
+                pre.kick()
+            yield batch_dict, pred_dicts, ret_dict
     for batch_dict in dataloader:
         load_data_to_gpu(batch_dict)
         if "voxels" not in batch_dict and "points" in batch_dict:

@@ -22,6 +22,29 @@ def grid_size_xyz(pc_range, voxel_size):
 
 
 # ----------------------------------------------------------------------------- voxelisation
+_COUNT_PINNED = {}
+
+
+def read_counts(counts_dev, while_waiting=None):
+    """A small int32 device tensor -> python list: the host sync of the index building.  The copy goes to pinned memory and the
+    host waits for the COPY's event, not for the stream (work queued by `while_waiting` in between keeps the GPU busy meanwhile).
+    On a side stream (the input pipeline) the host sleeps on the event instead of spinning: the wait is off the training stream
+    there, and a thread that spins for milliseconds every step eats into the process's CPU quota."""
+    dev = counts_dev.device
+    side = torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev)
+    key = (dev.index, counts_dev.numel(), side)
+    ent = _COUNT_PINNED.get(key)
+    if ent is None:
+        ent = _COUNT_PINNED[key] = (torch.empty((counts_dev.numel(),), dtype=torch.int32).pin_memory(), torch.cuda.Event(blocking=side))
+    host, ev = ent
+    host.copy_(counts_dev, non_blocking=True)
+    ev.record()
+    if while_waiting is not None:
+        while_waiting()
+    ev.synchronize()
+    return host.tolist()
+
+
 def voxelize_raw(points, pc_range, voxel_size, max_pts, max_voxels):
     """One sample, no host sync.  Returns buffers sized for the cap and the device-side count."""
     lib = L.load()
@@ -55,7 +78,7 @@ def voxelize_batch(points_list, pc_range, voxel_size, max_pts, max_voxels):
     """All samples of a batch with ONE host sync.  Mirrors voxelise + collate_batch
     (reference dataset.py:161-178): coords gain the batch column -> (b, z, y, x)."""
     raws = [voxelize_raw(p, pc_range, voxel_size, max_pts, max_voxels) for p in points_list]
-    counts = torch.cat([r[3] for r in raws]).tolist()  # the one sync
+    counts = read_counts(torch.cat([r[3] for r in raws]))  # the one sync
     vox, coords, nums = [], [], []
     for b, ((v, c, n, _), m) in enumerate(zip(raws, counts)):
         vox.append(v[:m])
@@ -227,9 +250,6 @@ def build_conv_rulebook(indices, batch, shape, ksize, stride, padding):
     return idx_out, out_shape, rb, gi_out
 
 
-_PLAN_PINNED = {}
-
-
 def build_index_plan(indices, batch, shape, steps, while_waiting=None):
     """All rulebooks of a sequential sparse backbone with ONE host sync.
 
@@ -271,18 +291,7 @@ def build_index_plan(indices, batch, shape, steps, while_waiting=None):
         conv_steps.append((st, cur, nxt, hs))
         levels.append(nxt)
     if conv_steps:
-        counts_dev = torch.cat([c[2]["n_dev"] for c in conv_steps])
-        key = (dev.index, counts_dev.numel())
-        ent = _PLAN_PINNED.get(key)
-        if ent is None:
-            ent = _PLAN_PINNED[key] = (torch.empty((counts_dev.numel(),), dtype=torch.int32).pin_memory(), torch.cuda.Event())
-        host, ev = ent
-        host.copy_(counts_dev, non_blocking=True)
-        ev.record()
-        if while_waiting is not None:
-            while_waiting()
-        ev.synchronize()  # the one sync
-        counts = host.tolist()
+        counts = read_counts(torch.cat([c[2]["n_dev"] for c in conv_steps]), while_waiting)  # the one sync
         for (st, cur, nxt, hs), n_out in zip(conv_steps, counts):
             if n_out > nxt["cap"]:
                 raise RuntimeError(f"strided rulebook {st['key']}: {n_out} outputs exceed the bound {nxt['cap']}")

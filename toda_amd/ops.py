@@ -22,6 +22,8 @@ def grid_size_xyz(pc_range, voxel_size):
 
 
 # ----------------------------------------------------------------------------- voxelisation
+import time as _time
+
 _COUNT_PINNED = {}
 
 
@@ -41,7 +43,13 @@ def read_counts(counts_dev, while_waiting=None):
     ev.record()
     if while_waiting is not None:
         while_waiting()
-    ev.synchronize()
+    if side:
+        # hipEventSynchronize spins even on a "blocking" event here (the thread's CPU time did not move): poll and sleep instead.
+        # The wait sits under a whole backward pass, 50 us of granularity cost nothing.
+        while not ev.query():
+            _time.sleep(5e-5)
+    else:
+        ev.synchronize()
     return host.tolist()
 
 

@@ -568,53 +568,81 @@ def launch_ranks(args, argv):
 
 
 def dry_run(args, rank, world):
-    """TODA_BENCH_DRYRUN=1: rendezvous + one all-reduce over gloo, no GPU work - exercises the launcher on a CPU-only box."""
+    """TODA_BENCH_DRYRUN=1: the N > 1 path of this file without a GPU, over gloo.  Plain: rendezvous + one all-reduce (exercises
+    the launcher).  With TODA_BENCH_DRYRUN_REHEARSAL=module:function the ranks also run what the driver's N = 8 run executes
+    around the kernels: the factory (test infrastructure, tests/bench_rehearsal.py - a tiny CenterPoint on the CPU) returns a
+    model wrapped by common_utils.wrap_ddp and its train step; warm-up, barrier, timed steps, barrier, max over ranks and
+    comm_report (no_sync steps, stand-alone all-reduce, exposed / hidden split) then run exactly as in run_gpu / main."""
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ones = torch.ones(1)
     dist.all_reduce(ones)
     dist.barrier()
+    line = {"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "comm": {"ranks": int(ones.item()), "backend": "gloo"}}
+    spec = os.environ.get("TODA_BENCH_DRYRUN_REHEARSAL")
+    if spec:
+        import importlib
+        mod, fn = spec.split(":")
+        made = getattr(importlib.import_module(mod), fn)(rank, world)
+        model, net, step = made["model"], made["net"], made["step"]
+        for it in range(args.warmup):
+            loss = step(it)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for it in range(args.warmup, args.warmup + args.steps):
+            loss = step(it)
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        assert np.isfinite(float(loss)), "rehearsal diverged"
+        line.update(ms_per_step=round(elapsed / args.steps * 1e3, 3), value=round(args.steps * made["per_gpu"] * world / elapsed, 3),
+                    reducer=type(model).__name__,
+                    comm=comm_report(model, net, step, args, world, torch.device("cpu"), elapsed / args.steps * 1e3,
+                                     sync=lambda: None, backend="gloo"))
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "comm": {"ranks": int(ones.item()), "backend": "gloo"}}))
+        print(json.dumps(line))
     dist.destroy_process_group()
     if os.environ.get("TODA_BENCH_DRYRUN_FAIL_RANK") == str(rank):
         raise SystemExit(3)
 
 
-def comm_report(model, net, step, args, world, device, ms_per_step):
+def comm_report(model, net, step, args, world, device, ms_per_step, sync=None, backend="rccl"):
     """Outside the timed region: how much of the gradient all-reduce the backward hides.  (i) the same steps with
     the all-reduce switched off (DDP.no_sync) -> ms per step without communication; (ii) one flat all-reduce of the
-    gradient payload on an otherwise idle GPU.  exposed = ms_per_step - (i); hidden = (ii) - exposed."""
+    gradient payload on an otherwise idle GPU.  exposed = ms_per_step - (i); hidden = (ii) - exposed.
+    `sync` / `backend`: the CPU rehearsal (dry_run) passes a no-op and "gloo"."""
+    sync = sync or torch.cuda.synchronize
     ones = torch.ones(1, device=device)
     dist.all_reduce(ones)
     n_par = sum(p.numel() for p in net.parameters() if p.requires_grad)
     flat = torch.zeros(n_par, device=device)
     for _ in range(3):
         dist.all_reduce(flat)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(10):
         dist.all_reduce(flat)
-    torch.cuda.synchronize()
+    sync()
     ar_ms = (time.perf_counter() - t0) / 10 * 1e3
     k = min(args.steps, 10)
     it0 = args.warmup + args.steps
     with model.no_sync():
         step(it0)
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         t0 = time.perf_counter()
         for it in range(it0 + 1, it0 + 1 + k):
             step(it)
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         nosync_ms = (time.perf_counter() - t0) / k * 1e3
     t = torch.tensor([ar_ms, nosync_ms], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ar_ms, nosync_ms = (float(v) for v in t.tolist())
     exposed = max(ms_per_step - nosync_ms, 0.0)
-    return {"backend": "rccl", "ranks": int(ones.item()), "grad_bytes": 4 * n_par,
+    return {"backend": backend, "ranks": int(ones.item()), "grad_bytes": 4 * n_par, "reducer": type(model).__name__,
             "allreduce_ms_standalone": round(ar_ms, 3), "ms_per_step_without_allreduce": round(nosync_ms, 3),
             "allreduce_exposed_ms": round(exposed, 3), "allreduce_hidden_ms": round(max(ar_ms - exposed, 0.0), 3)}
 

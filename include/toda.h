@@ -38,10 +38,21 @@ extern "C" {
 #define TODA_EINVAL (-1)   /* bad argument / unsupported shape            */
 #define TODA_EWORKSPACE (-2) /* workspace too small                       */
 #define TODA_ELAUNCH (-3)  /* HIP launch or runtime error                 */
+#define TODA_EFAULT (-4)   /* a kernel reported a fault (toda_device_fault) */
+
+/* Bits of the device fault word: the kernels whose workgroups wait for each other inside one launch bound their spins;
+ * a wait that gives up raises its bit and the launch finishes with invalid numbers instead of hanging the GPU. */
+#define TODA_FAULT_BN2D 1u /* bn2d_fwd/bwd_split_kernel: partner never published */
+#define TODA_FAULT_WINO 2u /* wino_fwd_ws_kernel: stream-K contributor never published */
 
 const char* toda_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int toda_abi_version(void);
+/* Reads and clears the fault word (host-mapped memory: no device synchronisation).  TODA_OK, or TODA_EFAULT with the
+ * kernels named in toda_last_error().  toda_bn2d_* and toda_conv3x3_fwd poll it on entry as well, so a fault raised by
+ * one launch is reported by the next call of that family at the latest; call it after a synchronisation point to learn
+ * about the launches before it.  (No reference counterpart: the reference's cuDNN / spconv kernels never wait on each other.) */
+int toda_device_fault(void);
 
 /* ------------------------------------------------------------------------
  * Hard voxelisation.  Replaces spconv Point2VoxelCPU3d.point_to_voxel /

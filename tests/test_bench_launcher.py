@@ -41,3 +41,22 @@ def test_world_size_mismatch_is_an_error_not_an_assert():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("reducer", ["own", "torch"])
+def test_two_rank_rehearsal_of_the_n_gpu_bench_path(reducer):
+    """What the driver's N = 8 run executes around the kernels, on two gloo ranks: wrap_ddp (both reducers), warm-up, barriers,
+    timed steps, max over ranks and comm_report - no_sync() steps, the stand-alone all-reduce, the exposed / hidden split."""
+    p = _run({"TODA_BENCH_DRYRUN_REHEARSAL": "tests.bench_rehearsal:make", "TODA_DDP": reducer, "PYTHONPATH": ROOT},
+             "--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    comm = line["comm"]
+    assert comm["ranks"] == 2 and comm["backend"] == "gloo" and comm["grad_bytes"] > 4_000_000
+    assert comm["reducer"] == ("DataParallel" if reducer == "own" else "DistributedDataParallel")
+    for key in ("allreduce_ms_standalone", "ms_per_step_without_allreduce", "allreduce_exposed_ms", "allreduce_hidden_ms"):
+        assert comm[key] >= 0.0
+    assert comm["ms_per_step_without_allreduce"] > 0 and line["ms_per_step"] > 0 and line["value"] > 0

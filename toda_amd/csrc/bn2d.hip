@@ -13,6 +13,8 @@
 // Deterministic: fixed reduction tree, no atomics.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -223,7 +225,7 @@ __device__ __forceinline__ void bn2_plane_of_block(int C, int P, int* c, int* b)
 }
 
 // thread 0 of the block publishes (v0, v1) for (c, b), waits for the P - 1 partners and returns all P pairs through `sh` (LDS, 2 P doubles)
-__device__ __forceinline__ void bn2_exchange(Bn2Sync* sy, int c, int b, int P, unsigned epoch, double v0, double v1, double* sh) {
+__device__ __forceinline__ void bn2_exchange(Bn2Sync* sy, int c, int b, int P, unsigned epoch, double v0, double v1, double* sh, unsigned* fault) {
     if (threadIdx.x == 0) {
         const int me = c * P + b;
         // relaxed agent-scope atomics only (they go through to memory past the XCD-private caches): a release / acquire pair
@@ -234,8 +236,18 @@ __device__ __forceinline__ void bn2_exchange(Bn2Sync* sy, int c, int b, int P, u
         __hip_atomic_store(&sy->flag[me], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int p = 0; p < P; ++p) {
             const int o = c * P + p;
-            if (p != b)
-                while (__hip_atomic_load(&sy->flag[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+            if (p != b) {
+                // bounded: a partner that never becomes resident (fewer CUs than the ordering argument above assumes) must not
+                // hang the GPU - after ~2 s the fault word goes up and the launch finishes with invalid statistics
+                unsigned polls = 0;
+                while (__hip_atomic_load(&sy->flag[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    if (++polls > FAULT_SPIN_LIMIT) {
+                        fault_raise(fault, TODA_FAULT_BN2D);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
             asm volatile("" ::: "memory");
             sh[2 * p] = __longlong_as_double((long long)__hip_atomic_load(&sy->val[o][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             sh[2 * p + 1] = __longlong_as_double((long long)__hip_atomic_load(&sy->val[o][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -248,7 +260,7 @@ template <int V, int K, bool RELU>
 __global__ void __launch_bounds__(BN2_BLOCK)
 bn2d_fwd_split_kernel(const float* __restrict__ x, int C, int P, int hwv, const float* __restrict__ gamma, const float* __restrict__ beta,
                       float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                      float* __restrict__ y, float* __restrict__ save, Bn2Sync* __restrict__ sy, unsigned epoch) {
+                      float* __restrict__ y, float* __restrict__ save, Bn2Sync* __restrict__ sy, unsigned epoch, unsigned* __restrict__ fault) {
     __shared__ double sh[BN2_BLOCK / 64];
     __shared__ double part[2 * BN2_MAX_P];
     int c, b;
@@ -282,7 +294,7 @@ bn2d_fwd_split_kernel(const float* __restrict__ x, int C, int P, int hwv, const 
     const double dmb = mean_b_d - (double)mean_b;
     const double m2_b = bn2_block_sum((double)q, sh) - n_b * dmb * dmb;        // sum (x - mean_b)^2 of this plane
     // planes -> channel (Chan et al.): mean = sum n_b mean_b / n, M2 = sum M2_b + sum n_b (mean_b - mean)^2; all n_b are equal
-    bn2_exchange(sy, c, b, P, epoch, mean_b_d, m2_b, part);
+    bn2_exchange(sy, c, b, P, epoch, mean_b_d, m2_b, part, fault);
     double mean_d = 0.0;
     for (int p = 0; p < P; ++p) mean_d += part[2 * p];
     mean_d /= P;
@@ -320,7 +332,7 @@ template <int V, int K, bool RELU>
 __global__ void __launch_bounds__(BN2_BLOCK)
 bn2d_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C, int P, int hwv, const float* __restrict__ gamma,
                       const float* __restrict__ beta, const float* __restrict__ save, float* __restrict__ dx,
-                      float* __restrict__ dgamma, float* __restrict__ dbeta, Bn2Sync* __restrict__ sy, unsigned epoch) {
+                      float* __restrict__ dgamma, float* __restrict__ dbeta, Bn2Sync* __restrict__ sy, unsigned epoch, unsigned* __restrict__ fault) {
     __shared__ double sh[BN2_BLOCK / 64];
     __shared__ double part[2 * BN2_MAX_P];
     int c, b;
@@ -353,7 +365,7 @@ bn2d_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
     }
     const double p1 = bn2_block_sum((double)s1, sh);
     const double p2 = bn2_block_sum((double)s2, sh);
-    bn2_exchange(sy, c, b, P, epoch, p1, p2, part);
+    bn2_exchange(sy, c, b, P, epoch, p1, p2, part, fault);
     double sum_g = 0.0, sum_gx = 0.0;
     for (int p = 0; p < P; ++p) sum_g += part[2 * p], sum_gx += part[2 * p + 1];
     const double n = (double)hwv * V * P;
@@ -426,18 +438,18 @@ static void bn2_launch_bwd(bool relu, dim3 grid, hipStream_t s, const float* x, 
 // split kernels: BB is the dummy 0 so that the same BN2_BY_K switch serves them; the trailing arguments carry P, sync, epoch
 template <int V, int BB, int K>
 static void bn2_launch_fwd_split(bool relu, dim3 grid, hipStream_t s, const float* x, int c, int P, int hwv, const float* gamma, const float* beta,
-                                 float* rm, float* rv, float momentum, float eps, float* y, float* save, Bn2Sync* sy, unsigned epoch) {
+                                 float* rm, float* rv, float momentum, float eps, float* y, float* save, Bn2Sync* sy, unsigned epoch, unsigned* fault) {
     if constexpr (K * V <= 36) {
-        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, save, sy, epoch);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, save, sy, epoch);
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, save, sy, epoch, fault);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, save, sy, epoch, fault);
     }
 }
 template <int V, int BB, int K>
 static void bn2_launch_bwd_split(bool relu, dim3 grid, hipStream_t s, const float* x, const float* dy, int c, int P, int hwv, const float* gamma,
-                                 const float* beta, const float* save, float* dx, float* dgamma, float* dbeta, Bn2Sync* sy, unsigned epoch) {
+                                 const float* beta, const float* save, float* dx, float* dgamma, float* dbeta, Bn2Sync* sy, unsigned epoch, unsigned* fault) {
     if constexpr (K * V <= 36) {
-        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch);
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch, fault);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch, fault);
     }
 }
 
@@ -473,6 +485,15 @@ static void bn2_launch_bwd_split(bool relu, dim3 grid, hipStream_t s, const floa
         else { BN2_BY_K(LAUNCH, 1, 0, relu != 0, grid, s, __VA_ARGS__) }                      \
     } while (0)
 
+// a fault raised by an earlier launch (bounded spin gave up) is reported by the next call; the message names the kernels
+static int bn2_fault_poll(const char* who) {
+    const unsigned v = fault_take();
+    if (!v) return TODA_OK;
+    toda::set_error("%s: device fault word 0x%x raised by an earlier launch (bounded inter-workgroup wait gave up: %s%s) - its results are invalid",
+                    who, v, (v & TODA_FAULT_BN2D) ? "bn2d split kernel " : "", (v & TODA_FAULT_WINO) ? "wino_fwd_ws_kernel" : "");
+    return TODA_EFAULT;
+}
+
 extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, float momentum, float eps, int relu, float* y, float* save, void* sync, unsigned epoch,
                              void* stream) {
@@ -480,13 +501,14 @@ extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const flo
     TODA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn2d_fwd: running_mean and running_var go together");
     // forward: the exchange costs 2-3 us, the single workgroup per channel only half-fills the GPU on <= 128 channels - measured
     // 19.1 vs 21.3 us at 2 x 128 x 188 x 188, 9.9 vs 12.6 at 2 x 256 x 94 x 94: one workgroup per channel wherever it fits
+    if (int rc = bn2_fault_poll("bn2d_fwd")) return rc;
     const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw) && bn2_floats_per_thread(batch, hw) == 0;
     TODA_CHECK_ARG(split || bn2_floats_per_thread(batch, hw) > 0, "bn2d_fwd: unsupported shape (batch %d, channels %d, hw %d)%s", batch, c, hw,
                    sync ? "" : " without a sync workspace");
     const int v = (hw & 3) ? 1 : 4, hwv = hw / v;
     const int k = bn2_pick_k(hwv, v);
     hipStream_t s = (hipStream_t)stream;
-    if (split) BN2_DISPATCH_SPLIT(bn2_launch_fwd_split, x, c, batch, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save, (Bn2Sync*)sync, epoch);
+    if (split) BN2_DISPATCH_SPLIT(bn2_launch_fwd_split, x, c, batch, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save, (Bn2Sync*)sync, epoch, fault_word_dev());
     else BN2_DISPATCH(bn2_launch_fwd, x, c, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
@@ -498,13 +520,16 @@ extern "C" int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, 
     // backward: per plane when a channel's dy no longer leaves room for anything else in the registers (the channel kernel then
     // spills and reads x twice: 51.6 vs 28.5 us at 2 x 128 x 188 x 188; at 2 x 256 x 94 x 94 it is 12.8 vs 17.7 the other way)
     const int per_channel = bn2_floats_per_thread(batch, hw);
-    const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw) && (per_channel == 0 || per_channel > 36);
+    if (int rc = bn2_fault_poll("bn2d_bwd")) return rc;
+    // TODA_BN2D_SPLIT=0: never the partner-exchange kernel where the per-channel one exists (it spills there, it cannot wait)
+    static const int env_split = getenv("TODA_BN2D_SPLIT") ? atoi(getenv("TODA_BN2D_SPLIT")) : 1;
+    const bool split = sync != nullptr && epoch != 0 && bn2_split_ok(batch, c, hw) && (per_channel == 0 || (per_channel > 36 && env_split));
     TODA_CHECK_ARG(split || per_channel > 0, "bn2d_bwd: unsupported shape (batch %d, channels %d, hw %d)%s", batch, c, hw,
                    sync ? "" : " without a sync workspace");
     const int v = (hw & 3) ? 1 : 4, hwv = hw / v;
     const int k = bn2_pick_k(hwv, v);
     hipStream_t s = (hipStream_t)stream;
-    if (split) BN2_DISPATCH_SPLIT(bn2_launch_bwd_split, x, dy, c, batch, hwv, gamma, beta, save, dx, dgamma, dbeta, (Bn2Sync*)sync, epoch);
+    if (split) BN2_DISPATCH_SPLIT(bn2_launch_bwd_split, x, dy, c, batch, hwv, gamma, beta, save, dx, dgamma, dbeta, (Bn2Sync*)sync, epoch, fault_word_dev());
     else BN2_DISPATCH(bn2_launch_bwd, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
     TODA_LAUNCH_CHECK();
     return TODA_OK;

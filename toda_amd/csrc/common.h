@@ -30,6 +30,15 @@ void set_error(const char* fmt, ...);
 
 #define TODA_LAUNCH_CHECK() TODA_HIP(hipGetLastError())
 
+// device fault word (common.hip): device-visible pointer to a host-mapped word, nullptr when pinned memory is unavailable;
+// fault_take() returns and clears it.  Kernels raise bits with fault_raise().
+unsigned* fault_word_dev();
+unsigned fault_take();
+constexpr unsigned FAULT_SPIN_LIMIT = 1u << 21;      // polls of ~1 us: about two seconds
+__device__ __forceinline__ void fault_raise(unsigned* word, unsigned bit) {
+    if (word) __hip_atomic_fetch_or(word, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -467,7 +467,7 @@ __device__ __forceinline__ void ws_epilogue(const f32x4 (&acc)[WN_FREQ], float* 
 __global__ void __launch_bounds__(WS_BLOCK, 2)
 wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
                    float* __restrict__ y, const WinoGeom g, const int n_units, float* __restrict__ slabs,
-                   int* __restrict__ flags, const int gang, const int ablate) {
+                   int* __restrict__ flags, const int gang, const int ablate, unsigned* __restrict__ fault) {
     __shared__ float lds[4 * WN_FREQ * WN_IMG];   // A0 | A1 | B0 | B1
     constexpr int IMG = WN_FREQ * WN_IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -560,7 +560,17 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
                     const long long unit_end = (long long)(unit + 1) * g.n_chunks;
                     for (int r2 = rng + 1; r2 < G && ws_range_lo(r2, G, S) < unit_end; ++r2) {
                         int* const fl = flags + (r2 * gsz + member) * 4 + wave;       // same member of the following ranges
-                        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                        // bounded: the contributor sits in a later workgroup, which is resident or next in line
+                        // only while dispatch is in id order and the grid fits the CUs it was sized for; if that ever fails the
+                        // wait gives up after ~2 s, raises the fault word and the launch ends with a wrong unit, not a hung GPU
+                        unsigned polls = 0;
+                        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                            if (++polls > FAULT_SPIN_LIMIT) {
+                                if (lane == 0) fault_raise(fault, TODA_FAULT_WINO);
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(8);
+                        }
                         ++n_in;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1091,8 +1101,17 @@ extern "C" int toda_conv3x3_fwd(const float* x, const float* u, const float* bia
         int* flags = (int*)ws;                                  // 4 words per workgroup: zero on entry, zero again on exit
         float* slabs = (float*)((char*)ws + WS_FLAG_BYTES);
         static const int ablate = getenv("TODA_WINO_ABLATE") ? atoi(getenv("TODA_WINO_ABLATE")) : 0;
+        if (const unsigned fv = fault_take()) {
+            // a bounded wait of an earlier launch gave up: its flags may still be up - put the workspace back into its all-zero
+            // state behind that launch and report
+            (void)hipMemsetAsync(ws, 0, WS_FLAG_BYTES, (hipStream_t)stream);
+            toda::set_error("conv3x3_fwd: device fault word 0x%x raised by an earlier launch (bounded inter-workgroup wait gave up: %s%s) - its "
+                            "results are invalid; the stream-K flags have been re-zeroed (TODA_WINO_VARIANT=0 selects the kernel without hand-offs)",
+                            fv, (fv & TODA_FAULT_BN2D) ? "bn2d split kernel " : "", (fv & TODA_FAULT_WINO) ? "wino_fwd_ws_kernel" : "");
+            return TODA_EFAULT;
+        }
         hipLaunchKernelGGL(wino_fwd_ws_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, u, bias, y, g, n_units, slabs, flags,
-                           gang, ablate);
+                           gang, ablate, fault_word_dev());
     }
     TODA_LAUNCH_CHECK();
     return TODA_OK;

@@ -33,8 +33,11 @@ def read_counts(counts_dev, while_waiting=None):
     On a side stream (the input pipeline) the host sleeps on the event instead of spinning: the wait is off the training stream
     there, and a thread that spins for milliseconds every step eats into the process's CPU quota."""
     dev = counts_dev.device
-    side = torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev)
-    key = (dev.index, counts_dev.numel(), side)
+    cur = torch.cuda.current_stream(dev)
+    side = cur != torch.cuda.default_stream(dev)
+    # one pinned buffer + event per STREAM (and size): two input pipelines alive together - train and eval prefetchers, or a
+    # while_waiting callback that comes back here on another stream - must not share a host buffer (ADVICE r2)
+    key = (dev.index, counts_dev.numel(), int(cur.cuda_stream))
     ent = _COUNT_PINNED.get(key)
     if ent is None:
         ent = _COUNT_PINNED[key] = (torch.empty((counts_dev.numel(),), dtype=torch.int32).pin_memory(), torch.cuda.Event(blocking=side))
@@ -50,7 +53,10 @@ def read_counts(counts_dev, while_waiting=None):
             _time.sleep(5e-5)
     else:
         ev.synchronize()
-    return host.tolist()
+    vals = host.tolist()
+    # the step's one natural look at the device fault word (host-mapped, no sync): a bounded inter-workgroup wait that gave up
+    L.check(L.load().toda_device_fault(), "toda_device_fault")
+    return vals
 
 
 def voxelize_raw(points, pc_range, voxel_size, max_pts, max_voxels):

@@ -47,13 +47,13 @@ def voxelize_on_gpu(batch_dict, voxel_cfg):
     return batch_dict
 
 
-def prepare_batch_on_gpu(batch_dict, net):
+def prepare_batch_on_gpu(batch_dict, net, voxel_cfg=None):
     """Everything of a training step that depends only on the INPUT: H2D, voxelisation, the sparse backbone's rulebooks.
     The reference does this part (voxelisation) in DataLoader workers, concurrently with the previous training step
     (pcdet/datasets/processor/data_processor.py:115-143); InputPrefetcher below does it on a side stream."""
     load_data_to_gpu(batch_dict)
     if "voxels" not in batch_dict and "points" in batch_dict:
-        voxelize_on_gpu(batch_dict, net.dataset.voxel_cfg)
+        voxelize_on_gpu(batch_dict, voxel_cfg if voxel_cfg is not None else net.dataset.voxel_cfg)
     backbone = getattr(net, "backbone_3d", None)
     if backbone is not None and hasattr(backbone, "plan") and "voxel_coords" in batch_dict and batch_dict["voxel_coords"].is_cuda:
         backbone.plan(batch_dict)
@@ -87,10 +87,16 @@ class InputPrefetcher:
     iteration are ENQUEUED: the host then waits in the side stream's syncs while the GPU has the whole backward to run (kicked
     right behind the forward, the host waits with nothing queued behind it and the GPU runs dry: measured no gain)."""
 
-    def __init__(self, batches, net, device, eager=True):
+    def __init__(self, batches, net, device, eager=True, voxel_cfg=None):
         self.it = iter(batches)
         self.net = net
+        self.voxel_cfg = voxel_cfg          # the voxeliser settings of the dataset being READ (evaluation of a train-built model: the eval set's cap / range)
         self.side = torch.cuda.Stream(device=device)
+        # device tensors that exist already (resident clouds, an object database, the model's weights) were produced on the
+        # caller's stream: the side stream waits for that stream ONCE, here.  Not in kick(): kick() runs right behind an enqueued
+        # backward pass and must not wait for it - what a later batch reads is either uploaded on the side stream itself or
+        # older than this point.
+        self.side.wait_stream(torch.cuda.current_stream(device))
         self.pending = None
         if eager:
             self.kick()
@@ -104,9 +110,9 @@ class InputPrefetcher:
             except StopIteration:
                 return
             if isinstance(batch, (tuple, list)):      # the (adversarial, original) pair of the stage-2 consistency step
-                batch = tuple(prepare_batch_on_gpu(b, self.net) for b in batch)
+                batch = tuple(prepare_batch_on_gpu(b, self.net, self.voxel_cfg) for b in batch)
             else:
-                batch = prepare_batch_on_gpu(batch, self.net)
+                batch = prepare_batch_on_gpu(batch, self.net, self.voxel_cfg)
             ev = torch.cuda.Event()
             ev.record(self.side)
         self.pending = (batch, ev)

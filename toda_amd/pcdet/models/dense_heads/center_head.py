@@ -38,6 +38,19 @@ class SeparateHead(nn.Module):
                             nn.init.constant_(m.bias, 0)
             setattr(self, name, branch)
 
+    def alias_fused_buffers(self):
+        """Point the hidden layers' BatchNorm running statistics at slices of two wide tensors NOW (what the fused forward
+        does lazily).  common_utils.wrap_ddp calls this before a wrapper captures module.buffers(): a wrapper that broadcasts
+        the tensors it saw at construction would otherwise keep syncing orphans once the first forward has re-pointed them."""
+        branches = [getattr(self, name) for name in self.sep_head_dict]
+        if len(branches) < 2 or not all(len(br) == 2 and type(br[0]) is nn.Sequential and len(br[0]) == 3 for br in branches):
+            return False
+        bns = [br[0][1] for br in branches]
+        if not all(type(bn) is nn.BatchNorm2d and bn.track_running_stats and bn.num_features == bns[0].num_features for bn in bns):
+            return False
+        ops._aliased_running_stats(self, bns)
+        return True
+
     def forward(self, x):
         names = list(self.sep_head_dict)
         branches = [getattr(self, name) for name in names]

@@ -226,6 +226,7 @@ class GradBucketReducer:
         self.pending = [len(b) for b in self.buckets]
         self.seen = [set() for _ in self.buckets]
         self.work = [None] * len(self.buckets)
+        self.next_launch = 0          # collectives are issued strictly in bucket-index order (see _ready)
         self.armed = False
 
     def _launch(self, bi):
@@ -256,16 +257,23 @@ class GradBucketReducer:
             return
         self.seen[bi].add(id(p))
         self.pending[bi] -= 1
-        if self.pending[bi] == 0:
-            self._launch(bi)
+        # Every rank must issue its collectives in the SAME order: a bucket goes out only once all buckets before it have gone
+        # (as DDP's reducer does).  Launching in completion order would depend on each rank's autograd order and on which
+        # parameters got a gradient in this pass - data dependent (an empty head, a loss term that is off) - and two ranks
+        # issuing all-reduces in different orders hang or add up the wrong buckets.
+        while self.next_launch < len(self.buckets) and self.pending[self.next_launch] == 0:
+            self._launch(self.next_launch)
+            self.next_launch += 1
 
     def finish(self):
         if not self.enabled:
             self._reset()
             return
-        for bi, b in enumerate(self.buckets):
-            if self.work[bi] is None:          # a parameter without a gradient in this pass: reduce what there is (zeros for it)
-                self._launch(bi)
+        # the rest in index order too: buckets holding a parameter without a gradient in this pass (zeros reduced for it) and
+        # whatever was queued behind them
+        while self.next_launch < len(self.buckets):
+            self._launch(self.next_launch)
+            self.next_launch += 1
         scale = 1.0 / self.world
         for bi, b in enumerate(self.buckets):
             self.work[bi].wait()
@@ -323,11 +331,16 @@ class DataParallel(torch.nn.Module):
 
 
 def wrap_ddp(model, device_ids=None, **kw):
-    """Data-parallel wrapper of the trainers and bench.py.  Default: DataParallel above (flat-bucket gradient reducer + coalesced
-    buffer broadcast).  TODA_DDP=torch (or reducer="torch"): torch's DistributedDataParallel with 8 MB bucket views, its buffer
-    sync replaced by BufferBroadcaster unless coalesced_buffer_broadcast=False."""
-    reducer = kw.pop("reducer", os.environ.get("TODA_DDP", "own"))
+    """Data-parallel wrapper of the trainers and bench.py.  Default: torch's DistributedDataParallel with 8 MB bucket views, its
+    buffer sync replaced by BufferBroadcaster unless coalesced_buffer_broadcast=False.  TODA_DDP=own (or reducer="own"):
+    DataParallel above (flat-bucket gradient reducer, 0.5 ms / 109 launches per step cheaper on one MI355X).  The own reducer
+    stays opt-in until it has run over RCCL with more than one GPU: it is covered by 2-rank gloo tests only (no multi-GPU box
+    was available to any round), and a first N = 8 run is no place for a collective path that has never seen RCCL."""
+    reducer = kw.pop("reducer", os.environ.get("TODA_DDP", "torch"))
     own_bcast = kw.pop("coalesced_buffer_broadcast", True)
+    for m in model.modules():       # fused heads re-point their BatchNorm buffers: do it before a wrapper captures module.buffers()
+        if hasattr(m, "alias_fused_buffers") and next(m.parameters(), torch.empty(0)).is_cuda:
+            m.alias_fused_buffers()
     if reducer != "torch" and not kw.get("static_graph") and own_bcast:
         return DataParallel(model, bucket_cap_mb=kw.get("bucket_cap_mb", 8))
     kw.setdefault("gradient_as_bucket_view", True)

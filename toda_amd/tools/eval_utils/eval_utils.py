@@ -31,7 +31,7 @@ def run_inference(model, dataloader, on_batch=None):
         # stream while this batch's forward and its host-side decoding run
         from toda_amd.pcdet.models import InputPrefetcher
         with torch.no_grad():
-            pre = InputPrefetcher(iter(dataloader), net, first.device, eager=False)
+            pre = InputPrefetcher(iter(dataloader), net, first.device, eager=False, voxel_cfg=getattr(dataset, "voxel_cfg", None))
         while True:
             try:
                 with torch.no_grad():

@@ -54,8 +54,14 @@ def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, ac
         net = getattr(net, "onepass", net)
         if hasattr(net, "dataset"):
             prefetch = InputPrefetcher(_stream(), net, first.device, eager=False)
+    def _progress(it):     # reference :47-48: progress in [0, 1) drives the PolarMix ASC / DESC / SIGMOID sector schedules
+        if total_epoch:
+            train_loader.dataset.train_percent = (cur_epoch * total_it_each_epoch + it) / (total_epoch * total_it_each_epoch)
+
     for cur_it in range(total_it_each_epoch):
         end = time.time()
+        if cur_it == 0 or prefetch is None:
+            _progress(cur_it)      # before the batch is BUILT (a device-side mix source reads it while mixing)
         batch = prefetch.next() if prefetch is not None else _next_host_batch()
         t_data = time.time() - end
         lr_scheduler.step(accumulated_iter)
@@ -64,14 +70,13 @@ def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, ac
             cur_lr = optimizer.param_groups[0]["lr"]
         model.train()
         optimizer.zero_grad()
-        if total_epoch:     # reference :47-48: progress in [0, 1) drives the PolarMix ASC / DESC / SIGMOID sector schedules
-            train_loader.dataset.train_percent = (cur_epoch * total_it_each_epoch + cur_it) / (total_epoch * total_it_each_epoch)
         loss, tb_dict, disp = model_func(model, batch)
         t_fwd = time.time() - end
         loss.backward()
         clip_grad_norm_(model.parameters(), optim_cfg.GRAD_NORM_CLIP)
         optimizer.step()
         if prefetch is not None and cur_it + 1 < total_it_each_epoch:
+            _progress(cur_it + 1)    # the batch built now is the one iteration cur_it + 1 trains on
             prefetch.kick()          # not behind the epoch's last iteration: nothing is fetched that this call does not train on
         accumulated_iter += 1
         data_time.update(t_data)

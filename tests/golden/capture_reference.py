@@ -157,6 +157,55 @@ def cap_bev(L):
              gx=x.grad.numpy(), **sd_np(m0), **{"after." + k[2:]: v for k, v in w0.items() if "running" in k}, **grads)
 
 
+# Wide variants: channel counts that are multiples of 32 and an even map width, so that the GPU twins of these
+# fixtures run on the hand-written kernels (Winograd 3x3 convolutions, bn2d, the fused hidden layer of the head, the narrow output
+# convolutions, the fused loss) instead of the library ones the 8 / 16-channel fixtures above fall back to.
+BEV_WIDE_CFG = dict(LAYER_NUMS=[1, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[32, 64], UPSAMPLE_STRIDES=[1, 2],
+                    NUM_UPSAMPLE_FILTERS=[32, 32])
+
+
+def cap_bev_wide(L):
+    np.int = int
+    torch.manual_seed(11)
+    m = L["base_bev_backbone"].BaseBEVBackbone(EasyDict(BEV_WIDE_CFG), 32).train()
+    w_init = sd_np(m)
+    x = torch.randn(2, 32, 16, 24, requires_grad=True)
+    y = m({"spatial_features": x})["spatial_features_2d"]
+    after = sd_np(m)
+    g = torch.randn_like(y)
+    y.backward(g)
+    grads = {"g." + n: p.grad.numpy() for n, p in m.named_parameters()}
+    np.savez_compressed(os.path.join(OUT, "bev_backbone_wide.npz"), x=x.detach().numpy(), y=y.detach().numpy(), gy=g.numpy(),
+             gx=x.grad.numpy(), **w_init, **{"after." + k[2:]: v for k, v in after.items() if "running" in k}, **grads)
+
+
+def cap_center_head_wide(L):
+    CenterHead = L["center_head"].CenterHead
+    rng = np.random.default_rng(12)
+    pc_range = np.array([-6.4, -6.4, -2, 6.4, 6.4, 4], np.float32)
+    vs = [0.1, 0.1, 0.15]
+    cfg = EasyDict(HEAD_CFG)
+    cfg.SHARED_CONV_CHANNEL = 64
+    torch.manual_seed(13)
+    head = CenterHead(cfg, 32, 3, CLASSES, np.array([128, 128, 40]), pc_range, vs, predict_boxes_when_training=False).train()
+    w0 = sd_np(head)
+    x = torch.randn(2, 32, 16, 16, requires_grad=True)
+    gt = make_gt(rng, 2, 9, -7.0, 7.0)
+    data = {"spatial_features_2d": x, "gt_boxes": torch.from_numpy(gt.copy()), "batch_size": 2}
+    head(data)
+    td = head.forward_ret_dict["target_dicts"]
+    preds = {k: v.detach().numpy().copy() for k, v in head.forward_ret_dict["pred_dicts"][0].items()}
+    loss, tb = head.get_loss()
+    loss.backward()
+    after = sd_np(head)
+    np.savez_compressed(os.path.join(OUT, "center_head_wide.npz"), x=x.detach().numpy(), gt=gt, pc_range=pc_range, voxel_size=np.array(vs),
+             heatmap=td["heatmaps"][0].numpy(), target_boxes=td["target_boxes"][0].numpy(), inds=td["inds"][0].numpy(),
+             masks=td["masks"][0].numpy(), loss=np.float32(loss.item()), hm_loss=np.float32(tb["hm_loss_head_0"]),
+             loc_loss=np.float32(tb["loc_loss_head_0"]), gx=x.grad.numpy(), **w0, **{"pred." + k: v for k, v in preds.items()},
+             **{"after." + k[2:]: v for k, v in after.items() if "running" in k},
+             **{"g." + n: p.grad.numpy() for n, p in head.named_parameters() if p.grad is not None})
+
+
 HEAD_CFG = dict(
     CLASS_AGNOSTIC=False, CLASS_NAMES_EACH_HEAD=[["Vehicle", "Pedestrian", "Cyclist"]], SHARED_CONV_CHANNEL=16,
     USE_BIAS_BEFORE_NORM=True, NUM_HM_CONV=2,
@@ -360,12 +409,12 @@ def cap_c1_chain(L):
 
 def main():
     L = setup()
-    cap_mean_vfe(L)
-    cap_bev(L)
-    cap_center_head(L)
-    cap_optim(L)
-    cap_losses(L)
-    cap_c1_chain(L)
+    caps = {"mean_vfe": cap_mean_vfe, "bev": cap_bev, "center_head": cap_center_head, "optim": cap_optim, "losses": cap_losses,
+            "c1_chain": cap_c1_chain, "bev_wide": cap_bev_wide, "center_head_wide": cap_center_head_wide}
+    only = sys.argv[1:]          # e.g. `capture_reference.py bev_wide center_head_wide`: just these (the others stay as committed)
+    for name, fn in caps.items():
+        if not only or name in only:
+            fn(L)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -68,3 +68,33 @@ def dense_out_sites(idx, batch, shape, ksize, stride, pad):
     om = F.conv3d(m, k, stride=tuple(stride), padding=tuple(pad)) > 0
     sites = om[:, 0].nonzero()  # already lexicographic in (b,z,y,x)
     return sites.numpy().astype(np.int32), list(om.shape[2:])
+
+
+class abi_calls:
+    """Counts calls of C-ABI entry points while a test runs: `with abi_calls("toda_conv3x3_fwd", ...) as n: ...; n["toda_conv3x3_fwd"]`.
+    The golden twins use it to prove that a fixture was served by the hand-written kernels and not by a library fallback."""
+
+    def __init__(self, *names):
+        self.names = names
+        self.count = {n: 0 for n in names}
+        self._orig = {}
+
+    def __enter__(self):
+        from toda_amd import lib as L
+
+        self._lib = L.load()
+        for n in self.names:
+            orig = getattr(self._lib, n)
+            self._orig[n] = orig
+
+            def wrapper(*args, _orig=orig, _n=n):
+                self.count[_n] += 1
+                return _orig(*args)
+
+            setattr(self._lib, n, wrapper)
+        return self.count
+
+    def __exit__(self, *exc):
+        for n, orig in self._orig.items():
+            setattr(self._lib, n, orig)
+        return False

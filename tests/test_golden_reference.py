@@ -61,13 +61,23 @@ BEV_CFG = dict(LAYER_NUMS=[1, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[8, 16], UPS
                NUM_UPSAMPLE_FILTERS=[16, 16])
 
 
-def check_bev_backbone(device, tol=1.0):
+BEV_WIDE_CFG = dict(LAYER_NUMS=[1, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[32, 64], UPSAMPLE_STRIDES=[1, 2],
+                    NUM_UPSAMPLE_FILTERS=[32, 32])
+
+
+def rel_err(got, want):
+    """max |got - want| relative to max |want|: the scale-relative max-norm error the wide fixtures are judged by."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+
+
+def check_bev_backbone(device, tol=1.0, name="bev_backbone", cfg=None, cin=12):
     """BaseBEVBackbone forward / input-grad / weight-grads / running statistics vs the reference's module (tol scales the
     tolerances: 1 on the CPU; the GPU twin allows the library convolutions' different summation order)."""
     from toda_amd.pcdet.models.backbones_2d import BaseBEVBackbone
 
-    g = load("bev_backbone")
-    m = BaseBEVBackbone(AttrDict(BEV_CFG), 12).train()
+    g = load(name)
+    m = BaseBEVBackbone(AttrDict(cfg or BEV_CFG), cin).train()
     load_weights(m, g)
     m = m.to(device)
     x = torch.from_numpy(g["x"]).to(device).requires_grad_(True)
@@ -86,6 +96,41 @@ def test_bev_backbone_matches_reference():
     check_bev_backbone("cpu")
 
 
+def test_bev_backbone_wide_matches_reference():
+    """32 / 64-channel neck on a 16 x 24 map (reference base_bev_backbone.py:81-112): the fixture whose GPU twin reaches the
+    hand-written Winograd and bn2d kernels."""
+    check_bev_backbone("cpu", tol=3.0, name="bev_backbone_wide", cfg=BEV_WIDE_CFG, cin=32)
+
+
+def check_bev_backbone_wide_scaled(device, tol_fwd, tol_grad):
+    """The wide fixture by scale-relative max-norm error (no per-element rtol / atol games): forward, input gradient, every
+    parameter gradient, BN running statistics.  Returns the measured errors."""
+    from toda_amd.pcdet.models.backbones_2d import BaseBEVBackbone
+
+    g = load("bev_backbone_wide")
+    m = BaseBEVBackbone(AttrDict(BEV_WIDE_CFG), 32).train()
+    load_weights(m, g)
+    m = m.to(device)
+    x = torch.from_numpy(g["x"]).to(device).requires_grad_(True)
+    y = m({"spatial_features": x})["spatial_features_2d"]
+    errs = {"y": rel_err(y.detach().cpu().numpy(), g["y"])}
+    y.backward(torch.from_numpy(g["gy"]).to(device))
+    errs["gx"] = rel_err(x.grad.cpu().numpy(), g["gx"])
+    for n, p in m.named_parameters():
+        errs["g." + n] = rel_err(p.grad.cpu().numpy(), g["g." + n])
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            errs["after." + k] = rel_err(v.cpu().numpy(), g["after." + k])
+    assert errs["y"] <= tol_fwd, errs
+    bad = {k: v for k, v in errs.items() if k != "y" and v > (tol_fwd if k.startswith("after.") else tol_grad)}
+    assert not bad, bad
+    return errs
+
+
+def test_bev_backbone_wide_scaled_error_on_cpu():
+    check_bev_backbone_wide_scaled("cpu", 1e-5, 1e-4)
+
+
 HEAD_CFG = dict(
     CLASS_AGNOSTIC=False, CLASS_NAMES_EACH_HEAD=[["Vehicle", "Pedestrian", "Cyclist"]], SHARED_CONV_CHANNEL=16,
     USE_BIAS_BEFORE_NORM=True, NUM_HM_CONV=2,
@@ -99,13 +144,52 @@ HEAD_CFG = dict(
 )
 
 
-def build_head(g):
+def build_head(g, shared=16, cin=24):
     from toda_amd.pcdet.models.dense_heads import CenterHead
 
-    head = CenterHead(AttrDict(HEAD_CFG), 24, 3, ["Vehicle", "Pedestrian", "Cyclist"], np.array([128, 128, 40]),
+    cfg = AttrDict(HEAD_CFG)
+    cfg.SHARED_CONV_CHANNEL = shared
+    head = CenterHead(cfg, cin, 3, ["Vehicle", "Pedestrian", "Cyclist"], np.array([128, 128, 40]),
                       g["pc_range"], list(g["voxel_size"]), predict_boxes_when_training=False).train()
     load_weights(head, g)
     return head
+
+
+def check_center_head_wide(device, tol_fwd, tol_grad, backend=None):
+    """center_head_wide.npz (SHARED_CONV_CHANNEL 64 on a 32-channel 16 x 16 map; reference center_head.py:11-45,73-80,221-272):
+    predictions, targets, loss terms, input and parameter gradients, BN running statistics by scale-relative max-norm error."""
+    import contextlib
+
+    g = load("center_head_wide")
+    head = build_head(g, shared=64, cin=32).to(device)
+    x = torch.from_numpy(g["x"]).to(device).requires_grad_(True)
+    with (backend() if backend else contextlib.nullcontext()):
+        head({"spatial_features_2d": x, "gt_boxes": torch.from_numpy(g["gt"].copy()).to(device), "batch_size": 2})
+    td = head.forward_ret_dict["target_dicts"]
+    assert np.array_equal(td["inds"][0].cpu().numpy(), g["inds"]) and np.array_equal(td["masks"][0].cpu().numpy(), g["masks"])
+    errs = {"heatmap": rel_err(td["heatmaps"][0].cpu().numpy(), g["heatmap"])}
+    for k, v in head.forward_ret_dict["pred_dicts"][0].items():
+        errs["pred." + k] = rel_err(v.detach().cpu().numpy(), g["pred." + k])
+    loss, tb = head.get_loss()
+    errs["loss"] = abs(float(loss) - float(g["loss"])) / max(1.0, abs(float(g["loss"])))
+    errs["hm_loss"] = abs(float(tb["hm_loss_head_0"]) - float(g["hm_loss"])) / max(1.0, abs(float(g["hm_loss"])))
+    errs["loc_loss"] = abs(float(tb["loc_loss_head_0"]) - float(g["loc_loss"])) / max(1.0, abs(float(g["loc_loss"])))
+    loss.backward()
+    errs["gx"] = rel_err(x.grad.cpu().numpy(), g["gx"])
+    for n, p in head.named_parameters():
+        if "g." + n in g:
+            errs["g." + n] = rel_err(p.grad.cpu().numpy(), g["g." + n])
+    for k, v in head.state_dict().items():
+        if "running" in k:
+            errs["after." + k] = rel_err(v.cpu().numpy(), g["after." + k])
+    fwd_keys = [k for k in errs if k.startswith(("pred.", "after.", "heatmap")) or k in ("loss", "hm_loss", "loc_loss")]
+    bad = {k: v for k, v in errs.items() if v > (tol_fwd if k in fwd_keys else tol_grad)}
+    assert not bad, bad
+    return errs
+
+
+def test_center_head_wide_matches_reference():
+    check_center_head_wide("cpu", 2e-5, 2e-4, backend=oracle_backend)
 
 
 def test_center_head_forward_targets_loss_backward_match_reference():

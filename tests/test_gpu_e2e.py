@@ -207,3 +207,117 @@ def test_full_size_detector_matches_oracle_backend(name):
     global_err = float(d_all.norm() / g_all.norm())
     assert global_err < 2e-3, global_err
     print(f"{name}: loss {float(out.loss):.5f} vs {float(ref.loss):.5f}, BEV features rel {rel:.2e} / max {worst:.2e}, grads {global_err:.2e}")
+
+
+def _full_cfg(name):
+    import os
+    from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(root, CFG.format(name)), cfg)
+    return cfg
+
+
+def _bn_buffers(model):
+    return {n: b.detach().cpu().clone() for n, b in model.named_buffers() if n.endswith(("running_mean", "running_var"))}
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("name", ["centerpoint_voxel_waymo", "toda_stage1_centerpoint_res"])
+def test_full_size_train_mode_forward_matches_oracle_backend(name):
+    """The path bench.py times - TRAIN-mode BatchNorm: statistics from the gather-GEMM epilogue, bn2d, the fused hidden layer of
+    the head - at the FULL size of BASELINE configs 3 and 5 (reference spconv_backbone.py:21-25,128-180,
+    base_bev_backbone.py:81-112, center_head.py:221-272).  One training forward of the same weights through the HIP path and
+    through the CPU oracle backend: loss and every tb_dict entry <= 1e-3, the stage-4 sparse features as the dense BEV map
+    <= 1e-3, and every BatchNorm's running_mean / running_var after the step <= 1e-3 of the buffer's scale (those ARE the batch
+    statistics: momentum x batch moment + (1 - momentum) x init)."""
+    from oracle.cpu_backend import oracle_backend
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import build_network, model_fn_decorator
+
+    cfg = _full_cfg(name)
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    torch.manual_seed(0)
+    cpu_model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).train()
+    gpu_model = copy.deepcopy(cpu_model).cuda()
+    before = _bn_buffers(cpu_model)
+    batch = ds.collate_batch([ds[0], ds[1]])
+    assert batch["points"].shape[0] > 150_000
+    fn = model_fn_decorator()
+    feats = {}
+
+    def grab(tag):
+        def hook(mod, args, out):
+            feats[tag] = out["spatial_features"].detach().cpu()
+        return hook
+
+    cpu_model.map_to_bev_module.register_forward_hook(grab("cpu"))
+    gpu_model.map_to_bev_module.register_forward_hook(grab("gpu"))
+    with torch.no_grad():
+        with oracle_backend():
+            ref = fn(cpu_model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
+        out = fn(gpu_model, {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()})
+    assert abs(float(out.loss) - float(ref.loss)) <= 1e-3 * max(1.0, abs(float(ref.loss))), (float(out.loss), float(ref.loss))
+    for key in ref.tb_dict:
+        assert abs(float(out.tb_dict[key]) - float(ref.tb_dict[key])) <= 1e-3 * max(1.0, abs(float(ref.tb_dict[key]))), key
+    a, b = feats["cpu"], feats["gpu"]
+    rel = float((a - b).norm() / a.norm())
+    worst = float((a - b).abs().max() / a.abs().max())
+    assert rel < 1e-3 and worst < 1e-3, (rel, worst)
+    cpu_after, gpu_after = _bn_buffers(cpu_model), _bn_buffers(gpu_model)
+    moved, worst_bn = 0, 0.0
+    for n, v in cpu_after.items():
+        moved += int(not torch.equal(v, before[n]))
+        scale = float(v.abs().max()) + 1e-12
+        err = float((gpu_after[n] - v).abs().max()) / scale
+        worst_bn = max(worst_bn, err)
+        assert err <= 1e-3, (n, err)
+    assert moved == len(cpu_after) and moved >= 40          # every norm of the detector saw the batch
+    print(f"{name} train-mode: loss {float(out.loss):.5f} vs {float(ref.loss):.5f}, BEV rel {rel:.2e} / max {worst:.2e}, "
+          f"{moved} BN buffers, worst {worst_bn:.2e}")
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("bn_train", [True, False])
+def test_full_size_c2_backbone_forward_matches_oracle_backend(bn_train):
+    """BASELINE config 2 at its full size (reference spconv_backbone.py:128-180): VoxelBackBone8x forward on
+    four 60k-pt nuScenes-shape clouds, MeanVFE -> 12 sparse convolutions -> dense BEV map, HIP path against the CPU oracle
+    backend, <= 1e-3 (north star).  bn_train=True is what `bench.py --workload c2` runs (a fresh model in train mode under
+    no_grad); bn_train=False uses non-trivial running statistics."""
+    from oracle.cpu_backend import oracle_backend
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import build_network, load_data_to_gpu, voxelize_on_gpu
+
+    cfg = _full_cfg("second_backbone_nuscenes")
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES)
+    torch.manual_seed(0)
+    cpu_model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).train()
+    if not bn_train:
+        g = torch.Generator().manual_seed(1)
+        for m in cpu_model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.copy_(0.05 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+        _freeze_bn(cpu_model)
+    gpu_model = copy.deepcopy(cpu_model).cuda()
+    batch = ds.collate_batch([ds[i] for i in range(4)])
+    assert batch["points"].shape[0] > 200_000 and batch["batch_size"] == 4
+
+    def forward(model):
+        b = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in batch.items()}
+        load_data_to_gpu(b)
+        voxelize_on_gpu(b, ds.voxel_cfg)
+        for m in (model.vfe, model.backbone_3d, model.map_to_bev_module):
+            b = m(b)
+        return b["spatial_features"].detach().cpu(), int(b["voxel_coords"].shape[0])
+
+    with torch.no_grad():
+        with oracle_backend():
+            a, n_cpu = forward(cpu_model)
+        b, n_gpu = forward(gpu_model)
+    assert n_cpu == n_gpu and a.shape == b.shape and a.shape[0] == 4
+    rel = float((a - b).norm() / a.norm())
+    worst = float((a - b).abs().max() / a.abs().max())
+    assert rel < 1e-3 and worst < 1e-3, (rel, worst)
+    print(f"c2 bn_train={bn_train}: {n_gpu} voxels, BEV {tuple(a.shape)}, rel {rel:.2e} / max {worst:.2e}")

@@ -87,3 +87,34 @@ def test_anchor_head_losses_on_gpu_match_reference():
     from tests.test_golden_reference import check_anchor_losses
 
     check_anchor_losses("cuda")
+
+
+def test_bev_backbone_wide_on_gpu_hits_the_hand_written_kernels():
+    """a13 on the fixture that reaches them (reference base_bev_backbone.py:81-112): 32 / 64 channels, 16 x 24
+    map.  Forward 1e-4, gradients 5e-4 of the tensor's scale (no x10 on the CPU tolerances), and the C-ABI call counts show the
+    Winograd convolutions (4 stride-1 3x3 layers: forward, dgrad, wgrad) and the single-pass BatchNorm2d + ReLU were taken."""
+    from tests.helpers import abi_calls
+    from tests.test_golden_reference import check_bev_backbone_wide_scaled
+
+    with abi_calls("toda_conv3x3_fwd", "toda_conv3x3_wgrad", "toda_bn2d_fwd", "toda_bn2d_bwd") as n:
+        errs = check_bev_backbone_wide_scaled("cuda", 1e-4, 5e-4)
+    print({k: f"{v:.1e}" for k, v in errs.items()})
+    assert n["toda_conv3x3_fwd"] >= 8 and n["toda_conv3x3_wgrad"] >= 4, n       # 4 layers x (forward + dgrad), 4 wgrads
+    assert n["toda_bn2d_fwd"] >= 5 and n["toda_bn2d_bwd"] >= 5, n
+
+
+def test_center_head_wide_on_gpu_hits_the_hand_written_kernels():
+    """a14-a16 on the 64-channel head (reference center_head.py:11-45,73-80,221-272): shared conv + the fused 64 -> 5 x 64 hidden
+    layer on the Winograd kernel, the narrow output convolutions, target assignment, the fused loss and bn2d - all through the
+    C ABI, against the reference's predictions, loss terms, gradients and BN statistics."""
+    from tests.helpers import abi_calls
+    from tests.test_golden_reference import check_center_head_wide
+
+    names = ("toda_conv3x3_fwd", "toda_conv3x3_wgrad", "toda_conv3x3_narrow_fwd", "toda_conv3x3_narrow_dgrad", "toda_conv3x3_narrow_wgrad",
+             "toda_bn2d_fwd", "toda_bn2d_bwd", "toda_center_assign", "toda_center_loss_fwd", "toda_center_loss_bwd")
+    with abi_calls(*names) as n:
+        errs = check_center_head_wide("cuda", 1e-4, 5e-4)
+    print({k: f"{v:.1e}" for k, v in errs.items()})
+    assert n["toda_conv3x3_fwd"] >= 4 and n["toda_conv3x3_wgrad"] >= 2, n       # shared conv + fused hidden layer, both directions
+    for k in names[2:]:
+        assert n[k] >= 1, (k, n)

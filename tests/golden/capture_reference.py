@@ -164,33 +164,77 @@ BEV_WIDE_CFG = dict(LAYER_NUMS=[1, 2], LAYER_STRIDES=[1, 2], NUM_FILTERS=[32, 64
                     NUM_UPSAMPLE_FILTERS=[32, 32])
 
 
+RELU_MARGIN = 6e-5
+
+
+def relu_margin_probe(module):
+    """Forward hooks on every nn.ReLU of a reference module: after a forward, probe() = the smallest |input| any of them saw.
+    Why: the gradient of a network is discontinuous where a ReLU input crosses zero, so two CORRECT fp32 implementations whose
+    activations differ by rounding (Winograd F(4x4,3x3): ~5e-6 of the output scale, times the BatchNorm's 1 / std) disagree by a
+    whole gradient element wherever an input lies inside that distance of zero - with ~150 k ReLU inputs per fixture one does,
+    more often than not (first capture of these fixtures: ONE flipped mask bit of 12 288 moved the upstream gradients by up to 9e-2
+    of their maximum while every forward value agreed to 2e-6).  The wide fixtures therefore draw seeds until every ReLU input of
+    the reference's run is at least RELU_MARGIN away from zero: a well-conditioned vector, not a looser tolerance."""
+    seen = []
+
+    def hook(mod, args):
+        seen.append(float(args[0].detach().abs().min()))
+
+    handles = [m.register_forward_pre_hook(hook) for m in module.modules() if isinstance(m, torch.nn.ReLU)]
+    return (lambda: min(seen) if seen else float("inf")), (lambda: [h.remove() for h in handles])
+
+
 def cap_bev_wide(L):
     np.int = int
-    torch.manual_seed(11)
-    m = L["base_bev_backbone"].BaseBEVBackbone(EasyDict(BEV_WIDE_CFG), 32).train()
-    w_init = sd_np(m)
-    x = torch.randn(2, 32, 16, 24, requires_grad=True)
-    y = m({"spatial_features": x})["spatial_features_2d"]
+    for seed in range(11, 11 + 20000):
+        torch.manual_seed(seed)
+        m = L["base_bev_backbone"].BaseBEVBackbone(EasyDict(BEV_WIDE_CFG), 32).train()
+        w_init = sd_np(m)
+        probe, done = relu_margin_probe(m)
+        x = torch.randn(2, 32, 16, 24, requires_grad=True)
+        y = m({"spatial_features": x})["spatial_features_2d"]
+        done()
+        if probe() >= RELU_MARGIN:
+            break
+    else:
+        raise RuntimeError("no well-conditioned seed found")
+    print(f"bev_backbone_wide: seed {seed}, smallest |ReLU input| {probe():.2e}")
     after = sd_np(m)
     g = torch.randn_like(y)
     y.backward(g)
     grads = {"g." + n: p.grad.numpy() for n, p in m.named_parameters()}
     np.savez_compressed(os.path.join(OUT, "bev_backbone_wide.npz"), x=x.detach().numpy(), y=y.detach().numpy(), gy=g.numpy(),
-             gx=x.grad.numpy(), **w_init, **{"after." + k[2:]: v for k, v in after.items() if "running" in k}, **grads)
+             gx=x.grad.numpy(), seed=np.int64(seed), relu_margin=np.float64(probe()), **w_init,
+             **{"after." + k[2:]: v for k, v in after.items() if "running" in k}, **grads)
 
 
 def cap_center_head_wide(L):
     CenterHead = L["center_head"].CenterHead
-    rng = np.random.default_rng(12)
     pc_range = np.array([-6.4, -6.4, -2, 6.4, 6.4, 4], np.float32)
     vs = [0.1, 0.1, 0.15]
     cfg = EasyDict(HEAD_CFG)
     cfg.SHARED_CONV_CHANNEL = 64
-    torch.manual_seed(13)
+    gt = make_gt(np.random.default_rng(12), 2, 9, -7.0, 7.0)
+    for seed in range(13, 13 + 100000):
+        torch.manual_seed(seed)
+        head = CenterHead(cfg, 32, 3, CLASSES, np.array([128, 128, 40]), pc_range, vs, predict_boxes_when_training=False).train()
+        w0 = sd_np(head)
+        probe, done = relu_margin_probe(head)
+        x = torch.randn(2, 32, 16, 16, requires_grad=True)
+        data = {"spatial_features_2d": x, "gt_boxes": torch.from_numpy(gt.copy()), "batch_size": 2}
+        with torch.no_grad():
+            head.shared_conv(x)
+            for h in head.heads_list:
+                h(head.shared_conv(x))
+        done()
+        if probe() >= RELU_MARGIN:
+            break
+    else:
+        raise RuntimeError("no well-conditioned seed found")
+    print(f"center_head_wide: seed {seed}, smallest |ReLU input| {probe():.2e}")
+    torch.manual_seed(seed)
     head = CenterHead(cfg, 32, 3, CLASSES, np.array([128, 128, 40]), pc_range, vs, predict_boxes_when_training=False).train()
-    w0 = sd_np(head)
     x = torch.randn(2, 32, 16, 16, requires_grad=True)
-    gt = make_gt(rng, 2, 9, -7.0, 7.0)
     data = {"spatial_features_2d": x, "gt_boxes": torch.from_numpy(gt.copy()), "batch_size": 2}
     head(data)
     td = head.forward_ret_dict["target_dicts"]
@@ -201,7 +245,8 @@ def cap_center_head_wide(L):
     np.savez_compressed(os.path.join(OUT, "center_head_wide.npz"), x=x.detach().numpy(), gt=gt, pc_range=pc_range, voxel_size=np.array(vs),
              heatmap=td["heatmaps"][0].numpy(), target_boxes=td["target_boxes"][0].numpy(), inds=td["inds"][0].numpy(),
              masks=td["masks"][0].numpy(), loss=np.float32(loss.item()), hm_loss=np.float32(tb["hm_loss_head_0"]),
-             loc_loss=np.float32(tb["loc_loss_head_0"]), gx=x.grad.numpy(), **w0, **{"pred." + k: v for k, v in preds.items()},
+             loc_loss=np.float32(tb["loc_loss_head_0"]), gx=x.grad.numpy(), seed=np.int64(seed), relu_margin=np.float64(probe()),
+             **w0, **{"pred." + k: v for k, v in preds.items()},
              **{"after." + k[2:]: v for k, v in after.items() if "running" in k},
              **{"g." + n: p.grad.numpy() for n, p in head.named_parameters() if p.grad is not None})
 

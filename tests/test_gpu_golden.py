@@ -91,13 +91,14 @@ def test_anchor_head_losses_on_gpu_match_reference():
 
 def test_bev_backbone_wide_on_gpu_hits_the_hand_written_kernels():
     """a13 on the fixture that reaches them (reference base_bev_backbone.py:81-112): 32 / 64 channels, 16 x 24
-    map.  Forward 1e-4, gradients 5e-4 of the tensor's scale (no x10 on the CPU tolerances), and the C-ABI call counts show the
+    map.  Forward 2e-5, gradients 5e-5 of the tensor's scale (measured: <= 3e-6 everywhere; the fixture keeps every ReLU input
+    6e-5 away from zero, see capture_reference.relu_margin_probe), and the C-ABI call counts show the
     Winograd convolutions (4 stride-1 3x3 layers: forward, dgrad, wgrad) and the single-pass BatchNorm2d + ReLU were taken."""
     from tests.helpers import abi_calls
     from tests.test_golden_reference import check_bev_backbone_wide_scaled
 
     with abi_calls("toda_conv3x3_fwd", "toda_conv3x3_wgrad", "toda_bn2d_fwd", "toda_bn2d_bwd") as n:
-        errs = check_bev_backbone_wide_scaled("cuda", 1e-4, 5e-4)
+        errs = check_bev_backbone_wide_scaled("cuda", 2e-5, 5e-5)
     print({k: f"{v:.1e}" for k, v in errs.items()})
     assert n["toda_conv3x3_fwd"] >= 8 and n["toda_conv3x3_wgrad"] >= 4, n       # 4 layers x (forward + dgrad), 4 wgrads
     assert n["toda_bn2d_fwd"] >= 5 and n["toda_bn2d_bwd"] >= 5, n
@@ -113,7 +114,7 @@ def test_center_head_wide_on_gpu_hits_the_hand_written_kernels():
     names = ("toda_conv3x3_fwd", "toda_conv3x3_wgrad", "toda_conv3x3_narrow_fwd", "toda_conv3x3_narrow_dgrad", "toda_conv3x3_narrow_wgrad",
              "toda_bn2d_fwd", "toda_bn2d_bwd", "toda_center_assign", "toda_center_loss_fwd", "toda_center_loss_bwd")
     with abi_calls(*names) as n:
-        errs = check_center_head_wide("cuda", 1e-4, 5e-4)
+        errs = check_center_head_wide("cuda", 2e-5, 5e-5)
     print({k: f"{v:.1e}" for k, v in errs.items()})
     assert n["toda_conv3x3_fwd"] >= 4 and n["toda_conv3x3_wgrad"] >= 2, n       # shared conv + fused hidden layer, both directions
     for k in names[2:]:

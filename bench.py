@@ -130,6 +130,16 @@ class KernelTimer:
             return self._orig_classed(feat, wp, nbr, c_produce, *rest)
 
         ops.gather_gemm_classed = labelled_classed
+        self._orig_halo = ops.gather_gemm_halo              # SubM layers on the LDS-staged halo kernel (same dispatch-stamped launches)
+        self.halo_tables = set()
+
+        def labelled_halo(feat, wp, nbr, c_produce, *rest, **kw):
+            if self._enabled and len(self.records) < self.CAPACITY:
+                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+                self.halo_tables.add((nbr.shape[1], nbr.shape[0], feat.shape[1], c_produce))
+            return self._orig_halo(feat, wp, nbr, c_produce, *rest, **kw)
+
+        ops.gather_gemm_halo = labelled_halo
 
     @property
     def enabled(self):

@@ -171,6 +171,39 @@ int toda_spconv_gather_gemm_classed(const float* in, int n_in, int c_gather, con
                                     int k_vol, int c_produce, const float* bias, float* out, const int32_t* order,
                                     const unsigned char* cls_sorted, const int32_t* ksize_host, const int32_t* stride_host,
                                     const int32_t* padding_host, void* stream);
+/* ------------------------------------------------------------------------
+ * LDS-staged halo tiles for submanifold layers (north star: "gather -> MFMA-GEMM ->
+ * scatter sparse conv with ... LDS-staged feature tiles").  Replaces, for the SubM
+ * layers whose channel count has a halo geometry (64 -> 64, 32 -> 32), the per-offset
+ * row gathers of toda_spconv_gather_gemm* in the forward and data-gradient passes of
+ * spconv SubMConv3d (pcdet/models/backbones_3d/spconv_backbone.py:21-25,54-64,
+ * 128-180; backward through autograd, tools/train_utils/train_utils.py:55).
+ *
+ *   toda_halo_supported            1 when (c_gather, c_produce, k_vol) has a halo kernel
+ *   toda_halo_plan_bytes           size of the plan buffer for n rows
+ *   toda_halo_plan_workspace_bytes scratch of the plan builder (Morton bitmap of the lattice)
+ *   toda_halo_plan_build           from the level's coordinates and its SubM neighbour table
+ *                                  nbr[k_vol][n]: output rows regrouped into blocks that are
+ *                                  compact in space (Morton order over (y, x), z innermost), each
+ *                                  block's unique neighbour rows and 16-bit local ids.  One plan
+ *                                  serves every SubM layer (forward and dgrad) on that table.
+ *                                  Deterministic; results of the convolution do not depend on it.
+ *   toda_spconv_gather_gemm_halo   out[n][c] = conv(in; wp, table) with the block's unique input
+ *                                  rows staged in LDS (32 channels of them at a time); equal to
+ *                                  toda_spconv_gather_gemm to fp32 rounding (64 channels sum in two
+ *                                  passes of 32), run-to-run deterministic.  sums (nullable,
+ *                                  >= toda_spconv_gather_gemm_stats_doubles): BatchNorm moments of
+ *                                  the output as toda_spconv_gather_gemm_stats.
+ * ---------------------------------------------------------------------- */
+int toda_halo_supported(int c_gather, int c_produce, int k_vol);
+size_t toda_halo_plan_bytes(int n, int k_vol, int c_gather);
+size_t toda_halo_plan_workspace_bytes(int n, int batch, const int32_t* shape_host);
+int toda_halo_plan_build(const int32_t* indices, int n, int batch, const int32_t* shape_host, const int32_t* nbr,
+                         int k_vol, int c_gather, void* plan, size_t plan_bytes, void* ws, size_t ws_bytes, void* stream);
+int toda_spconv_gather_gemm_halo(const float* in, int n, int c_gather, const float* wp, const int32_t* nbr, int k_vol,
+                                 int c_produce, const float* bias, float* out, const void* plan, size_t plan_bytes,
+                                 double* sums, size_t sums_doubles, void* stream);
+
 /* dw[co][k][ci] = sum_o in[nbr[k*n_out+o], ci] * dout[o, co] */
 size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout);
 int toda_spconv_wgrad(const float* in, int n_in, const float* dout, const int32_t* nbr,

@@ -1011,6 +1011,350 @@ gather_gemm_stage_kernel(const float* __restrict__ in, int n_in, int cg, const f
     }
 }
 
+// ---- LDS-staged halo tiles (submanifold layers) ----------------------------------------------------------------------------
+// Every variant above re-gathers a block's 256-byte input rows from L1 / L2 once PER OFFSET (27 times per row block; the waves
+// wait on vector memory in half of their cycles, ~750 cycles per gather instruction - profiles/r02_pmc_stall_gather_gemm.json).
+// Here a workgroup owns R = 128 output rows that are compact in space (Morton order, halo_plan.hip): the union of their 27
+// neighbour sets is 220 rows on average on the C3 stride-4 level (128 x 16 pair references), so the block's unique input rows are
+// loaded ONCE into LDS (<= UMAX rows; rows swizzled by their local id so that the fragment reads spread over the banks) and all 27
+// offsets' A fragments come from ds_read_b128 through 16-bit local ids - the offset loop issues no vector-memory instruction
+// except the next weight slice.  8 waves x 16 rows; weight slices in a 3-deep LDS ring (the slice of offset k + 2 is fetched
+// into registers at the start of offset k and written after its MFMAs: the slice a wave reads first after a barrier has been
+// in LDS for a whole step); local ids two offsets ahead, A fragments one offset ahead (two register sets, loop unrolled by two:
+// no copies).  A (tile, offset) with a neighbour that did not fit (HALO_SPILL) takes that offset from the global table exactly
+// as gather_gemm_lds_kernel does: same operands, same MFMA order, same bits.
+constexpr unsigned short HALO_NONE = 0xFFFFu, HALO_SPILL = 0xFFFEu;
+struct HaloGeomK {
+    int R, UMAX;
+};
+static inline bool halo_geom_k(int c_gather, HaloGeomK* g) {      // keep in sync with halo_plan.hip
+    if (c_gather == 64) {
+        *g = HaloGeomK{128, 320};
+        return true;
+    }
+    if (c_gather == 32) {
+        *g = HaloGeomK{128, 320};
+        return true;
+    }
+    return false;
+}
+
+// Two measured dead ends shaped this kernel (389.5 k-row 64 -> 64 level, per-offset kernel 0.58-0.60 ms):
+//   * whole 256-byte rows in LDS + the weight slices in an LDS ring with a barrier per offset = ONE 512-thread workgroup per CU:
+//     0.75 ms.  A wave that waits at a barrier has no other workgroup's waves to give its SIMD to.
+//   * the same without barriers, every wave streaming its B fragments from L1 / L2: 0.83-0.89 ms - 16 KiB of weights per
+//     (16-row tile, offset) is 7 GB per launch through the CUs' 64 B/clk L1 path.
+// So: weights stay in LDS, and the workgroup is made small enough for TWO per CU by staging HALF rows.  The gathered channels are
+// worked off in passes of QP = 2 channel groups (32 channels = 128 bytes per row): pass p stages channels [32 p, 32 p + 32) of
+// the block's unique rows (41 KiB), walks the K offsets with the matching half of each weight slice (8 KiB, 3-deep ring) and
+// leaves its sums in the accumulators; the next pass refills the rows with the other half.  77 KiB per workgroup, two
+// workgroups = 16 waves per CU with independent barriers.
+template <int Q, int NT, int QP, int R, int UMAX, int KMAX>
+__global__ void __launch_bounds__(R * 4, 4)
+gather_gemm_halo_kernel(const float* __restrict__ in, int n, int cg, const float* __restrict__ wp, const int* __restrict__ nbr, int K, int cp,
+                        const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order_all,
+                        const int* __restrict__ urows_all, const unsigned short* __restrict__ lids_all, double* __restrict__ stats, const int ablate) {
+    constexpr int WAVES = R / 16, BLK = WAVES * 64;
+    constexpr int PASSES = Q / QP;
+    constexpr int ROW4 = QP * 4;                        // float4 per staged (partial) row
+    constexpr int SLICE = QP * NT * 64;                 // float4 of weights per (offset, pass)
+    constexpr int W_PER = (SLICE + BLK - 1) / BLK;
+    constexpr int ROWS_PER_INSTR = 64 / ROW4;           // rows one wave instruction moves (16-byte pieces)
+    constexpr int FILL_ITERS = UMAX / (WAVES * ROWS_PER_INSTR);
+    static_assert(Q % QP == 0 && UMAX % (WAVES * ROWS_PER_INSTR) == 0, "UMAX must be a whole number of fill rounds");
+    static_assert((KMAX * R) % 8 == 0, "local ids are copied 16 bytes at a time");
+    __shared__ f32x4 halo[(UMAX + 1) * ROW4];           // row UMAX = zeros ("no neighbour")
+    __shared__ f32x4 wl[3][SLICE];
+    __shared__ __attribute__((aligned(16))) unsigned short lid_s[KMAX * R];
+    __shared__ int s_spill;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_spill = 0;
+    __syncthreads();
+    const int r = lane & 15, g = lane >> 4;
+    const int blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n * (unsigned)cg * 4u);
+    const int total = PASSES * K;                       // (pass, offset) steps = barriers every wave passes
+    const int* __restrict__ urows = urows_all + (size_t)blk * UMAX;
+    bool saw_spill = false;
+    auto fill = [&](int p) {
+        const int sub = lane / ROW4, c = lane % ROW4;
+        f32x4 v[FILL_ITERS];
+        int jj[FILL_ITERS];
+#pragma unroll
+        for (int it = 0; it < FILL_ITERS; ++it) {
+            const int j = (it * WAVES + wave) * ROWS_PER_INSTR + sub;
+            jj[it] = j;
+            const int u = urows[j];
+            v[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  in_rsrc, u >= 0 ? (unsigned)u * (unsigned)cg * 4u + (unsigned)(p * ROW4 + c) * 16u : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int it = 0; it < FILL_ITERS; ++it) halo[jj[it] * ROW4 + (c ^ (jj[it] & (ROW4 - 1)))] = v[it];
+    };
+    {
+        // (integer vectors: with the ids moved as float4 and inspected through bit casts hipcc tested only the first dword)
+        const u32x4* __restrict__ l4 = reinterpret_cast<const u32x4*>(lids_all + (size_t)blk * K * R);
+        u32x4* ls4 = reinterpret_cast<u32x4*>(lid_s);
+        for (int e = tid; e < K * R / 8; e += BLK) {
+            const u32x4 v = l4[e];
+            ls4[e] = v;
+            const unsigned lo_hit = (unsigned)((v.x & 0xFFFFu) == HALO_SPILL) | (unsigned)((v.y & 0xFFFFu) == HALO_SPILL) |
+                                    (unsigned)((v.z & 0xFFFFu) == HALO_SPILL) | (unsigned)((v.w & 0xFFFFu) == HALO_SPILL);
+            const unsigned hi_hit = (unsigned)((v.x >> 16) == HALO_SPILL) | (unsigned)((v.y >> 16) == HALO_SPILL) |
+                                    (unsigned)((v.z >> 16) == HALO_SPILL) | (unsigned)((v.w >> 16) == HALO_SPILL);
+            saw_spill = saw_spill || (lo_hit | hi_hit) != 0u;
+        }
+        if (tid < ROW4) halo[UMAX * ROW4 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int myrow = order_all[(size_t)blk * R + 16 * wave + r];        // -1 on the padding of the last block
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) {
+        float b = 0.0f;
+        if (bias && NT * r + nn < cp) b = bias[NT * r + nn];
+        acc[nn] = f32x4{b, b, b, b};
+    }
+    const unsigned short* my_lids = lid_s + 16 * wave + r;
+    auto lid_at = [&](int k) -> unsigned { return myrow < 0 ? (unsigned)HALO_NONE : (unsigned)my_lids[(k < K ? k : K - 1) * R]; };
+    // A block with a neighbour that did not fit (more than UMAX unique rows: dense, deep lattices - 57 ids of 10.5 M on the C3
+    // stride-4 level) is worked off from the global table and the global weights, in the SAME (pass, offset, channel group) order,
+    // so a row's bits do not depend on which path its block took.  A separate loop on purpose: merged into the LDS loop, the
+    // buffer loads of this path and the LDS reads of that one share destination registers and hipcc then waits for every
+    // outstanding vector-memory load (the weight slice in flight) in front of each fragment read.
+    if (__any(saw_spill) && lane == 0) s_spill = 1;      // (benign race: every writer stores the same value)
+    __syncthreads();                                      // publishes the flag and the local ids
+    const bool block_spills = s_spill != 0 || (ablate & 32);      // (ablate: timing experiments only)
+    if (block_spills) {
+        for (int p = 0; p < PASSES; ++p)
+            for (int k = 0; k < K; ++k) {
+                const int src = myrow >= 0 ? nbr[(size_t)k * n + myrow] : -1;
+                if (!__any(src >= 0)) continue;
+                f32x4 a[QP];
+#pragma unroll
+                for (int q = 0; q < QP; ++q)
+                    a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         in_rsrc, src >= 0 ? (unsigned)src * (unsigned)cg * 4u + (unsigned)(16 * (p * QP + q) + 4 * g) * 4u : OOB, 0, 0));
+                const f32x4* __restrict__ wk = wp4 + ((size_t)k * Q + (size_t)p * QP) * NT * 64 + lane;
+#pragma unroll
+                for (int q = 0; q < QP; ++q) {
+                    f32x4 b[NT];
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn) b[nn] = wk[(q * NT + nn) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][j], b[nn][j], acc[nn], 0, 0, 0);
+                }
+            }
+    } else {
+        // Weight ring, 3 LDS buffers + 2 register stages: at the START of step s (every wave is past the barrier of step s - 1, so
+        // the buffer step s - 1 read is free) the slice of step s + 2 goes from its register stage to LDS and the slice of step
+        // s + 4 is requested into that stage - two whole steps of cover for the L2 round trip (requested and written inside one
+        // step it was exposed: -0.06 ms in the ablation).  Stages alternate with the step parity (K odd: their contents are swapped between
+        // passes).  No division or modulo in the loop: cursors.
+        int buf = 0, s = 0;                                 // buffer holding the slice of step s
+        const size_t k_stride = (size_t)Q * NT * 64;
+        int ld_k = 0, ld_p = 0;                             // (offset, pass) of the slice requested next
+        const f32x4* ld_ptr = wp4;
+        auto ld_advance = [&]() {
+            if (ld_k + 1 < K) {
+                ++ld_k;
+                ld_ptr += k_stride;
+            } else if (ld_p + 1 < PASSES) {
+                ld_k = 0;
+                ++ld_p;
+                ld_ptr = wp4 + (size_t)ld_p * QP * NT * 64;
+            }                                               // past the last slice: keep re-requesting it (never written)
+        };
+        f32x4 stA[W_PER], stB[W_PER];
+        {   // slices 0 and 1 straight to LDS, 2 and 3 into the stages
+#pragma unroll
+            for (int t = 0; t < W_PER; ++t) {
+                const int e = t * BLK + tid;
+                if (SLICE % BLK == 0 || e < SLICE) wl[0][e] = ld_ptr[e];
+            }
+            ld_advance();
+#pragma unroll
+            for (int t = 0; t < W_PER; ++t) {
+                const int e = t * BLK + tid;
+                if (SLICE % BLK == 0 || e < SLICE) wl[1][e] = ld_ptr[e];
+            }
+            ld_advance();
+#pragma unroll
+            for (int t = 0; t < W_PER; ++t) {
+                const int e = t * BLK + tid;
+                if (SLICE % BLK == 0 || e < SLICE) stA[t] = ld_ptr[e];
+            }
+            ld_advance();
+#pragma unroll
+            for (int t = 0; t < W_PER; ++t) {
+                const int e = t * BLK + tid;
+                if (SLICE % BLK == 0 || e < SLICE) stB[t] = ld_ptr[e];
+            }
+            ld_advance();
+        }
+        fill(0);
+        __syncthreads();
+        auto load_a = [&](unsigned lid, f32x4 (&a)[QP]) {
+            const unsigned row = lid == HALO_NONE ? (unsigned)UMAX : lid;
+            const f32x4* base = halo + row * ROW4;
+            const unsigned sw = row & (ROW4 - 1);
+#pragma unroll
+            for (int q = 0; q < QP; ++q) a[q] = base[(unsigned)(4 * q + g) ^ sw];
+        };
+        // one step: cur = operands of offset k (already loaded), nxt = the set the fragments of offset k + 1 are loaded into,
+        // st = the register stage of this step's parity
+        // B fragments of the NEXT step's first channel group are read before the barrier that ends a step (their slice has been in
+        // LDS since the step before), so that the MFMAs behind a barrier start at once instead of behind an LDS round trip that
+        // all waves of the workgroup would take together.
+        f32x4 b_first[NT];
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) b_first[nn] = wl[0][nn * 64 + lane];
+        auto step = [&](bool more, unsigned lid_cur, const f32x4 (&a_cur)[QP], unsigned lid_nxt, f32x4 (&a_nxt)[QP], f32x4 (&st)[W_PER]) {
+            const bool hit = __any(lid_cur != HALO_NONE);      // wave-uniform: some row of the tile has a neighbour at this offset
+            f32x4 b[NT];
+            if (hit) {
+                if (QP > 1) {
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn) b[nn] = wl[buf][(NT + nn) * 64 + lane];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][j], b_first[nn][j], acc[nn], 0, 0, 0);
+            }
+            {
+                const int wb = buf == 0 ? 2 : buf - 1;      // buffer of step s + 2 = the one step s - 1 read
+                if (s + 2 < total) {
+#pragma unroll
+                    for (int t = 0; t < W_PER; ++t) {
+                        const int e = t * BLK + tid;
+                        if (SLICE % BLK == 0 || e < SLICE) wl[wb][e] = st[t];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < W_PER; ++t) {
+                    const int e = t * BLK + tid;
+                    if (SLICE % BLK == 0 || e < SLICE) st[t] = ld_ptr[e];
+                }
+                ld_advance();
+            }
+            if (more) load_a(lid_nxt, a_nxt);
+            if (hit) {
+#pragma unroll
+                for (int q = 1; q < QP; ++q) {
+                    if (q > 1) {
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) b[nn] = wl[buf][(q * NT + nn) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) acc[nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[q][j], b[nn][j], acc[nn], 0, 0, 0);
+                }
+            }
+            buf = buf == 2 ? 0 : buf + 1;
+            ++s;
+            if (s < total) {
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) b_first[nn] = wl[buf][nn * 64 + lane];
+            }
+            __syncthreads();
+        };
+        auto run_pass = [&](int p, f32x4 (&stE)[W_PER], f32x4 (&stO)[W_PER]) {      // stE / stO: stages of the even / odd offsets of this pass
+            f32x4 aA[QP], aB[QP];
+            unsigned l0 = lid_at(0), l1 = lid_at(1), l2, l3;
+            load_a(l0, aA);
+            int k = 0;
+            for (; k + 3 < K; k += 2) {            // all but the last one or two offsets
+                l2 = lid_at(k + 2);
+                step(true, l0, aA, l1, aB, stE);
+                l3 = lid_at(k + 3);
+                step(true, l1, aB, l2, aA, stO);
+                l0 = l2;
+                l1 = l3;
+            }
+            if (k + 2 < K) {                        // three offsets left (K odd)
+                l2 = lid_at(k + 2);
+                step(true, l0, aA, l1, aB, stE);
+                step(true, l1, aB, l2, aA, stO);
+                step(false, l2, aA, l2, aB, stE);
+            } else if (k + 1 < K) {                 // two left (K even)
+                step(true, l0, aA, l1, aB, stE);
+                step(false, l1, aB, l1, aA, stO);
+            } else {
+                step(false, l0, aA, l0, aB, stE);
+            }
+            if (p + 1 < PASSES) {                   // (every wave is past the barrier of the pass's last offset: nobody reads the rows)
+                fill(p + 1);
+                __syncthreads();
+            }
+        };
+        for (int p = 0; p < PASSES; ++p) {
+            run_pass(p, stA, stB);
+            if ((K & 1) && p + 1 < PASSES) {       // odd K: the next pass starts on the other parity - swap the stages' contents
+#pragma unroll
+                for (int t = 0; t < W_PER; ++t) {
+                    const f32x4 tmp = stA[t];
+                    stA[t] = stB[t];
+                    stB[t] = tmp;
+                }
+            }
+        }
+    }
+
+    // BatchNorm moments of the block's rows (see gather_gemm_lds_kernel): partial sums [2 cp][gridDim.x] behind the results
+    if (stats) {
+        __shared__ float st_sh[WAVES][2][16 * NT];
+        float sm[NT], sq[NT];
+        int prow[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) prow[reg] = __shfl(myrow, 4 * g + reg, 64);
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            sm[nn] = sq[nn] = 0.0f;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                if (prow[reg] >= 0) {
+                    const float v = acc[nn][reg];
+                    sm[nn] += v;
+                    sq[nn] += v * v;
+                }
+            sm[nn] += __shfl_xor(sm[nn], 16, 64);
+            sq[nn] += __shfl_xor(sq[nn], 16, 64);
+            sm[nn] += __shfl_xor(sm[nn], 32, 64);
+            sq[nn] += __shfl_xor(sq[nn], 32, 64);
+            if (g == 0) {
+                st_sh[wave][0][NT * r + nn] = sm[nn];
+                st_sh[wave][1][NT * r + nn] = sq[nn];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * cp) {
+            const int qq = tid / cp, ch = tid - qq * cp;
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) a += (double)st_sh[w][qq][ch];
+            stats[2 * cp + (size_t)(qq * cp + ch) * gridDim.x + blk] = a;
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int row = __shfl(myrow, 4 * g + reg, 64);
+        if (row < 0) continue;
+        float* dst = out + (size_t)row * cp + NT * r;
+        if constexpr (NT == 2) {
+            *reinterpret_cast<float2*>(dst) = make_float2(acc[0][reg], acc[1][reg]);
+        } else {
+#pragma unroll
+            for (int nn = 0; nn < NT; nn += 4)
+                *reinterpret_cast<f32x4*>(dst + nn) = f32x4{acc[nn][reg], acc[nn + 1][reg], acc[nn + 2][reg], acc[nn + 3][reg]};
+        }
+    }
+}
+
 // wgrad: dW[co][k][ci] = sum_o in[nbr[k][o]][ci] * dout[o][co].  Grid (row chunk, offset, channel
 // sub-block).  The contraction runs over PAIRS, not rows: every wave reads 64 neighbour ids at a
 // time (one coalesced 256-byte load), compacts the valid (in,out) pairs into a small LDS queue
@@ -1775,6 +2119,41 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
                                        int n_out, int k_vol, int c_produce, const float* bias, float* out,
                                        void* stream) {
     return toda_spconv_gather_gemm_ordered(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, nullptr, stream);
+}
+
+// SubM gather-GEMM over a halo plan (toda_halo_plan_build): forward, and - with the transposed / offset-reversed packed operand - the
+// data gradient of the same table.  sums (nullable): BatchNorm moments from the epilogue, as toda_spconv_gather_gemm_stats.
+extern "C" int toda_spconv_gather_gemm_halo(const float* in, int n, int c_gather, const float* wp, const int32_t* nbr, int k_vol, int c_produce,
+                                            const float* bias, float* out, const void* plan, size_t plan_bytes, double* sums, size_t sums_doubles,
+                                            void* stream) {
+    HaloGeomK hg;
+    TODA_CHECK_ARG(c_gather == c_produce && halo_geom_k(c_gather, &hg) && k_vol >= 2 && k_vol <= 27,
+                   "gather_gemm_halo: unsupported shape (%d -> %d channels, %d offsets)", c_gather, c_produce, k_vol);
+    TODA_CHECK_ARG(n >= 0, "gather_gemm_halo: n < 0");
+    if (n == 0) return TODA_OK;
+    TODA_CHECK_ARG(in && wp && nbr && out && plan, "gather_gemm_halo: null pointer");
+    TODA_CHECK_ARG((unsigned long long)n * c_gather * 4ull < 0xFFFFFFF0ull, "gather_gemm_halo: feature table must be < 4 GiB");
+    const size_t nb = (size_t)cdiv(n, hg.R);
+    const size_t o_urows = align_up(nb * hg.R * 4, 256), o_lids = o_urows + align_up(nb * hg.UMAX * 4, 256);
+    TODA_CHECK_ARG(plan_bytes >= o_lids + nb * k_vol * hg.R * 2, "gather_gemm_halo: plan buffer too small");
+    TODA_CHECK_ARG(sums == nullptr || sums_doubles >= (size_t)2 * c_produce * (1 + nb), "gather_gemm_halo: statistics buffer too small");
+    const int32_t* order = (const int32_t*)plan;
+    const int32_t* urows = (const int32_t*)((const char*)plan + o_urows);
+    const unsigned short* lids = (const unsigned short*)((const char*)plan + o_lids);
+    hipStream_t s = (hipStream_t)stream;
+    static const int ablate = getenv("TODA_HALO_ABLATE") ? atoi(getenv("TODA_HALO_ABLATE")) : 0;      // timing experiments only (wrong results)
+    if (c_gather == 64)
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_halo_kernel<4, 4, 2, 128, 320, 27>), dim3((unsigned)nb), dim3(512), 0, s, in, n, c_gather, wp, nbr, k_vol,
+                  c_produce, bias, out, order, urows, lids, sums, ablate);
+    else
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_halo_kernel<2, 2, 2, 128, 320, 27>), dim3((unsigned)nb), dim3(512), 0, s, in, n, c_gather, wp, nbr, k_vol,
+                  c_produce, bias, out, order, urows, lids, sums, ablate);
+    TODA_LAUNCH_CHECK();
+    if (sums) {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c_produce), dim3(256), 0, s, sums, (int)nb, 2 * c_produce);
+        TODA_LAUNCH_CHECK();
+    }
+    return TODA_OK;
 }
 
 extern "C" size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout) {

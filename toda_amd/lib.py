@@ -39,6 +39,11 @@ SIGNATURES = {
     "toda_spconv_gather_gemm_stats_supported": (_i, [_i, _i]),
     "toda_spconv_gather_gemm_stats_doubles": (_sz, [_i, _i]),
     "toda_spconv_gather_gemm_stats": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "toda_halo_supported": (_i, [_i, _i, _i]),
+    "toda_halo_plan_bytes": (_sz, [_i, _i, _i]),
+    "toda_halo_plan_workspace_bytes": (_sz, [_i, _i, _vp]),
+    "toda_halo_plan_build": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
+    "toda_spconv_gather_gemm_halo": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "toda_spconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "toda_spconv_wgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_sparse_to_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -22,6 +22,7 @@ def grid_size_xyz(pc_range, voxel_size):
 
 
 # ----------------------------------------------------------------------------- voxelisation
+import os as _os_early
 import time as _time
 
 _COUNT_PINNED = {}
@@ -169,6 +170,7 @@ class Rulebook:
         self._order = {}
         self.in_indices = None    # strided conv: coordinates of its input sites (rows of the data-gradient table)
         self._class_order = None
+        self.halo = {}            # SubM: channel count -> halo plan (build_halo_plan), shared by forward and dgrad
 
     def order_for(self, nbr):
         """Mask-sorted visiting order of `nbr`'s rows (built once per table, reused by every conv and dgrad on it).
@@ -323,6 +325,9 @@ def build_index_plan(indices, batch, shape, steps, while_waiting=None):
                                          grid_index=cur["gi"])
             cur["gi"] = gi
             out[st["key"]] = {"kind": "subm", "rb": rb, "n_in": cur["n"]}
+            for ch in st.get("halo_channels", ()):      # layers on this table that take the LDS-staged halo kernel
+                if cur["n"] >= HALO_MIN_ROWS and halo_supported(ch, ch, rb.k_vol):
+                    build_halo_plan(rb, cur["idx"], batch, cur["shape"], ch)
         else:
             nxt = levels[li + 1]
             ks, sd, pd = _triple(st["ksize"]), _triple(st["stride"]), _triple(st["padding"])
@@ -434,6 +439,54 @@ def gather_gemm_classed(feat, wp, nbr, c_produce, order, cls_sorted, ksize, stri
     return out
 
 
+# LDS-staged halo tiles for the SubM layers: OPT-IN.  Measured on the C3 levels (profiles/r03_halo_prototype.md): HBM traffic of the
+# dominant 64 -> 64 launch 2.10x -> 0.98x the algorithmic bytes and 0.59 ms against 0.60 in isolation, but inside the training step the
+# per-offset kernel is the faster one (0.58 against 0.62 ms; 18.1 against 18.4-18.5 ms per step with the plan builder on the side stream).
+HALO = _os_early.environ.get("TODA_HALO", "0") == "1"
+HALO_MIN_ROWS = int(_os_early.environ.get("TODA_HALO_MIN_ROWS", "32768"))
+
+
+def halo_supported(c_gather, c_produce, k_vol):
+    return HALO and bool(L.load().toda_halo_supported(int(c_gather), int(c_produce), int(k_vol)))
+
+
+def build_halo_plan(rb, indices, batch, shape, channels):
+    """Halo plan of a SubM rulebook for layers with `channels` in and out (toda_halo_plan_build): Morton-ordered row blocks,
+    each block's unique neighbour rows and 16-bit local ids.  Cached on the rulebook; one plan serves every SubM layer on the
+    table, forward and data gradient."""
+    if channels in rb.halo:
+        return rb.halo[channels]
+    lib = L.load()
+    n, K = rb.nbr_fwd.shape[1], rb.nbr_fwd.shape[0]
+    dev = rb.nbr_fwd.device
+    nbytes = lib.toda_halo_plan_bytes(n, K, int(channels))
+    sh = L.host_i32([int(v) for v in shape])
+    ws_bytes = lib.toda_halo_plan_workspace_bytes(n, int(batch), L.hptr(sh))
+    plan = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
+    rc = lib.toda_halo_plan_build(L.ptr(indices.contiguous()), n, int(batch), L.hptr(sh), L.ptr(rb.nbr_fwd), K, int(channels), L.ptr(plan), nbytes,
+                                  L.ptr(ws), ws_bytes, L.stream())
+    L.check(rc, "toda_halo_plan_build")
+    rb.halo[channels] = plan
+    return plan
+
+
+def gather_gemm_halo(feat, wp, nbr, c_produce, plan, bias=None, want_stats=False):
+    """SubM gather-GEMM with the block's unique input rows staged once in LDS (toda_spconv_gather_gemm_halo); bit-identical to
+    gather_gemm.  want_stats: also the BatchNorm moments of the output, as gather_gemm_with_stats."""
+    lib = L.load()
+    K, n = nbr.shape
+    out = torch.empty((n, c_produce), dtype=torch.float32, device=feat.device)
+    sums, nd = None, 0
+    if want_stats:
+        nd = lib.toda_spconv_gather_gemm_stats_doubles(n, c_produce)
+        sums = torch.empty((nd,), dtype=torch.float64, device=feat.device)
+    rc = lib.toda_spconv_gather_gemm_halo(L.ptr(feat), n, feat.shape[1], L.ptr(wp), L.ptr(nbr), K, c_produce, L.ptr(bias), L.ptr(out),
+                                          L.ptr(plan), plan.numel(), L.ptr(sums), nd, L.stream())
+    L.check(rc, "toda_spconv_gather_gemm_halo")
+    return (out, sums) if want_stats else out
+
+
 def wgrad(feat, dout, nbr, wshape):
     lib = L.load()
     K, n_out = nbr.shape
@@ -479,10 +532,16 @@ class _SparseConv(torch.autograd.Function):
         if wp_fwd is None:
             wp_fwd = pack_weight(weight, False, False)
         sums = None
-        if want_stats:
+        plan = rb.halo.get(weight.shape[-1]) if (rb.kind == "subm" and weight.shape[0] == weight.shape[-1] and features.shape[0] == rb.n_out) else None
+        if plan is not None and want_stats:
+            out, sums = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias, True)
+        elif plan is not None:
+            out = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias)
+        elif want_stats:
             out, sums = gather_gemm_with_stats(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
         else:
             out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, order=rb.order_for(rb.nbr_fwd))
+        ctx.halo_plan = plan
         ctx.save_for_backward(features, weight)
         ctx.rb = rb
         ctx.wp_bwd = wp_bwd          # the dgrad operand when the module packed it with the rest of the backbone
@@ -513,7 +572,9 @@ class _SparseConv(torch.autograd.Function):
         if need_d:
             wp_t = ctx.wp_bwd if ctx.wp_bwd is not None else pack_weight(weight, True, rb.flip_bwd)
             co = rb.class_order()
-            if co is not None:
+            if ctx.halo_plan is not None:      # SubM: the forward table with the offsets reversed in wp_t - the same plan
+                gfeat = gather_gemm_halo(gout, wp_t, rb.nbr_bwd, weight.shape[-1], ctx.halo_plan)
+            elif co is not None:
                 gfeat = gather_gemm_classed(gout, wp_t, rb.nbr_bwd, weight.shape[-1], co[0], co[1], rb.ksize, rb.geom["stride"], rb.geom["padding"])
             else:
                 gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None, order=rb.order_for(rb.nbr_bwd))

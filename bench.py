@@ -242,6 +242,8 @@ def run_gpu(args, rank, world, device):
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
     timer = KernelTimer()
 
+    import collections
+    phases = collections.defaultdict(float) if os.environ.get("TODA_BENCH_PHASES") else None
     fwd_only = args.workload == "c2"
     # device-side input pipeline as in tools/train_utils/train_utils.py (the reference voxelises in DataLoader workers, concurrently
     # with training): step t + 1's voxelisation and rulebooks run on a side stream while step t's backward runs.  Every timed step
@@ -289,6 +291,8 @@ def run_gpu(args, rank, world, device):
                 if prefetch is not None:
                     prefetch.kick()          # the next batch's voxelisation + rulebooks on the side stream, under this forward
             return out
+        ph = phases if timer.enabled else None          # host-side phase clock of the timed steps (TODA_BENCH_PHASES)
+        t_ph = time.perf_counter()
         scheduler.step(it)
         optimizer.zero_grad()
         if pair:
@@ -303,16 +307,30 @@ def run_gpu(args, rank, world, device):
                 batch = dict(batches[it % len(batches)])
             if prefetch is None:
                 voxelize_on_gpu(batch, dataset.voxel_cfg)
+            if ph is not None:
+                ph["next"] += time.perf_counter() - t_ph
+                t_ph = time.perf_counter()
             ret, tb, _ = model(batch)
             loss = ret["loss"].mean()
+        if ph is not None:
+            ph["forward"] += time.perf_counter() - t_ph
+            t_ph = time.perf_counter()
         loss.backward()
+        if ph is not None:
+            ph["backward"] += time.perf_counter() - t_ph
+            t_ph = time.perf_counter()
         clip_grad_norm_(params, clip)
         optimizer.step()
+        if ph is not None:
+            ph["clip+optimizer"] += time.perf_counter() - t_ph
+            t_ph = time.perf_counter()
         if prefetch is not None:
             # next batch's index work goes to the side stream once this step's backward + optimizer are ENQUEUED: the host then
             # sits in the side stream's two syncs while the GPU still has the whole backward to run (kicking before backward() -
             # the first version - parked the host there with nothing queued behind the forward)
             prefetch.kick()
+        if ph is not None:
+            ph["kick (next batch: voxelise + plan, 2 syncs)"] += time.perf_counter() - t_ph
         if not pair:
             net.update_global_step()
         return loss
@@ -350,6 +368,8 @@ def run_gpu(args, rank, world, device):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if phases is not None and rank == 0:
+        print("[host phases, ms per step] " + ", ".join(f"{k} {v / args.steps * 1e3:.2f}" for k, v in phases.items()), file=sys.stderr)
     final_loss = float(loss.item())
     assert np.isfinite(final_loss), "training diverged"
     step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]

@@ -91,7 +91,13 @@ class InputPrefetcher:
         self.it = iter(batches)
         self.net = net
         self.voxel_cfg = voxel_cfg          # the voxeliser settings of the dataset being READ (evaluation of a train-built model: the eval set's cap / range)
-        self.side = torch.cuda.Stream(device=device)
+        # HIGH priority: the side stream's kernels are small (index building) and the host WAITS for them twice per batch; at
+        # normal priority they queue behind the backward pass's chip-filling kernels, the host comes back from kick() only when
+        # that pass is done and the GPU then idles while the next forward is being enqueued (r02 trace: 0.6-0.9 ms gaps at the
+        # step boundary).  TODA_PREFETCH_PRIORITY=0 restores the default priority.
+        import os
+        prio = int(os.environ.get("TODA_PREFETCH_PRIORITY", "-1"))
+        self.side = torch.cuda.Stream(device=device, priority=prio)
         # device tensors that exist already (resident clouds, an object database, the model's weights) were produced on the
         # caller's stream: the side stream waits for that stream ONCE, here.  Not in kick(): kick() runs right behind an enqueued
         # backward pass and must not wait for it - what a later batch reads is either uploaded on the side stream itself or

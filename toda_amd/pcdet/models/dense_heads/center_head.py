@@ -111,10 +111,25 @@ class CenterHead(nn.Module):
     # ------------------------------------------------------------------ targets
     def _head_class_lut(self, head_idx, device):
         """lut[global class id (1-based, 0 = padding)] -> 1-based id inside this head, 0 = not here."""
-        lut = torch.zeros(len(self.class_names) + 1, dtype=torch.float32)
-        for local, name in enumerate(self.class_names_each_head[head_idx]):
-            lut[self.class_names.index(name) + 1] = local + 1
-        return lut.to(device)
+        # cached per device: a fresh `.to(device)` of a pageable host tensor is a SYNCHRONOUS copy - the host sat in it until the
+        # GPU had worked off the whole sparse backbone (cProfile: 6 ms of an 18 ms step inside Tensor.to), lost its launch lead
+        # every step and the GPU then idled at the step boundary
+        cache = self.__dict__.setdefault("_const_cache", {})
+        key = ("lut", head_idx, str(device))
+        if key not in cache:
+            lut = torch.zeros(len(self.class_names) + 1, dtype=torch.float32)
+            for local, name in enumerate(self.class_names_each_head[head_idx]):
+                lut[self.class_names.index(name) + 1] = local + 1
+            cache[key] = lut.to(device)
+        return cache[key]
+
+    def _device_const(self, key, device, build):
+        """Small constant tensors of the head (class maps, range limits, code weights) on `device`, uploaded once."""
+        cache = self.__dict__.setdefault("_const_cache", {})
+        key = (key, str(device))
+        if key not in cache:
+            cache[key] = build().to(device)
+        return cache[key]
 
     def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
         """gt_boxes [B, G, code+1]; feature_map_size (H, W).  Returns the reference's dict of
@@ -162,7 +177,7 @@ class CenterHead(nn.Module):
             pred_boxes = torch.cat([pred[name] for name in self.separate_head_cfg.HEAD_ORDER], dim=1)
             reg = self.reg_loss_func(pred_boxes, target_dicts["masks"][idx], target_dicts["inds"][idx],
                                      target_dicts["target_boxes"][idx])
-            loc_loss = (reg * reg.new_tensor(weights["code_weights"])).sum() * weights["loc_weight"]
+            loc_loss = (reg * self._device_const("code_weights", reg.device, lambda: torch.tensor(weights["code_weights"], dtype=reg.dtype))).sum() * weights["loc_weight"]
             loss = loss + hm_loss + loc_loss
             tb_dict[f"hm_loss_head_{idx}"] = hm_loss.detach()
             tb_dict[f"loc_loss_head_{idx}"] = loc_loss.detach()
@@ -173,7 +188,7 @@ class CenterHead(nn.Module):
     def generate_predicted_boxes(self, batch_size, pred_dicts):
         post = self.model_cfg.POST_PROCESSING
         ref = pred_dicts[0]["hm"]
-        limit = torch.tensor(post.POST_CENTER_LIMIT_RANGE, dtype=torch.float32, device=ref.device)
+        limit = self._device_const("limit", ref.device, lambda: torch.tensor(post.POST_CENTER_LIMIT_RANGE, dtype=torch.float32))
         ret = [{"pred_boxes": [], "pred_scores": [], "pred_labels": []} for _ in range(batch_size)]
         for idx, pred in enumerate(pred_dicts):
             decoded = centernet_utils.decode_bbox_from_heatmap(
@@ -184,7 +199,7 @@ class CenterHead(nn.Module):
                 feature_map_stride=self.feature_map_stride, K=post.MAX_OBJ_PER_SAMPLE,
                 circle_nms=(post.NMS_CONFIG.NMS_TYPE == "circle_nms"), score_thresh=post.SCORE_THRESH,
                 post_center_limit_range=limit)
-            mapping = self.class_id_mapping_each_head[idx].to(ref.device)
+            mapping = self._device_const(("mapping", idx), ref.device, lambda: self.class_id_mapping_each_head[idx])
             for k, final in enumerate(decoded):
                 final["pred_labels"] = mapping[final["pred_labels"].long()]
                 if post.NMS_CONFIG.NMS_TYPE != "circle_nms":

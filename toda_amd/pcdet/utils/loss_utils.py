@@ -104,7 +104,9 @@ class WeightedSmoothL1Loss(nn.Module):
         target = torch.where(torch.isnan(target), input, target)  # ignore nan targets
         diff = input - target
         if self.code_weights is not None:
-            diff = diff * self._cw.to(diff.device).view(1, 1, -1)
+            if self._cw.device != diff.device:       # once: a per-call .to(device) of a host tensor is a synchronous copy
+                self._cw = self._cw.to(diff.device)
+            diff = diff * self._cw.view(1, 1, -1)
         loss = self.smooth_l1_loss(diff, self.beta)
         if weights is not None:
             assert weights.shape[0] == loss.shape[0] and weights.shape[1] == loss.shape[1]

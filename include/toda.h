@@ -408,6 +408,31 @@ int toda_conv3x3_fwd(const float* x, const float* u, const float* bias, int batc
                      int W, float* y, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The other convolutions of BaseBEVBackbone (pcdet/models/backbones_2d/base_bev_backbone.py:32-36: ZeroPad2d(1) +
+ * Conv2d(c_in, c, 3, stride 2, padding 0) at the head of a block; :47-66: the deblocks ConvTranspose2d(c, c_up, k = s,
+ * stride = s) with s = 1 and s = 2), forward and autograd backward on the fp32 matrix cores, NCHW in and out (torch runs them
+ * on MIOpen / rocBLAS behind layout transposes and im2col / col2im passes).
+ *   toda_conv3x3s2_*   x [B][cin][H][W] (H, W even) -> y [B][cout][H/2][W/2]; w [cout][cin][3][3] (nn.Conv2d layout).
+ *                      _dgrad covers the four input-pixel parities in one launch (an input pixel is reached by 1, 2, 2 or 4 of
+ *                      the 9 taps); _wgrad contracts over pixels in splits, folded in fixed order (deterministic).
+ *   toda_deconv_*      x [B][cin][H][W] -> y [B][cout][s H][s W]; w [cin][cout][s][s] (nn.ConvTranspose2d layout), s in {1, 2};
+ *                      the pixel shuffle of s = 2 is the store of the forward GEMM / the gather of the backward ones.
+ * No bias (the reference builds these layers with bias=False; a caller with a bias adds it afterwards).
+ * ---------------------------------------------------------------------- */
+int toda_conv3x3s2_supported(int batch, int cin, int cout, int H, int W);
+int toda_conv3x3s2_fwd(const float* x, const float* w, int batch, int cin, int cout, int H, int W, float* y, void* stream);
+int toda_conv3x3s2_dgrad(const float* dy, const float* w, int batch, int cin, int cout, int H, int W, float* dx, void* stream);
+size_t toda_conv3x3s2_wgrad_workspace_bytes(int batch, int cin, int cout, int H, int W);
+int toda_conv3x3s2_wgrad(const float* x, const float* dy, int batch, int cin, int cout, int H, int W, float* dw, void* ws,
+                         size_t ws_bytes, void* stream);
+int toda_deconv_supported(int batch, int cin, int cout, int H, int W, int s);
+int toda_deconv_fwd(const float* x, const float* w, int batch, int cin, int cout, int H, int W, int s, float* y, void* stream);
+int toda_deconv_dgrad(const float* dy, const float* w, int batch, int cin, int cout, int H, int W, int s, float* dx, void* stream);
+size_t toda_deconv_wgrad_workspace_bytes(int batch, int cin, int cout, int H, int W, int s);
+int toda_deconv_wgrad(const float* x, const float* dy, int batch, int cin, int cout, int H, int W, int s, float* dw, void* ws,
+                      size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * CenterHead.get_loss of one head group, value and gradient (pcdet/models/dense_heads/center_head.py:229-262:
  * sigmoid + clamp(1e-4, 1 - 1e-4) of the heat-map logits; pcdet/utils/loss_utils.py:264-297 neg_loss_cornernet /
  * FocalLossCenterNet; :300-385 _gather_feat, _transpose_and_gather_feat, _reg_loss / RegLossCenterNet; the

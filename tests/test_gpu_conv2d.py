@@ -226,3 +226,56 @@ def test_single_pass_batchnorm2d_matches_torch(shape, relu, split, monkeypatch):
     assert float(((gx - gxr) * safe).abs().max()) <= 2e-4 * max(1e-3, float(gxr.abs().max()))
     assert torch.allclose(bn.weight.grad.double(), ref.weight.grad, rtol=2e-4, atol=2e-3)
     assert torch.allclose(bn.bias.grad.double(), ref.bias.grad, rtol=2e-4, atol=2e-3)
+
+
+# ------------------------------------------------------------------ stride-2 3x3 convolution and transposed-convolution deblocks
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w", [(2, 128, 256, 188, 188), (2, 32, 64, 16, 24), (1, 40, 24, 10, 6), (3, 128, 128, 46, 50)])
+def test_conv3x3_stride2_matches_conv2d_fp64(b, cin, cout, h, w):
+    """ZeroPad2d(1) + Conv2d(3, stride 2) (reference base_bev_backbone.py:32-36) through toda_conv3x3s2_*: forward, data gradient
+    (four parity classes), weight gradient against torch conv2d in float64; bit-reproducible."""
+    from toda_amd import ops
+
+    torch.manual_seed(1)
+    x = torch.randn(b, cin, h, w, device="cuda", requires_grad=True)
+    wt = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    gy = torch.randn(b, cout, h // 2, w // 2, device="cuda")
+    y = ops.conv3x3s2(x, wt)
+    y.backward(gy)
+    xr, wr = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, stride=2, padding=1)
+    yr.backward(gy.double())
+    assert y.shape == yr.shape
+    assert _rel(y, yr) < 2e-6 and _rel(x.grad, xr.grad) < 2e-6 and _rel(wt.grad, wr.grad) < 5e-6, (_rel(y, yr), _rel(x.grad, xr.grad), _rel(wt.grad, wr.grad))
+    g1 = (x.grad.clone(), wt.grad.clone())
+    x.grad = wt.grad = None
+    y2 = ops.conv3x3s2(x, wt)
+    y2.backward(gy)
+    assert torch.equal(y, y2) and torch.equal(g1[0], x.grad) and torch.equal(g1[1], wt.grad)
+
+
+@pytest.mark.parametrize("b,cin,cout,h,w,s", [(2, 128, 256, 188, 188, 1), (2, 256, 256, 94, 94, 2), (2, 64, 32, 8, 12, 2), (1, 24, 40, 7, 5, 2),
+                                              (3, 40, 24, 9, 11, 1)])
+def test_deconv_matches_conv_transpose2d_fp64(b, cin, cout, h, w, s):
+    """ConvTranspose2d(kernel = stride = s) (reference base_bev_backbone.py:47-66) through toda_deconv_*: forward with the pixel
+    shuffle in the store, data gradient with the un-shuffle in the gather, weight gradient, against torch in float64."""
+    from toda_amd import ops
+
+    torch.manual_seed(2)
+    x = torch.randn(b, cin, h, w, device="cuda", requires_grad=True)
+    wt = (torch.randn(cin, cout, s, s, device="cuda") * 0.05).requires_grad_(True)
+    gy = torch.randn(b, cout, h * s, w * s, device="cuda")
+    y = ops.deconv(x, wt, s)
+    y.backward(gy)
+    xr, wr = x.detach().double().requires_grad_(True), wt.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.conv_transpose2d(xr, wr, stride=s)
+    yr.backward(gy.double())
+    assert y.shape == yr.shape
+    assert _rel(y, yr) < 2e-6 and _rel(x.grad, xr.grad) < 2e-6 and _rel(wt.grad, wr.grad) < 5e-6, (_rel(y, yr), _rel(x.grad, xr.grad), _rel(wt.grad, wr.grad))
+    g1 = (x.grad.clone(), wt.grad.clone())
+    x.grad = wt.grad = None
+    ops.deconv(x, wt, s).backward(gy)
+    assert torch.equal(g1[0], x.grad) and torch.equal(g1[1], wt.grad)

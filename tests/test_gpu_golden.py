@@ -97,11 +97,16 @@ def test_bev_backbone_wide_on_gpu_hits_the_hand_written_kernels():
     from tests.helpers import abi_calls
     from tests.test_golden_reference import check_bev_backbone_wide_scaled
 
-    with abi_calls("toda_conv3x3_fwd", "toda_conv3x3_wgrad", "toda_bn2d_fwd", "toda_bn2d_bwd") as n:
+    names = ("toda_conv3x3_fwd", "toda_conv3x3_wgrad", "toda_bn2d_fwd", "toda_bn2d_bwd", "toda_conv3x3s2_fwd", "toda_conv3x3s2_dgrad",
+             "toda_conv3x3s2_wgrad", "toda_deconv_fwd", "toda_deconv_dgrad", "toda_deconv_wgrad")
+    with abi_calls(*names) as n:
         errs = check_bev_backbone_wide_scaled("cuda", 2e-5, 5e-5)
     print({k: f"{v:.1e}" for k, v in errs.items()})
     assert n["toda_conv3x3_fwd"] >= 8 and n["toda_conv3x3_wgrad"] >= 4, n       # 4 layers x (forward + dgrad), 4 wgrads
     assert n["toda_bn2d_fwd"] >= 5 and n["toda_bn2d_bwd"] >= 5, n
+    # the stride-2 head of block 1 and both deblocks (1x1 and 2x2 / stride 2): no convolution of the neck is left to a library
+    assert n["toda_conv3x3s2_fwd"] == 1 and n["toda_conv3x3s2_dgrad"] == 1 and n["toda_conv3x3s2_wgrad"] == 1, n
+    assert n["toda_deconv_fwd"] == 2 and n["toda_deconv_dgrad"] == 2 and n["toda_deconv_wgrad"] == 2, n
 
 
 def test_center_head_wide_on_gpu_hits_the_hand_written_kernels():

@@ -1,0 +1,765 @@
+// The three convolutions of the BEV neck that are not 3x3 / stride 1 (reference pcdet/models/backbones_2d/base_bev_backbone.py:32-36,
+// 47-66): the stride-2 3x3 head of a block (ZeroPad2d(1) + Conv2d(3, stride 2)), and the up-sampling deblocks
+// ConvTranspose2d(k = s, stride = s) with s = 1 (a 1x1 convolution) and s = 2.  Forward, data gradient and weight gradient, NCHW in
+// and out, on the fp32 matrix cores - in round 2 these ran on MIOpen / rocBLAS (implicit-GEMM + transposes, GEMM + im2col / col2im:
+// 1.2 ms of an 18 ms step, 23 launches).
+//
+// One kernel core: C[R1 x R2] += O1[R1 x c] . O2[R2 x c]^T over tiles of 128 x 128 x 16, 4 waves of 64 x 64
+// (v_mfma_f32_16x16x4_f32, 16 accumulator tiles per wave), operands staged through LDS as [row][16 contraction values] so that a
+// lane's fragment of FOUR MFMA steps is one ds_read_b128 (the k-permutation of spconv.hip: lane group g holds contraction indices
+// 4g..4g+3, step j contracts over {4g'+j}), register-staged double buffering.  What differs between the nine GEMMs is only how an
+// operand element is found in memory and where a result element goes - "accessors":
+//   forward / data gradient: O1 = weights (rows = produced channels), O2 = pixels of the map (rows = pixels, contraction = gathered
+//     channels x taps); the pixel index mapping carries the stride-2 gather, the pixel shuffle of the transposed convolution (as an
+//     epilogue store: no separate shuffle pass) and the parity classes of the stride-2 data gradient (an input pixel reaches only the
+//     taps of its parity: 1, 2, 2 or 4 of 9 - one launch covers the four classes, no multiplication by structural zeros);
+//   weight gradient: both operands are maps, the contraction runs over pixels, split over workgroups into slabs that a second
+//     kernel adds in fixed order (deterministic, no float atomics).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace toda {
+
+typedef float pg4 __attribute__((ext_vector_type(4)));
+
+constexpr int PG_K = 32;           // contraction values per stage
+constexpr int PG_LD = PG_K + 4;    // LDS row stride in floats of a [row][contraction] image (16-byte aligned, spreads the b128 fragment reads)
+constexpr int PG_BLOCK = 256;
+
+// ---- operand accessors ----------------------------------------------------------------------------------------------------
+// A thread fetches 8 values per stage: COL operands 8 consecutive ROWS at one contraction index (the rows - pixels - are the same
+// for the whole contraction loop: init() decomposes them ONCE, load() only adds the contraction index), other operands 8
+// consecutive CONTRACTION indices of one row (init() fixes the row, load() walks the contraction).  Index arithmetic is the cost
+// of these kernels, not bytes: no division by a run-time value inside the loop.  Out-of-range elements read as 0.
+
+// dense matrix with strides: element (r, c) = p[r * sr + c * sc]
+template <bool COLSHAPE>
+struct MatOp {
+    static constexpr bool COL = COLSHAPE;
+    const float* p;
+    int rows, cols;
+    long long sr, sc;
+    struct State {
+        long long base;
+        int r;
+    };
+    __device__ __forceinline__ void init(State& s, int r) const {
+        s.r = r;
+        s.base = (long long)r * sr;
+    }
+    __device__ __forceinline__ void load(const State& s, int c, float (&v)[8]) const {
+        if (COL) {
+            const bool cok = c < cols;
+            const long long o = s.base + (long long)c * sc;
+            if (sr == 1 && cok && s.r + 8 <= rows && (o & 3) == 0) {        // 8 consecutive rows = 8 consecutive floats
+                const pg4 a = *reinterpret_cast<const pg4*>(p + o), b = *reinterpret_cast<const pg4*>(p + o + 4);
+                v[0] = a[0], v[1] = a[1], v[2] = a[2], v[3] = a[3], v[4] = b[0], v[5] = b[1], v[6] = b[2], v[7] = b[3];
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (cok && s.r + i < rows) ? p[o + (long long)i * sr] : 0.0f;
+        } else {
+            const bool rok = s.r < rows;
+            if (sc == 1 && rok && c + 8 <= cols && ((s.base + c) & 3) == 0) {
+                const pg4 a = *reinterpret_cast<const pg4*>(p + s.base + c), b = *reinterpret_cast<const pg4*>(p + s.base + c + 4);
+                v[0] = a[0], v[1] = a[1], v[2] = a[2], v[3] = a[3], v[4] = b[0], v[5] = b[1], v[6] = b[2], v[7] = b[3];
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (rok && c + i < cols) ? p[s.base + (long long)(c + i) * sc] : 0.0f;
+        }
+    }
+};
+
+// Pixels of an NCHW map as operand ROWS, channels as contraction: element (n = b * hw + pix, k) = x[(b * C + k) * hw + pix].
+struct PixPlain {
+    static constexpr bool COL = true;
+    const float* x;
+    int B, C, hw;
+    struct State {
+        long long off[8];      // element offset of channel 0 of each pixel, < 0 = outside
+        bool vec;
+    };
+    __device__ __forceinline__ void init(State& s, int n) const {
+        int b = n / hw, pix = n - b * hw;          // ONE division; the other seven pixels follow by carry
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s.off[i] = b < B ? (long long)b * C * hw + pix : -1;
+            if (++pix == hw) pix = 0, ++b;
+        }
+        // two aligned groups of four pixels inside one image each
+        s.vec = (hw & 3) == 0 && s.off[0] >= 0 && s.off[7] >= 0 && s.off[3] == s.off[0] + 3 && s.off[7] == s.off[4] + 3;
+    }
+    __device__ __forceinline__ void load(const State& s, int k, float (&v)[8]) const {
+        const bool kok = k < C;
+        const long long d = (long long)k * hw;
+        if (s.vec && kok) {
+            const pg4 a = *reinterpret_cast<const pg4*>(x + s.off[0] + d), b = *reinterpret_cast<const pg4*>(x + s.off[4] + d);
+            v[0] = a[0], v[1] = a[1], v[2] = a[2], v[3] = a[3], v[4] = b[0], v[5] = b[1], v[6] = b[2], v[7] = b[3];
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (kok && s.off[i] >= 0) ? x[s.off[i] + d] : 0.0f;
+    }
+};
+
+// walks n = b * hw + pix in steps without dividing: position of the thread's first pixel of the current stage
+struct PixCursor {
+    int b, pix;
+};
+
+// Channels of an NCHW map as operand rows, pixels as contraction (weight gradients): element (ch, n) = x[(b * C + ch) * hw + pix].
+struct ChanPlain {
+    static constexpr bool COL = false;
+    const float* x;
+    int B, C, hw;
+    struct State {
+        int ch;
+    };
+    __device__ __forceinline__ void init(State& s, int ch) const { s.ch = ch; }
+    __device__ __forceinline__ void load(const State& s, int n, float (&v)[8]) const {
+        const bool ok = s.ch < C;
+        const int b0 = n / hw, p0 = n - b0 * hw;          // (one division per stage and thread; the 8 pixels follow by carry)
+        if ((hw & 3) == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int b = b0, pix = p0 + 4 * h;
+                if (pix >= hw) pix -= hw, ++b;
+                pg4 t = pg4{0.f, 0.f, 0.f, 0.f};
+                if (ok && b < B) t = *reinterpret_cast<const pg4*>(x + ((long long)b * C + s.ch) * hw + pix);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[4 * h + i] = t[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int b = b0, pix = p0 + i;
+                while (pix >= hw) pix -= hw, ++b;
+                v[i] = (ok && b < B) ? x[((long long)b * C + s.ch) * hw + pix] : 0.0f;
+            }
+        }
+    }
+};
+
+// stride-2 3x3 gather: x [B][C][H][W] (H, W even), output pixels (b, oy, ox) of the Ho x Wo map, taps k = ci * 9 + ky * 3 + kx
+// reading x[b][ci][2 oy + ky - 1][2 ox + kx - 1] (ZeroPad2d(1) + Conv2d(3, stride 2, padding 0)).  Only the top row and the left
+// column of taps can fall outside (2 oy + 1 <= H - 1 on an even map).
+struct ConvS2Geom {
+    const float* x;
+    int B, C, H, W, Ho, Wo;
+};
+struct PixConvS2 {          // rows = output pixels, contraction = (ci, ky, kx)
+    static constexpr bool COL = true;
+    ConvS2Geom g;
+    struct State {
+        long long off[8];      // offset of x[b][0][2 oy - 1][2 ox - 1]; < 0 marks an invalid pixel through `ok`
+        unsigned ok, top, left;   // bit i: pixel valid / oy == 0 / ox == 0
+    };
+    __device__ __forceinline__ void init(State& s, int n) const {
+        const int howo = g.Ho * g.Wo;
+        s.ok = s.top = s.left = 0u;
+        int b = n / howo;
+        const int rem = n - b * howo;
+        int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s.off[i] = ((long long)b * g.C * g.H + (2 * oy - 1)) * g.W + 2 * ox - 1;
+            s.ok |= (unsigned)(b < g.B) << i;
+            s.top |= (unsigned)(oy == 0) << i;
+            s.left |= (unsigned)(ox == 0) << i;
+            if (++ox == g.Wo) {
+                ox = 0;
+                if (++oy == g.Ho) oy = 0, ++b;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const State& s, int k, float (&v)[8]) const {
+        const int ci = k / 9, t = k - ci * 9;
+        const int ky = t / 3, kx = t - ky * 3;
+        const long long d = ((long long)ci * g.H + ky) * g.W + kx;
+        unsigned m = ci < g.C ? s.ok : 0u;
+        if (ky == 0) m &= ~s.top;
+        if (kx == 0) m &= ~s.left;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? g.x[s.off[i] + d] : 0.0f;
+    }
+};
+struct TapConvS2 {          // rows = (ci, ky, kx), contraction = output pixels (weight gradient)
+    static constexpr bool COL = false;
+    ConvS2Geom g;
+    int rows;
+    struct State {
+        long long d;
+        int ky, kx;
+        bool ok;
+    };
+    __device__ __forceinline__ void init(State& s, int k) const {
+        const int ci = k / 9, t = k - ci * 9;
+        s.ky = t / 3, s.kx = t - s.ky * 3;
+        s.ok = k < rows;
+        s.d = ((long long)ci * g.H + s.ky - 1) * g.W + s.kx - 1;
+    }
+    __device__ __forceinline__ void load(const State& s, int n, float (&v)[8]) const {
+        const int howo = g.Ho * g.Wo;
+        int b = n / howo;
+        const int rem = n - b * howo;
+        int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool in = s.ok && b < g.B && !(s.ky == 0 && oy == 0) && !(s.kx == 0 && ox == 0);
+            v[i] = in ? g.x[((long long)b * g.C * g.H + 2 * oy) * g.W + 2 * ox + s.d] : 0.0f;
+            if (++ox == g.Wo) {
+                ox = 0;
+                if (++oy == g.Ho) oy = 0, ++b;
+            }
+        }
+    }
+};
+
+// pixel un-shuffle of a 2x up-sampled map: dy [B][C][2h][2w]; element ((b, y, x), k = co * 4 + i * 2 + j) = dy[b][co][2y + i][2x + j]
+struct UnshuffleGeom {
+    const float* dy;
+    int B, C, h, w;      // C = channels of dy, (h, w) = the LOW-resolution map
+};
+struct PixUnshuffle {       // rows = low-resolution pixels, contraction = (co, i, j)
+    static constexpr bool COL = true;
+    UnshuffleGeom g;
+    struct State {
+        long long off[8];
+        unsigned ok;
+    };
+    __device__ __forceinline__ void init(State& s, int n) const {
+        const int hw = g.h * g.w;
+        s.ok = 0u;
+        int b = n / hw;
+        const int rem = n - b * hw;
+        int y = rem / g.w, x = rem - y * g.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s.off[i] = ((long long)b * g.C * (2 * g.h) + 2 * y) * (2 * g.w) + 2 * x;
+            s.ok |= (unsigned)(b < g.B) << i;
+            if (++x == g.w) {
+                x = 0;
+                if (++y == g.h) y = 0, ++b;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const State& s, int k, float (&v)[8]) const {
+        const int co = k >> 2, i2 = (k >> 1) & 1, j2 = k & 1;
+        const long long d = ((long long)co * (2 * g.h) + i2) * (2 * g.w) + j2;
+        const unsigned m = co < g.C ? s.ok : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? g.dy[s.off[i] + d] : 0.0f;
+    }
+};
+struct ChanUnshuffle {      // rows = (co, i, j), contraction = low-resolution pixels (weight gradient)
+    static constexpr bool COL = false;
+    UnshuffleGeom g;
+    int rows;
+    struct State {
+        long long d;
+        bool ok;
+    };
+    __device__ __forceinline__ void init(State& s, int k) const {
+        const int co = k >> 2, i2 = (k >> 1) & 1, j2 = k & 1;
+        s.ok = k < rows;
+        s.d = ((long long)co * (2 * g.h) + i2) * (2 * g.w) + j2;
+    }
+    __device__ __forceinline__ void load(const State& s, int n, float (&v)[8]) const {
+        const int hw = g.h * g.w;
+        int b = n / hw;
+        const int rem = n - b * hw;
+        int y = rem / g.w, x = rem - y * g.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = (s.ok && b < g.B) ? g.dy[((long long)b * g.C * (2 * g.h) + 2 * y) * (2 * g.w) + 2 * x + s.d] : 0.0f;
+            if (++x == g.w) {
+                x = 0;
+                if (++y == g.h) y = 0, ++b;
+            }
+        }
+    }
+};
+
+// Data gradient of the stride-2 3x3 convolution, one parity class (py, px) of the INPUT pixels per blockIdx.z: input pixel
+// (2 y' + py, 2 x' + px) is reached through the taps ky = iy + 1 (mod 2): ky = 1 for even rows (output row y'), {0, 2} for odd
+// rows (output rows y' + 1 and y'), the same in x.  Contraction index k = (co << lt) + tap, lt = log2(taps of the class).
+struct S2Class {
+    int py, px, lty, ltx;      // log2 of the taps per axis (0 or 1)
+    __device__ __forceinline__ void set(int cls) {
+        py = cls >> 1, px = cls & 1;
+        lty = py, ltx = px;
+    }
+};
+struct PixS2Dgrad {         // rows = input pixels of the class (b, y', x'), contraction = (co, tap of the class)
+    static constexpr bool COL = true;
+    const float* dy;        // [B][Cout][Ho][Wo]
+    int B, Cout, H, W, Ho, Wo;
+    S2Class c;
+    struct State {
+        long long off[8];      // offset of dy[b][0][y'][x']
+        unsigned ok, bottom, right;
+    };
+    __device__ __forceinline__ void init(State& s, int n) const {
+        const int hh = H / 2, ww = W / 2;
+        s.ok = s.bottom = s.right = 0u;
+        int b = n / (hh * ww);
+        const int rem = n - b * (hh * ww);
+        int yy = rem / ww, xx = rem - yy * ww;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s.off[i] = ((long long)b * Cout * Ho + yy) * Wo + xx;
+            s.ok |= (unsigned)(b < B) << i;
+            s.bottom |= (unsigned)(yy + 1 >= Ho) << i;
+            s.right |= (unsigned)(xx + 1 >= Wo) << i;
+            if (++xx == ww) {
+                xx = 0;
+                if (++yy == hh) yy = 0, ++b;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const State& s, int k, float (&v)[8]) const {
+        const int lt = c.lty + c.ltx;
+        const int co = k >> lt, t = k & ((1 << lt) - 1);
+        const int ty = c.lty ? (t >> c.ltx) : 0, tx = c.ltx ? (t & 1) : 0;
+        // odd parity: tap index 0 = kernel tap 0 = output y' + 1, tap index 1 = kernel tap 2 = output y'
+        const int dyy = (c.lty && ty == 0) ? 1 : 0, dxx = (c.ltx && tx == 0) ? 1 : 0;
+        const long long d = ((long long)co * Ho + dyy) * Wo + dxx;
+        unsigned m = co < Cout ? s.ok : 0u;
+        if (dyy) m &= ~s.bottom;
+        if (dxx) m &= ~s.right;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? dy[s.off[i] + d] : 0.0f;
+    }
+};
+struct WS2Dgrad {           // rows = ci, contraction = (co, tap of the class): w[co][ci][ky][kx]
+    static constexpr bool COL = false;
+    const float* w;
+    int Cin, Cout;
+    S2Class c;
+    struct State {
+        int ci;
+    };
+    __device__ __forceinline__ void init(State& s, int ci) const { s.ci = ci; }
+    __device__ __forceinline__ void load(const State& s, int k, float (&v)[8]) const {
+        const int lt = c.lty + c.ltx;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kk = k + i;
+            const int co = kk >> lt, t = kk & ((1 << lt) - 1);
+            const int ty = c.lty ? (t >> c.ltx) : 0, tx = c.ltx ? (t & 1) : 0;
+            const int ky = c.lty ? 2 * ty : 1, kx = c.ltx ? 2 * tx : 1;
+            v[i] = (s.ci < Cin && co < Cout) ? w[(((long long)co * Cin + s.ci) * 3 + ky) * 3 + kx] : 0.0f;
+        }
+    }
+};
+
+// ---- result stores: column n of the tile product is decomposed once (prep), then its 16 rows are written (put) ------------------
+struct StoreNCHW {          // r1 = channel m, r2 = pixel n = b * hw + pix
+    static constexpr bool ROWS4 = true;      // four consecutive r2 of one r1 are four consecutive floats when hw % 4 == 0
+    float* y;
+    int M, N, hw;
+    __device__ __forceinline__ bool vec_ok() const { return (hw & 3) == 0 && (N & 3) == 0; }
+    __device__ __forceinline__ void put4(long long base, int m, pg4 v) const {
+        if (base >= 0 && m < M) *reinterpret_cast<pg4*>(y + base + (long long)m * hw) = v;
+    }
+    __device__ __forceinline__ long long prep(int n) const {
+        if (n >= N) return -1;
+        const int b = n / hw, pix = n - b * hw;
+        return (long long)b * M * hw + pix;
+    }
+    __device__ __forceinline__ void put(long long base, int m, float v) const {
+        if (base >= 0 && m < M) y[base + (long long)m * hw] = v;
+    }
+};
+struct StoreShuffle {       // r1 = (co, i, j), r2 = (b, y, x) of the low-resolution map: y_out[b][co][2y + i][2x + j]
+    static constexpr bool ROWS4 = false;
+    float* y;
+    int M, N, C, h, w;
+    __device__ __forceinline__ long long prep(int n) const {
+        if (n >= N) return -1;
+        const int hw = h * w;
+        const int b = n / hw, rem = n - b * hw;
+        const int yy = rem / w, xx = rem - yy * w;
+        return ((long long)b * C * (2 * h) + 2 * yy) * (2 * w) + 2 * xx;
+    }
+    __device__ __forceinline__ void put(long long base, int m, float v) const {
+        if (base >= 0 && m < M) {
+            const int co = m >> 2, i = (m >> 1) & 1, j = m & 1;
+            y[base + ((long long)co * (2 * h) + i) * (2 * w) + j] = v;
+        }
+    }
+};
+struct StoreS2Class {       // r1 = ci, r2 = (b, y', x') of the class: dx[b][ci][2y' + py][2x' + px]
+    static constexpr bool ROWS4 = false;
+    float* dx;
+    int M, N, H, W, py, px;
+    __device__ __forceinline__ long long prep(int n) const {
+        if (n >= N) return -1;
+        const int hh = H / 2, ww = W / 2;
+        const int b = n / (hh * ww), rem = n - b * (hh * ww);
+        const int yy = rem / ww, xx = rem - yy * ww;
+        return ((long long)b * M * H + 2 * yy + py) * W + 2 * xx + px;
+    }
+    __device__ __forceinline__ void put(long long base, int m, float v) const {
+        if (base >= 0 && m < M) dx[base + (long long)m * H * W] = v;
+    }
+};
+struct StoreSlab {          // weight gradients: partial sums of contraction split z -> slab[z][r1][r2]
+    static constexpr bool ROWS4 = true;
+    float* slab;
+    int M, N;
+    __device__ __forceinline__ bool vec_ok() const { return (N & 3) == 0; }
+    __device__ __forceinline__ void put4(long long base, int m, pg4 v) const {
+        if (base >= 0 && m < M) *reinterpret_cast<pg4*>(slab + base + (long long)m * N) = v;
+    }
+    __device__ __forceinline__ long long prep(int n) const { return n < N ? (long long)blockIdx.z * M * N + n : -1; }
+    __device__ __forceinline__ void put(long long base, int m, float v) const {
+        if (base >= 0 && m < M) slab[base + (long long)m * N] = v;
+    }
+};
+
+// ---- the tile product --------------------------------------------------------------------------------------------------------
+// grid: x = tiles over R2, y = tiles over R1, z = contraction split (weight gradients) or parity class (stride-2 data gradient).
+// LDS images: an operand whose CONTRACTION index is contiguous in memory is staged [row][PG_K] (16-byte stores, one ds_read_b128
+// per fragment of four steps); a COL operand (rows contiguous in memory: pixels of an NCHW map) is staged as it is read,
+// [contraction][row] (16-byte stores again - transposing it in the store cost 16-way bank conflicts), and its fragment is four
+// ds_read_b32.  Both follow the same k-permutation: lane group g holds contraction indices 4g..4g+3 of each group of 16.
+template <class Op, int T>
+struct PgStage {
+    static constexpr int FLOATS = Op::COL ? PG_K * (T + 4) : T * PG_LD;
+};
+
+// T = tile rows of both operands (128 or 64): 4 waves of (T / 2) x (T / 2).  The 64-row tile is for the GEMMs whose pixel count
+// gives too few 128 x 128 tiles to fill 256 CUs (the 94 x 94 maps: 278 tiles).
+template <int T, class Op1, class Op2, class Store>
+__device__ __forceinline__ void pg_tile(const Op1& o1, const Op2& o2, const Store& st, int c_begin, int c_end) {
+    constexpr int LC = T + 4;                 // row stride of a [contraction][row] image
+    constexpr int WT = T / 32;                // 16 x 16 result tiles per wave and dimension
+    constexpr int PER = T / 64;               // groups of 8 values a thread fetches per operand and stage
+    __shared__ __attribute__((aligned(16))) float s1[2][PgStage<Op1, T>::FLOATS];
+    __shared__ __attribute__((aligned(16))) float s2[2][PgStage<Op2, T>::FLOATS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r1_0 = blockIdx.y * T, r2_0 = blockIdx.x * T;
+    const int wm = wave >> 1, wn = wave & 1;                 // quadrant of this wave
+    const int fi = lane & 15, fg = lane >> 4;
+
+    // a thread's share of a stage (PER groups of 8 values):
+    //   COL: contraction index t >> 3 (0..31), rows (t & 7) * 8 PER .. ;   else: row t / (4 / PER) ..., 8 PER consecutive contraction values
+    constexpr int ROW_DIV = 4 / PER;          // threads per row of a [row][contraction] image
+    typename Op1::State q1[PER];
+    typename Op2::State q2[PER];
+#pragma unroll
+    for (int h = 0; h < PER; ++h) {
+        if (Op1::COL) o1.init(q1[h], r1_0 + (t & 7) * (8 * PER) + 8 * h);
+        else if (h == 0) o1.init(q1[0], r1_0 + t / ROW_DIV);
+        if (Op2::COL) o2.init(q2[h], r2_0 + (t & 7) * (8 * PER) + 8 * h);
+        else if (h == 0) o2.init(q2[0], r2_0 + t / ROW_DIV);
+    }
+    float v1[PER][8], v2[PER][8];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int h = 0; h < PER; ++h) {
+            if (Op1::COL) o1.load(q1[h], c0 + (t >> 3), v1[h]);
+            else o1.load(q1[0], c0 + (t % ROW_DIV) * (8 * PER) + 8 * h, v1[h]);
+            if (Op2::COL) o2.load(q2[h], c0 + (t >> 3), v2[h]);
+            else o2.load(q2[0], c0 + (t % ROW_DIV) * (8 * PER) + 8 * h, v2[h]);
+        }
+    };
+    auto stash_one = [&](float* img, bool col, const float (&v)[PER][8]) {
+        float* dst = col ? img + (t >> 3) * LC + (t & 7) * (8 * PER) : img + (t / ROW_DIV) * PG_LD + (t % ROW_DIV) * (8 * PER);
+#pragma unroll
+        for (int h = 0; h < PER; ++h) {
+            *reinterpret_cast<pg4*>(dst + 8 * h) = pg4{v[h][0], v[h][1], v[h][2], v[h][3]};
+            *reinterpret_cast<pg4*>(dst + 8 * h + 4) = pg4{v[h][4], v[h][5], v[h][6], v[h][7]};
+        }
+    };
+
+    pg4 acc[WT][WT];
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+        for (int b = 0; b < WT; ++b) acc[a][b] = pg4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(c_begin);
+    stash_one(s1[0], Op1::COL, v1);
+    stash_one(s2[0], Op2::COL, v2);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += PG_K) {
+        const bool more = c0 + PG_K < c_end;
+        if (more) fetch(c0 + PG_K);
+#pragma unroll
+        for (int kk = 0; kk < PG_K; kk += 16) {           // groups of 16 contraction values = 4 MFMA steps
+            pg4 fa[WT], fb[WT];
+#pragma unroll
+            for (int a = 0; a < WT; ++a) {
+                if (Op1::COL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[a][j] = s1[buf][(kk + 4 * fg + j) * LC + wm * (T / 2) + a * 16 + fi];
+                } else {
+                    fa[a] = *reinterpret_cast<const pg4*>(&s1[buf][(wm * (T / 2) + a * 16 + fi) * PG_LD + kk + 4 * fg]);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < WT; ++b) {
+                if (Op2::COL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[b][j] = s2[buf][(kk + 4 * fg + j) * LC + wn * (T / 2) + b * 16 + fi];
+                } else {
+                    fb[b] = *reinterpret_cast<const pg4*>(&s2[buf][(wn * (T / 2) + b * 16 + fi) * PG_LD + kk + 4 * fg]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < WT; ++a)
+#pragma unroll
+                    for (int b = 0; b < WT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            stash_one(s1[buf ^ 1], Op1::COL, v1);
+            stash_one(s2[buf ^ 1], Op2::COL, v2);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D: column = lane & 15 (operand-2 row), row = 4 * (lane >> 4) + reg (operand-1 row)
+    if constexpr (Store::ROWS4) {
+        // Results whose operand-2 index is contiguous in memory go out as 16-byte stores: the wave's quadrant is turned in LDS (the
+        // operand images are free after the loop's last barrier) and a lane then owns 4 consecutive columns of a row.
+        if (st.vec_ok()) {
+            constexpr int QW = T / 2;              // quadrant width
+            static_assert(PgStage<Op1, T>::FLOATS * 2 >= 2 * QW * QW && PgStage<Op2, T>::FLOATS * 2 >= 2 * QW * QW, "quadrant images must fit the operand buffers");
+            float* img = (wave & 2 ? &s2[0][0] : &s1[0][0]) + (wave & 1) * (QW * QW);          // [QW rows][QW]: one private image per wave
+#pragma unroll
+            for (int a = 0; a < WT; ++a)
+#pragma unroll
+                for (int b = 0; b < WT; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) img[(a * 16 + 4 * fg + reg) * QW + b * 16 + fi] = acc[a][b][reg];
+            __builtin_amdgcn_wave_barrier();
+            constexpr int LPR = QW / 4;            // lanes per row
+            const int c4 = (lane % LPR) * 4;
+            const long long base = st.prep(r2_0 + wn * QW + c4);
+#pragma unroll
+            for (int it = 0; it < QW / (64 / LPR); ++it) {
+                const int row = it * (64 / LPR) + lane / LPR;
+                st.put4(base, r1_0 + wm * QW + row, *reinterpret_cast<const pg4*>(&img[row * QW + c4]));
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
+        const long long base = st.prep(r2_0 + wn * (T / 2) + b * 16 + fi);
+#pragma unroll
+        for (int a = 0; a < WT; ++a)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) st.put(base, r1_0 + wm * (T / 2) + a * 16 + 4 * fg + reg, acc[a][b][reg]);
+    }
+}
+
+template <int T, class Op1, class Op2, class Store>
+__global__ void __launch_bounds__(PG_BLOCK)
+pg_gemm_kernel(const Op1 o1, const Op2 o2, const Store st, int c_total, int c_per_split) {
+    const int c_begin = blockIdx.z * c_per_split;
+    const int c_end = min(c_total, c_begin + c_per_split);
+    pg_tile<T>(o1, o2, st, c_begin, c_end > c_begin ? c_end : c_begin);      // (an empty split still owns a slab: it stores zeros)
+}
+
+// stride-2 data gradient: blockIdx.z = parity class
+template <int T>
+__global__ void __launch_bounds__(PG_BLOCK)
+pg_s2_dgrad_kernel(WS2Dgrad o1, PixS2Dgrad o2, StoreS2Class st) {
+    S2Class c;
+    c.set(blockIdx.z);
+    o1.c = c;
+    o2.c = c;
+    st.py = c.py, st.px = c.px;
+    pg_tile<T>(o1, o2, st, 0, o2.Cout << (c.lty + c.ltx));
+}
+
+__global__ void __launch_bounds__(PG_BLOCK)
+pg_slab_reduce_kernel(const float* __restrict__ slab, int splits, long long elems, float* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * PG_BLOCK + threadIdx.x;
+    if (e >= elems) return;
+    float s = 0.f;
+    int z = 0;
+    for (; z + 8 <= splits; z += 8) {          // adds in split order; eight loads in flight
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = slab[(long long)(z + i) * elems + e];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; z < splits; ++z) s += slab[(long long)z * elems + e];
+    out[e] = s;
+}
+
+static int pg_splits(long long n_pixels, int tiles) {
+    // weight gradients: the output is a few tiles, the parallelism comes from splitting the pixels - about 768 workgroups
+    // (256 CUs x 2 resident + tail), contraction chunks of at least 8 stages
+    int want = cdiv(768, tiles > 0 ? tiles : 1);
+    long long max_by_len = n_pixels / (8 * PG_K);
+    if (max_by_len < 1) max_by_len = 1;
+    if (want > max_by_len) want = (int)max_by_len;
+    if (want > 512) want = 512;
+    if (want < 1) want = 1;
+    return want;
+}
+
+// 128-row tiles when they fill the chip (or when contraction splits do: gz > 1, the weight gradients), 64-row tiles otherwise
+static inline bool pg_small(long long r1, long long r2, int gz) { return gz == 1 && (long long)cdiv(r1, 128) * cdiv(r2, 128) < 768; }
+#define PG_LAUNCH(O1, O2, ST, r1, r2, gz, ...)                                                                                             \
+    do {                                                                                                                                   \
+        if (pg_small(r1, r2, gz))                                                                                                            \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(pg_gemm_kernel<64, O1, O2, ST>), dim3(cdiv(r2, 64), cdiv(r1, 64), gz), dim3(PG_BLOCK), 0,    \
+                               (hipStream_t)stream, __VA_ARGS__);                                                                          \
+        else                                                                                                                               \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(pg_gemm_kernel<128, O1, O2, ST>), dim3(cdiv(r2, 128), cdiv(r1, 128), gz), dim3(PG_BLOCK), 0, \
+                               (hipStream_t)stream, __VA_ARGS__);                                                                          \
+    } while (0)
+
+static int pg_check(const char* who, int B, int Cin, int Cout, int H, int W) {
+    TODA_CHECK_ARG(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1, "%s: bad shape", who);
+    TODA_CHECK_ARG(4LL * B * (long long)(Cin > Cout ? Cin : Cout) * H * W * 4 < (1LL << 40), "%s: map too large", who);
+    return TODA_OK;
+}
+
+}  // namespace toda
+
+using namespace toda;
+
+// ---------------------------------------------------------------- ZeroPad2d(1) + Conv2d(3, stride 2): base_bev_backbone.py:32-36
+extern "C" int toda_conv3x3s2_supported(int batch, int cin, int cout, int H, int W) {
+    return (batch >= 1 && cin >= 1 && cout >= 1 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0) ? 1 : 0;
+}
+
+extern "C" int toda_conv3x3s2_fwd(const float* x, const float* w, int batch, int cin, int cout, int H, int W, float* y, void* stream) {
+    TODA_CHECK_ARG(x && w && y && toda_conv3x3s2_supported(batch, cin, cout, H, W), "conv3x3s2_fwd: null pointer or odd map");
+    if (int rc = pg_check("conv3x3s2_fwd", batch, cin, cout, H, W)) return rc;
+    const int Ho = H / 2, Wo = W / 2, N = batch * Ho * Wo, K = cin * 9;
+    MatOp<false> o1{w, cout, K, K, 1};
+    PixConvS2 o2{ConvS2Geom{x, batch, cin, H, W, Ho, Wo}};
+    StoreNCHW st{y, cout, N, Ho * Wo};
+    PG_LAUNCH(MatOp<false>, PixConvS2, StoreNCHW, cout, N, 1, o1, o2, st, K, K);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_conv3x3s2_dgrad(const float* dy, const float* w, int batch, int cin, int cout, int H, int W, float* dx, void* stream) {
+    TODA_CHECK_ARG(dy && w && dx && toda_conv3x3s2_supported(batch, cin, cout, H, W), "conv3x3s2_dgrad: null pointer or odd map");
+    if (int rc = pg_check("conv3x3s2_dgrad", batch, cin, cout, H, W)) return rc;
+    const int N = batch * (H / 2) * (W / 2);
+    WS2Dgrad o1{w, cin, cout, S2Class{}};
+    PixS2Dgrad o2{dy, batch, cout, H, W, H / 2, W / 2, S2Class{}};
+    StoreS2Class st{dx, cin, N, H, W, 0, 0};
+    if ((long long)cdiv(cin, 128) * cdiv(N, 128) * 4 < 768)
+        hipLaunchKernelGGL(pg_s2_dgrad_kernel<64>, dim3(cdiv(N, 64), cdiv(cin, 64), 4), dim3(PG_BLOCK), 0, (hipStream_t)stream, o1, o2, st);
+    else
+        hipLaunchKernelGGL(pg_s2_dgrad_kernel<128>, dim3(cdiv(N, 128), cdiv(cin, 128), 4), dim3(PG_BLOCK), 0, (hipStream_t)stream, o1, o2, st);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" size_t toda_conv3x3s2_wgrad_workspace_bytes(int batch, int cin, int cout, int H, int W) {
+    const long long n = (long long)batch * (H / 2) * (W / 2);
+    const int splits = pg_splits(n, cdiv(cin * 9, 128) * cdiv(cout, 128));
+    return align_up((size_t)splits * cout * cin * 9 * sizeof(float), 256);
+}
+
+extern "C" int toda_conv3x3s2_wgrad(const float* x, const float* dy, int batch, int cin, int cout, int H, int W, float* dw, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    TODA_CHECK_ARG(x && dy && dw && ws && toda_conv3x3s2_supported(batch, cin, cout, H, W), "conv3x3s2_wgrad: null pointer or odd map");
+    if (int rc = pg_check("conv3x3s2_wgrad", batch, cin, cout, H, W)) return rc;
+    const int Ho = H / 2, Wo = W / 2, N = batch * Ho * Wo, K = cin * 9;
+    const int splits = pg_splits(N, cdiv(K, 128) * cdiv(cout, 128));
+    if (ws_bytes < toda_conv3x3s2_wgrad_workspace_bytes(batch, cin, cout, H, W)) {
+        set_error("conv3x3s2_wgrad: workspace too small");
+        return TODA_EWORKSPACE;
+    }
+    int per = cdiv(cdiv(N, splits), PG_K) * PG_K;
+    ChanPlain o1{dy, batch, cout, Ho * Wo};                       // rows co, contraction pixels
+    TapConvS2 o2{ConvS2Geom{x, batch, cin, H, W, Ho, Wo}, K};   // rows (ci, ky, kx)
+    StoreSlab st{(float*)ws, cout, K};
+    PG_LAUNCH(ChanPlain, TapConvS2, StoreSlab, cout, K, splits, o1, o2, st, N, per);
+    const long long elems = (long long)cout * K;
+    hipLaunchKernelGGL(pg_slab_reduce_kernel, dim3(cdiv(elems, PG_BLOCK)), dim3(PG_BLOCK), 0, (hipStream_t)stream, (const float*)ws, splits, elems, dw);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+// --------------------------------------------- ConvTranspose2d(Cin, Cout, k = s, stride = s), s in {1, 2}: base_bev_backbone.py:47-66
+// weight [Cin][Cout][s][s]
+extern "C" int toda_deconv_supported(int batch, int cin, int cout, int H, int W, int s) {
+    return (batch >= 1 && cin >= 1 && cout >= 1 && H >= 1 && W >= 1 && (s == 1 || s == 2)) ? 1 : 0;
+}
+
+extern "C" int toda_deconv_fwd(const float* x, const float* w, int batch, int cin, int cout, int H, int W, int s, float* y, void* stream) {
+    TODA_CHECK_ARG(x && w && y && toda_deconv_supported(batch, cin, cout, H, W, s), "deconv_fwd: null pointer or stride not in {1, 2}");
+    if (int rc = pg_check("deconv_fwd", batch, cin, cout, H * s, W * s)) return rc;
+    const int N = batch * H * W, M = cout * s * s;
+    MatOp<true> o1{w, M, cin, 1, M};          // element (m, k) = w[k][m]: rows contiguous
+    PixPlain o2{x, batch, cin, H * W};
+    if (s == 1) {
+        StoreNCHW st{y, cout, N, H * W};
+        PG_LAUNCH(MatOp<true>, PixPlain, StoreNCHW, M, N, 1, o1, o2, st, cin, cin);
+    } else {
+        StoreShuffle st{y, M, N, cout, H, W};
+        PG_LAUNCH(MatOp<true>, PixPlain, StoreShuffle, M, N, 1, o1, o2, st, cin, cin);
+    }
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_deconv_dgrad(const float* dy, const float* w, int batch, int cin, int cout, int H, int W, int s, float* dx, void* stream) {
+    TODA_CHECK_ARG(dy && w && dx && toda_deconv_supported(batch, cin, cout, H, W, s), "deconv_dgrad: null pointer or stride not in {1, 2}");
+    if (int rc = pg_check("deconv_dgrad", batch, cin, cout, H * s, W * s)) return rc;
+    const int N = batch * H * W, K = cout * s * s;
+    MatOp<false> o1{w, cin, K, K, 1};         // element (ci, k) = w[ci][k]
+    StoreNCHW st{dx, cin, N, H * W};
+    if (s == 1) {
+        PixPlain o2{dy, batch, cout, H * W};
+        PG_LAUNCH(MatOp<false>, PixPlain, StoreNCHW, cin, N, 1, o1, o2, st, K, K);
+    } else {
+        PixUnshuffle o2{UnshuffleGeom{dy, batch, cout, H, W}};
+        PG_LAUNCH(MatOp<false>, PixUnshuffle, StoreNCHW, cin, N, 1, o1, o2, st, K, K);
+    }
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" size_t toda_deconv_wgrad_workspace_bytes(int batch, int cin, int cout, int H, int W, int s) {
+    const long long n = (long long)batch * H * W;
+    const int K = cout * s * s;
+    const int splits = pg_splits(n, cdiv(K, 128) * cdiv(cin, 128));
+    return align_up((size_t)splits * cin * K * sizeof(float), 256);
+}
+
+extern "C" int toda_deconv_wgrad(const float* x, const float* dy, int batch, int cin, int cout, int H, int W, int s, float* dw, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    TODA_CHECK_ARG(x && dy && dw && ws && toda_deconv_supported(batch, cin, cout, H, W, s), "deconv_wgrad: null pointer or stride not in {1, 2}");
+    if (int rc = pg_check("deconv_wgrad", batch, cin, cout, H * s, W * s)) return rc;
+    const int N = batch * H * W, K = cout * s * s;
+    const int splits = pg_splits(N, cdiv(K, 128) * cdiv(cin, 128));
+    if (ws_bytes < toda_deconv_wgrad_workspace_bytes(batch, cin, cout, H, W, s)) {
+        set_error("deconv_wgrad: workspace too small");
+        return TODA_EWORKSPACE;
+    }
+    int per = cdiv(cdiv(N, splits), PG_K) * PG_K;
+    ChanPlain o1{x, batch, cin, H * W};                           // rows ci, contraction pixels
+    StoreSlab st{(float*)ws, cin, K};
+    if (s == 1) {
+        ChanPlain o2{dy, batch, cout, H * W};
+        PG_LAUNCH(ChanPlain, ChanPlain, StoreSlab, cin, K, splits, o1, o2, st, N, per);
+    } else {
+        ChanUnshuffle o2{UnshuffleGeom{dy, batch, cout, H, W}, K};
+        PG_LAUNCH(ChanPlain, ChanUnshuffle, StoreSlab, cin, K, splits, o1, o2, st, N, per);
+    }
+    const long long elems = (long long)cin * K;
+    hipLaunchKernelGGL(pg_slab_reduce_kernel, dim3(cdiv(elems, PG_BLOCK)), dim3(PG_BLOCK), 0, (hipStream_t)stream, (const float*)ws, splits, elems, dw);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}

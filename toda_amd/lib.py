@@ -56,6 +56,16 @@ SIGNATURES = {
     "toda_bn_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp, _vp, _vp]),
     "toda_rows_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_rows_bn_bwd_res": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "toda_conv3x3s2_supported": (_i, [_i, _i, _i, _i, _i]),
+    "toda_conv3x3s2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "toda_conv3x3s2_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "toda_conv3x3s2_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "toda_conv3x3s2_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "toda_deconv_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "toda_deconv_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "toda_deconv_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "toda_deconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "toda_deconv_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_bn2d_supported": (_i, [_i, _i, _i]),
     "toda_bn2d_sync_bytes": (_sz, []),
     "toda_bn2d_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp, C.c_uint, _vp]),

@@ -834,6 +834,12 @@ def run_dense_sequential(seq, x):
             x = conv3x3(x, mods[i + 1].weight, mods[i + 1].bias)      # ZeroPad2d(1) + Conv2d(3x3, padding 0) = one padded convolution
             i += 2
             continue
+        elif (type(m) is torch.nn.ZeroPad2d and tuple(m.padding) == (1, 1, 1, 1) and i + 1 < len(mods) and conv3x3s2_supported(x, mods[i + 1])):
+            x = conv3x3s2(x, mods[i + 1].weight, mods[i + 1].bias)    # the stride-2 head of a block
+            i += 2
+            continue
+        elif deconv_supported(x, m):
+            x = deconv(x, m.weight, m.stride[0], m.bias)              # up-sampling deblock (kernel = stride)
         elif type(m) is torch.nn.Conv2d and m.padding == (1, 1) and conv3x3_supported(x, m):
             x = conv3x3(x, m.weight, m.bias)
         elif type(m) is torch.nn.BatchNorm2d and bn2d_supported(x, m):
@@ -941,6 +947,113 @@ def conv3x3_wgrad(x, gy, wshape):
 
 def conv3x3(x, weight, bias=None):
     return _Conv3x3.apply(x, weight, bias)
+
+
+# ------------------------------------------- stride-2 3x3 convolution and the transposed-convolution deblocks of the BEV neck
+class _Conv3x3S2(torch.autograd.Function):
+    """ZeroPad2d(1) + Conv2d(3, stride 2, padding 0) = conv2d(x, weight, stride 2, padding 1) on even maps
+    (reference base_bev_backbone.py:32-36), forward / data gradient / weight gradient through toda_conv3x3s2_*."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = L.load()
+        x, weight = x.contiguous(), weight.contiguous()
+        b, cin, h, w = x.shape
+        cout = weight.shape[0]
+        y = torch.empty((b, cout, h // 2, w // 2), dtype=torch.float32, device=x.device)
+        L.check(lib.toda_conv3x3s2_fwd(L.ptr(x), L.ptr(weight), b, cin, cout, h, w, L.ptr(y), L.stream()), "toda_conv3x3s2_fwd")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        lib = L.load()
+        gy = gy.contiguous()
+        b, cin, h, w = x.shape
+        cout = weight.shape[0]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            L.check(lib.toda_conv3x3s2_dgrad(L.ptr(gy), L.ptr(weight), b, cin, cout, h, w, L.ptr(gx), L.stream()), "toda_conv3x3s2_dgrad")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            nb = lib.toda_conv3x3s2_wgrad_workspace_bytes(b, cin, cout, h, w)
+            ws = torch.empty((max(nb, 16),), dtype=torch.uint8, device=x.device)
+            L.check(lib.toda_conv3x3s2_wgrad(L.ptr(x), L.ptr(gy), b, cin, cout, h, w, L.ptr(gw), L.ptr(ws), nb, L.stream()), "toda_conv3x3s2_wgrad")
+        return gx, gw
+
+
+DENSE_GEMM = _os.environ.get("TODA_DENSE_GEMM", "1") == "1"      # 0: the stride-2 conv and the deblocks back on torch (MIOpen / rocBLAS) - A/B knob
+
+
+def conv3x3s2_supported(x, conv):
+    """nn.Conv2d(3x3, stride 2, padding 0) behind a ZeroPad2d(1) (the caller checks the pad), fp32 NCHW on the GPU, even H and W."""
+    if not DENSE_GEMM or DENSE_CONV != "winograd" or type(conv) is not torch.nn.Conv2d or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return False
+    if conv.kernel_size != (3, 3) or conv.stride != (2, 2) or conv.dilation != (1, 1) or conv.groups != 1 or conv.padding != (0, 0):
+        return False
+    if conv.padding_mode != "zeros" or conv.in_channels != x.shape[1]:
+        return False
+    b, c, h, w = x.shape
+    return bool(L.load().toda_conv3x3s2_supported(b, conv.in_channels, conv.out_channels, h, w))
+
+
+def conv3x3s2(x, weight, bias=None):
+    y = _Conv3x3S2.apply(x, weight)
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+
+class _Deconv(torch.autograd.Function):
+    """ConvTranspose2d(Cin, Cout, kernel = stride = s), s in {1, 2} (reference base_bev_backbone.py:47-66): one GEMM per direction;
+    the pixel shuffle of s = 2 is the store of the forward GEMM and the gather of the backward ones (toda_deconv_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s):
+        lib = L.load()
+        x, weight = x.contiguous(), weight.contiguous()
+        b, cin, h, w = x.shape
+        cout = weight.shape[1]
+        y = torch.empty((b, cout, h * s, w * s), dtype=torch.float32, device=x.device)
+        L.check(lib.toda_deconv_fwd(L.ptr(x), L.ptr(weight), b, cin, cout, h, w, s, L.ptr(y), L.stream()), "toda_deconv_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.s = s
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        lib = L.load()
+        gy = gy.contiguous()
+        b, cin, h, w = x.shape
+        cout, s = weight.shape[1], ctx.s
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            L.check(lib.toda_deconv_dgrad(L.ptr(gy), L.ptr(weight), b, cin, cout, h, w, s, L.ptr(gx), L.stream()), "toda_deconv_dgrad")
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            nb = lib.toda_deconv_wgrad_workspace_bytes(b, cin, cout, h, w, s)
+            ws = torch.empty((max(nb, 16),), dtype=torch.uint8, device=x.device)
+            L.check(lib.toda_deconv_wgrad(L.ptr(x), L.ptr(gy), b, cin, cout, h, w, s, L.ptr(gw), L.ptr(ws), nb, L.stream()), "toda_deconv_wgrad")
+        return gx, gw, None
+
+
+def deconv_supported(x, m):
+    """nn.ConvTranspose2d with kernel = stride in {1, 2}, no padding / output padding / dilation / groups, fp32 NCHW on the GPU."""
+    if not DENSE_GEMM or DENSE_CONV != "winograd" or type(m) is not torch.nn.ConvTranspose2d or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return False
+    s = m.stride[0]
+    if m.kernel_size != (s, s) or m.stride != (s, s) or s not in (1, 2) or m.padding != (0, 0) or m.output_padding != (0, 0):
+        return False
+    if m.dilation != (1, 1) or m.groups != 1 or m.in_channels != x.shape[1]:
+        return False
+    return True
+
+
+def deconv(x, weight, s, bias=None):
+    y = _Deconv.apply(x, weight, int(s))
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 
 # ---------------------------------------------------- narrow-output 3x3 convolutions (last layer of the head branches)

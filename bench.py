@@ -352,9 +352,22 @@ def run_gpu(args, rank, world, device):
     t0 = time.perf_counter()
     cpu0 = time.thread_time()
     marks[0].record()
+    # next to each step's GPU time (event to event): the host time to enqueue it and the allocator's counters, so that a slow step
+    # can be told apart as host-side (long enqueue, GPU starved), allocator-side (a device allocation or a retry inside the step)
+    # or GPU-side (neither) - VERDICT r2 item 5
+    host_step_s, alloc_marks = [], []
+
+    def alloc_counters():
+        st = torch.cuda.memory_stats(device)
+        return (int(st.get("num_device_alloc", 0)), int(st.get("num_alloc_retries", 0)))
+
+    alloc_marks.append(alloc_counters())
     for k, it in enumerate(range(args.warmup, args.warmup + args.steps)):
+        th = time.perf_counter()
         loss = step(it)
         marks[k + 1].record()        # no sync: the median step time is read after the clock has stopped
+        host_step_s.append(time.perf_counter() - th)
+        alloc_marks.append(alloc_counters())
     t_issued = time.perf_counter() - t0      # host wall time to ENQUEUE the K steps (includes waiting at the two host syncs per step)
     cpu_busy = time.thread_time() - cpu0     # CPU time of this thread over the same span: what the host really WORKS per step
     torch.cuda.synchronize()
@@ -412,7 +425,10 @@ def run_gpu(args, rank, world, device):
     if world > 1 and not fwd_only:
         comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3)
     return {"elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
-            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows, "issue_s": t_issued, "cpu_s": cpu_busy}
+            "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows, "issue_s": t_issued, "cpu_s": cpu_busy,
+            "host_step_ms": [t * 1e3 for t in host_step_s],
+            "device_allocs": [alloc_marks[k + 1][0] - alloc_marks[k][0] for k in range(args.steps)],
+            "alloc_retries": [alloc_marks[k + 1][1] - alloc_marks[k][1] for k in range(args.steps)]}
 
 
 # (gathered channels, produced channels, K) of a dominant launch shape -> (PMC summary under profiles/, kernel instantiation,
@@ -729,6 +745,9 @@ def main(argv=None):
         step_ms = res["step_ms"]
         if os.environ.get("TODA_BENCH_STEP_MS"):      # every timed step's GPU time (event to event), to look at outliers
             print("[step_ms] " + " ".join(f"{t:.2f}" for t in step_ms), file=sys.stderr)
+            print("[host_enqueue_ms] " + " ".join(f"{t:.2f}" for t in res["host_step_ms"]), file=sys.stderr)
+            print("[device_allocs] " + " ".join(str(v) for v in res["device_allocs"]) + "  [alloc_retries] " +
+                  " ".join(str(v) for v in res["alloc_retries"]), file=sys.stderr)
         line = {
             "metric": "LiDAR training samples/sec" if args.workload != "c2" else "LiDAR backbone forward samples/sec", "value": round(total_samples / res["elapsed"], 3),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -739,7 +758,10 @@ def main(argv=None):
                        "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4),
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
                        "alloc_retries": int(torch.cuda.memory_stats(device).get("num_alloc_retries", 0)),
-                       "reserved_gib": round(torch.cuda.memory_reserved(device) / 2 ** 30, 2)},
+                       "reserved_gib": round(torch.cuda.memory_reserved(device) / 2 ** 30, 2),
+                       "device_allocs_in_timed_steps": int(sum(res["device_allocs"])),
+                       "slowest_step_ms": round(max(step_ms), 3) if step_ms else None,
+                       "slowest_step_host_enqueue_ms": round(res["host_step_ms"][int(np.argmax(step_ms))], 3) if step_ms else None},
             # per-step GPU time between events recorded at the step boundaries of rank 0 (no sync inside the region)
             "host_issue_ms_per_step": round(res["issue_s"] / args.steps * 1e3, 3),
             "host_cpu_ms_per_step": round(res["cpu_s"] / args.steps * 1e3, 3),

@@ -446,8 +446,11 @@ HALO = _os_early.environ.get("TODA_HALO", "0") == "1"
 HALO_MIN_ROWS = int(_os_early.environ.get("TODA_HALO_MIN_ROWS", "32768"))
 
 
+HALO_CHANNELS = {int(v) for v in _os_early.environ.get("TODA_HALO_CHANNELS", "32,64").split(",") if v}
+
+
 def halo_supported(c_gather, c_produce, k_vol):
-    return HALO and bool(L.load().toda_halo_supported(int(c_gather), int(c_produce), int(k_vol)))
+    return HALO and int(c_gather) in HALO_CHANNELS and bool(L.load().toda_halo_supported(int(c_gather), int(c_produce), int(k_vol)))
 
 
 def build_halo_plan(rb, indices, batch, shape, channels):

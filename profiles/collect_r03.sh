@@ -58,13 +58,14 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCP_LATENCY TA_BUSY TA_TOTAL_WAVEFRONTS" \
          "TCC_HIT TCC_MISS TCC_REQ TCP_PENDING_STALL_CYCLES TCP_READ_TAGCONFLICT_STALL_CYCLES" \
          "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA" \
-         "GRBM_GUI_ACTIVE"; do
+         "GRBM_GUI_ACTIVE" \
+         "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"; do
   i=$((i+1))
   rm -rf /tmp/r03_st_$i
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r03_st_$i -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/r03_st_$i.log 2>&1
   echo "  set $i done"
 done
-ST=$(find /tmp/r03_st_* /tmp/r03_pmc_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv")
+ST=$(find /tmp/r03_st_* -name "*counter_collection.csv")
 python3 $R/toda_amd/tools/pmc_summary.py gather_gemm_lds_kernel $O/r03_pmc_stall_gather_gemm.json $ST > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py wgrad_kernel $O/r03_pmc_stall_sparse_wgrad.json $ST > /dev/null
 fi

@@ -209,6 +209,15 @@ size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout
 int toda_spconv_wgrad(const float* in, int n_in, const float* dout, const int32_t* nbr,
                       int n_out, int k_vol, int cin, int cout, float* dw,
                       void* ws, size_t ws_bytes, void* stream);
+/* The same contraction with the output-gradient rows of a 128-row tile staged in LDS once for all 27 offsets (one third of
+ * the HBM traffic of toda_spconv_wgrad on the 32 -> 32 level; measured slower in the step, so the host picks it only on request:
+ * profiles/r03_wgrad_tiled.md).  K = 27, channels in {32, 64} with cin <= cout, 0 < rows < 2^23; same summation structure
+ * (per-workgroup slabs + fixed-order fold): deterministic. */
+int toda_spconv_wgrad_tiled_supported(int n_in, int n_out, int k_vol, int cin, int cout);
+size_t toda_spconv_wgrad_tiled_workspace_bytes(int n_out, int cin, int cout);
+int toda_spconv_wgrad_tiled(const float* in, int n_in, const float* dout, const int32_t* nbr,
+                            int n_out, int k_vol, int cin, int cout, float* dw,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* SparseConvTensor.dense() as used by HeightCompression
  * (pcdet/models/backbones_2d/map_to_bev/height_compression.py:21-23):

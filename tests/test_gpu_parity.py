@@ -277,6 +277,43 @@ def test_strided_conv_fwd_dgrad_wgrad(ks, st, pd, cin, cout):
     np.testing.assert_allclose(wt.grad.cpu().numpy(), dw0, rtol=1e-4, atol=1e-4 * np.abs(dw0).max())
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
+def test_dout_stationary_wgrad_matches_oracle(cin, cout):
+    """toda_spconv_wgrad_tiled (wgrad_tile_kernel; opt-in, TODA_WG_TILE=1; K = 27, 32 / 64 channels: the output-gradient tile staged in
+    LDS for all 27 offsets, three or four offsets per wave, queue tails carried across tiles, ring of in-flight gathers) against the oracle's per-offset gather -> GEMM and a float64
+    contraction on the device; a row count that is no multiple of the 128-row tile; bit-reproducible (slabs, no atomics)."""
+    from toda_amd import ops
+
+    shape, batch = [21, 260, 250], 2
+    idx, feat = H.clustered_sparse(batch, shape, 40000, cin, seed=cin + 7 * cout)
+    n = len(idx)
+    assert n >= 65536 and n % 128 != 0, n
+    rng = np.random.default_rng(4)
+    g = rng.standard_normal((n, cout)).astype(np.float32)
+    nbr0, _ = O.rulebook_subm(idx, batch, shape)
+    wshape = (cout, 3, 3, 3, cin)
+    dw0 = O.spconv_wgrad(feat, g, nbr0, wshape)
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    assert np.array_equal(rb.nbr_fwd.cpu().numpy(), nbr0)
+    with H.abi_calls("toda_spconv_wgrad_tiled", "toda_spconv_wgrad") as calls:
+        dw = ops.wgrad(dev(feat), dev(g), rb.nbr_fwd, wshape, tiled=True)
+    assert calls["toda_spconv_wgrad_tiled"] == 1 and calls["toda_spconv_wgrad"] == 0
+    plain = ops.wgrad(dev(feat), dev(g), rb.nbr_fwd, wshape, tiled=False)      # the per-(chunk, offset) kernel on the same inputs
+    assert float((dw - plain).abs().max()) <= 2e-6 * float(plain.abs().max())
+    scale = np.abs(dw0).max()
+    np.testing.assert_allclose(dw.cpu().numpy(), dw0, rtol=1e-4, atol=1e-4 * scale)
+    # float64 contraction on the device, offset by offset
+    x64, g64, nb = dev(feat).double(), dev(g).double(), rb.nbr_fwd.long()
+    ref = torch.zeros((cout, 27, cin), dtype=torch.float64, device="cuda")
+    for k in range(27):
+        m = nb[k] >= 0
+        ref[:, k, :] = g64[m].T @ x64[nb[k][m]]
+    err = float((dw.double().reshape(cout, 27, cin) - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    assert torch.equal(ops.wgrad(dev(feat), dev(g), rb.nbr_fwd, wshape, tiled=True), dw)
+    assert not ops.L.load().toda_spconv_wgrad_tiled_supported(n, n, 27, 64, 32) and not ops.L.load().toda_spconv_wgrad_tiled_supported(n, n, 3, 64, 64)
+
+
 def test_conv_linearity_and_determinism_at_scale():
     """Size-independent properties at a Waymo-like row count (no oracle run needed)."""
     from toda_amd import ops

@@ -1580,6 +1580,336 @@ wgrad_reduce_kernel(const float* __restrict__ slab, int chunks, long long elems,
     dw[e] = s;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// wgrad, dout-stationary form for the wide K = 27 layers (32 -> 32, 64 -> 64, 32 -> 64).  In wgrad_kernel a
+// workgroup is one (row chunk, offset): the 27 offset-blocks of a chunk each fetch the chunk's dout rows again, and every
+// (in, out) pair costs one row of each table through L2 - (cin + cout) * 4 bytes for 2 * cin * cout FLOP, 8 (32 -> 32) or 16
+// (64 -> 64) FLOP per L2 byte: PMC 1.03 GB from HBM / 2.4 GB through L2 per launch of the 32 -> 32 layer at 682 k rows against
+// 0.25 GB algorithmic, MFMA pipe 50 % busy, 70 % of the wave cycles in s_waitcnt.  Here a workgroup owns whole 128-row tiles for
+// ALL 27 offsets: the tile's dout rows are staged in LDS once (one contiguous 16 / 32 KiB copy) and serve every pair of the
+// tile as the B operand; only the gathered input rows still come through L2, half of the former traffic.  8 waves, wave w
+// owns three or four fixed offsets (WT_OFF: dealt by pair density so that the waves of a tile finish together) and keeps their
+// MTB x NTB accumulator tiles for the whole launch.  Per tile a wave first compacts the valid pairs of all its offsets into
+// per-(wave, offset) LDS queues (ballot + prefix popcount), then runs the full 16-pair rounds of all its queues as ONE stream in
+// which the input-row gathers of round r + 1 are issued before the MFMAs of round r (in wgrad_kernel a round is load -> wait ->
+// multiply, and only other waves cover the wait).  A queue's tail (< 16 pairs) is carried into the next tile - its B rows stay valid
+// because the tiles rotate through THREE LDS buffers (the one being filled for t + 1, the current one, the previous one); a
+// tail that has seen no full round for a whole tile is flushed as a partial round before its buffer can be refilled.  64 input
+// channels are split over two workgroups (contiguous 128-byte half rows each): 4 offsets x 2 x 4 tiles = 128 accumulator registers.
+// Tiles are dealt so that each XCD walks one contiguous row range with all its workgroups side by side (neighbouring tiles
+// gather overlapping input rows: they meet in that XCD's L2).  Slabs + wgrad_reduce_kernel as before: deterministic.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef TODA_WT_DEPTH
+#define TODA_WT_DEPTH 2
+#endif
+constexpr int WT_DEPTH = TODA_WT_DEPTH;      // rounds of input-row gathers in flight per wave
+constexpr int WT_WAVES = 8, WT_SLOTS = 4, WT_BLOCK = WT_WAVES * 64, WT_R = 128, WT_QCAP = WT_R + 16, WT_K = 27;
+// offsets of a wave (-1: empty slot): longest-processing-time deal of the per-offset pair counts of the C3 levels (centre 1.0;
+// level 2: dz = 0 ring 0.5-0.6, dz = +-1 0.3-0.5; levels 3, 4: dz = 0 ring 0.85, dz = +-1 0.45): heaviest wave 1.10x the mean
+__device__ __constant__ signed char WT_OFF[2][WT_WAVES][WT_SLOTS] = {
+    {{13, 0, 2, -1}, {10, 1, 3, 6}, {12, 5, 7, 8}, {14, 19, 21, 18}, {16, 23, 25, -1}, {4, 9, 20, -1}, {22, 11, 24, -1}, {15, 17, 26, -1}},
+    {{13, 19, 8, -1}, {10, 1, 21, 24}, {12, 3, 23, 26}, {14, 5, 25, -1}, {16, 7, 0, 20}, {9, 17, 18, -1}, {11, 4, 2, -1}, {15, 22, 6, -1}}};
+
+template <int MTB, int NTB>
+__global__ void __launch_bounds__(WT_BLOCK, NTB <= 2 ? 2 : 1)
+wgrad_tile_kernel(const float* __restrict__ in, int n_in, int cin, const float* __restrict__ dout, const int* __restrict__ nbr,
+                  int n_out, int n_tiles, int G, int nsub, int profile, float* __restrict__ slab) {
+    constexpr int CO = 16 * NTB, TILE_F = WT_R * CO;
+    constexpr int FILL = (TILE_F / 4 + WT_BLOCK - 1) / WT_BLOCK;     // 16-byte pieces per thread and tile
+    __shared__ float tile[3 * TILE_F];
+    // queue entry: (input row << 9) | row of the 3 x 128-row ring (n_in < 2^23, checked by the host)
+    __shared__ unsigned q_all[WT_WAVES][WT_SLOTS][WT_QCAP];
+    __shared__ unsigned rl[WT_WAVES][64];     // padded round stream of the wave: index of the round's first queue entry in q_all[wave], ~0: empty round
+    static_assert(MTB == 2, "8-byte half-row gathers");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ii = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int sub = l % nsub, wl = l / nsub, gx = G >> 3;
+    const int gid = xcd * gx + wl;                                   // slab of this workgroup (both channel halves share it)
+    const int t8 = (n_tiles + 7) >> 3;
+    const int t_end = min((xcd + 1) * t8, n_tiles);
+    const int ci_base = sub * 16 * MTB;
+    int koff[WT_SLOTS];
+#pragma unroll
+    for (int j = 0; j < WT_SLOTS; ++j) koff[j] = __builtin_amdgcn_readfirstlane((int)WT_OFF[profile][wv][j]);
+
+    f32x4 acc[WT_SLOTS][MTB][NTB];
+#pragma unroll
+    for (int j = 0; j < WT_SLOTS; ++j)
+#pragma unroll
+        for (int m = 0; m < MTB; ++m)
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) acc[j][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int qn[WT_SLOTS] = {0, 0, 0, 0};
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cin * 4u);
+    const __amdgpu_buffer_rsrc_t dout_rsrc = table_rsrc(dout, (unsigned)n_out * (unsigned)CO * 4u);
+    const __amdgpu_buffer_rsrc_t id_rsrc = table_rsrc(reinterpret_cast<const float*>(nbr), (unsigned)((size_t)WT_K * n_out * 4u));
+    // the same descriptor as in_rsrc, as four scalar words for the inline-asm loads of the round stream (GFX9 layout: base[47:0],
+    // stride 0, num_records in bytes, word 3 as table_rsrc)
+    const unsigned long long in_addr = (unsigned long long)in;
+    const u32x4 in_desc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)in_addr),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(in_addr >> 32) & 0xFFFFu)),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)n_in * (unsigned)cin * 4u)), 0x00020000u};
+
+    // A operands of one round: queue entries [d, d + 16), 4 pairs per MFMA step; entries >= limit: zeros
+    auto gather = [&](const unsigned* q, int d, int limit, float (&a)[4][MTB]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p = d + 4 * t + g;
+            const bool ok = p < limit;
+            const unsigned e = q[ok ? p : d];
+            const unsigned ia = ((e >> 9) * (unsigned)cin + (unsigned)(ci_base + MTB * ii)) * 4u;
+            if constexpr (MTB == 2) {
+                const f32x2w v = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, ok ? ia : OOB, 0, 0));
+                a[t][0] = v[0], a[t][1] = v[1];
+            } else {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? ia : OOB, 0, 0));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[t][m] = v[m];
+            }
+        }
+    };
+    // B operands from the LDS ring + the MFMAs of the round
+    auto multiply = [&](const unsigned* q, int d, int limit, const float (&a)[4][MTB], f32x4 (&ac)[MTB][NTB]) {
+        float b[4][NTB];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p = d + 4 * t + g;
+            const bool ok = p < limit;
+            const float* bp = tile + (q[ok ? p : d] & 511u) * CO + NTB * ii;
+            if constexpr (NTB == 2) {
+                const f32x2w v = *reinterpret_cast<const f32x2w*>(bp);
+                b[t][0] = ok ? v[0] : 0.f, b[t][1] = ok ? v[1] : 0.f;
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bp);
+#pragma unroll
+                for (int n = 0; n < 4; ++n) b[t][n] = ok ? v[n] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n) ac[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][m], b[t][n], ac[m][n], 0, 0, 0);
+    };
+
+    // dout rows of tile t -> registers (out-of-range pieces of the last tile: zeros) / registers -> LDS buffer
+    f32x4 stage[FILL];
+    auto fetch_tile = [&](int t) {
+#pragma unroll
+        for (int f = 0; f < FILL; ++f) {
+            const int piece = tid + f * WT_BLOCK;
+            const unsigned off = ((unsigned)t * (unsigned)TILE_F + (unsigned)piece * 4u) * 4u;
+            stage[f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, (piece < TILE_F / 4 && t < t_end) ? off : OOB, 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int f = 0; f < FILL; ++f) {
+            const int piece = tid + f * WT_BLOCK;
+            if (piece < TILE_F / 4) *reinterpret_cast<f32x4*>(tile + buf * TILE_F + piece * 4) = stage[f];
+        }
+    };
+    // ids of tile t for this wave's offsets, two batches of 64 rows each (-1: no neighbour / past the end / empty slot)
+    int ids[WT_SLOTS][2];
+    auto fetch_ids = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < WT_SLOTS; ++j)
+#pragma unroll
+            for (int bt = 0; bt < 2; ++bt) {
+                const int o = t * WT_R + bt * 64 + lane;
+                const bool live = koff[j] >= 0 && t < t_end && o < n_out;
+                const int v = __builtin_bit_cast(int, __builtin_amdgcn_raw_buffer_load_b32(
+                    id_rsrc, live ? (unsigned)(((size_t)koff[j] * n_out + o) * 4u) : OOB, 0, 0));
+                ids[j][bt] = live ? v : -1;
+            }
+    };
+
+    int t = xcd * t8 + wl;
+    if (t < t_end) {
+        fetch_tile(t);
+        fetch_ids(t);
+        store_tile(0);
+    }
+    int buf = 0;
+    for (; t < t_end; t += gx) {
+        __syncthreads();                 // buffer `buf` complete; every wave has left the previous tile (its carry-overs included)
+        // 1. compact this tile's pairs behind the carried tails
+        int carried[WT_SLOTS];
+#pragma unroll
+        for (int j = 0; j < WT_SLOTS; ++j) {
+            carried[j] = qn[j];
+            unsigned* q = q_all[wv][j];
+#pragma unroll
+            for (int bt = 0; bt < 2; ++bt) {
+                const int i = ids[j][bt];
+                const unsigned long long vote = __ballot(i >= 0);
+                if (i >= 0) q[qn[j] + __popcll(vote & ((1ull << lane) - 1))] = ((unsigned)i << 9) | (unsigned)(buf * WT_R + bt * 64 + lane);
+                qn[j] += __popcll(vote);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int tn = t + gx;
+        constexpr bool EARLY = false;     // the next tile's dout rows and ids in flight under this tile's rounds: 16 + 8 registers that
+                                          // the 64-channel form (128 accumulators + the ring) does not have
+        if constexpr (EARLY) {
+            fetch_tile(tn);
+            fetch_ids(tn);
+        }
+        // 2. the full 16-pair rounds of all slots as ONE stream r = 0 .. r_tot - 1 (slot-major).  The input-row gathers of round
+        //    r + WT_DEPTH are issued when round r has been multiplied, WT_DEPTH - 1 rounds of loads stay in flight behind the one a
+        //    round waits for (vmcnt is counted by hand: the loads are inline asm, hipcc does not see them and cannot merge their
+        //    waits with anything; past the end of the stream the same four loads go to an out-of-range offset - no memory access -
+        //    so that the count is the same on every path).  Ring positions are static (the stream is walked WT_DEPTH rounds per
+        //    loop iteration), the slot of a round is a wave-uniform switch around the MFMAs.
+        //    Each slot's rounds are padded to a multiple of WT_DEPTH with empty rounds (dummy loads, no MFMAs), so a round's ring
+        //    position is its index modulo WT_DEPTH in every slot and both the ring position and the accumulator set are static.
+        int rj[WT_SLOTS], base[WT_SLOTS + 1];
+        base[0] = 0;
+#pragma unroll
+        for (int j = 0; j < WT_SLOTS; ++j) {
+            rj[j] = qn[j] >> 4;
+            base[j + 1] = base[j] + (rj[j] + WT_DEPTH - 1) / WT_DEPTH * WT_DEPTH;
+        }
+        const int s_tot = base[WT_SLOTS];            // padded stream length (<= 4 x 12)
+        {
+            int jj = 0;
+#pragma unroll
+            for (int j = 1; j < WT_SLOTS; ++j)
+                if (lane >= base[j]) jj = j;
+            int idx = lane - base[0];
+#pragma unroll
+            for (int j = 1; j < WT_SLOTS; ++j)
+                if (jj == j) idx = lane - base[j];
+            int rjj = rj[0];
+#pragma unroll
+            for (int j = 1; j < WT_SLOTS; ++j)
+                if (jj == j) rjj = rj[j];
+            rl[wv][lane] = (lane < s_tot && idx < rjj) ? ((unsigned)(jj * WT_QCAP + (idx << 4))) : 0xFFFFFFFFu;
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x2w ring_a[WT_DEPTH][4];
+        unsigned ring_e[WT_DEPTH][4];
+        auto issue = [&](int sidx, f32x2w (&ra)[4], unsigned (&re)[4]) {
+            const unsigned ent = sidx < 64 ? rl[wv][sidx] : 0xFFFFFFFFu;
+            const bool live = ent != 0xFFFFFFFFu;
+            const unsigned* q = &q_all[wv][0][0] + (live ? ent : 0u);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const unsigned e = q[4 * tt + g];
+                re[tt] = e;
+                const unsigned ia = live ? ((e >> 9) * (unsigned)cin + (unsigned)(ci_base + 2 * ii)) * 4u : OOB;
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(ra[tt]) : "v"(ia), "s"(in_desc) : "memory");
+            }
+        };
+        auto mult = [&](f32x2w (&ra)[4], const unsigned (&re)[4], f32x4 (&ac)[MTB][NTB]) {
+            float bb[4][NTB];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const float* bp = tile + (re[tt] & 511u) * CO + NTB * ii;
+                if constexpr (NTB == 2) {
+                    const f32x2w v = *reinterpret_cast<const f32x2w*>(bp);
+                    bb[tt][0] = v[0], bb[tt][1] = v[1];
+                } else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(bp);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) bb[tt][n] = v[n];
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n) ac[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[tt][m], bb[tt][n], ac[m][n], 0, 0, 0);
+        };
+        if (s_tot > 0) {
+#pragma unroll
+            for (int pp = 0; pp < WT_DEPTH; ++pp) issue(pp, ring_a[pp], ring_e[pp]);
+#pragma unroll
+            for (int j = 0; j < WT_SLOTS; ++j) {
+                for (int i0 = 0; i0 < rj[j]; i0 += WT_DEPTH) {
+#pragma unroll
+                    for (int pp = 0; pp < WT_DEPTH; ++pp) {
+                        // the oldest round of the ring has landed when at most (WT_DEPTH - 1) x 4 younger loads are outstanding
+                        asm volatile("s_waitcnt vmcnt(%4)"
+                                     : "+v"(ring_a[pp][0]), "+v"(ring_a[pp][1]), "+v"(ring_a[pp][2]), "+v"(ring_a[pp][3])
+                                     : "n"((WT_DEPTH - 1) * 4));
+                        if (i0 + pp < rj[j]) mult(ring_a[pp], ring_e[pp], acc[j]);
+                        issue(base[j] + i0 + pp + WT_DEPTH, ring_a[pp], ring_e[pp]);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy loads behind the end of the stream
+        }
+        if constexpr (!EARLY) {
+            fetch_tile(tn);
+            fetch_ids(tn);
+        }
+        // 3. tails
+#pragma unroll
+        for (int j = 0; j < WT_SLOTS; ++j) {
+            unsigned* q = q_all[wv][j];
+            const int done = rj[j] << 4;
+            const int left = qn[j] - done;
+            if (done == 0 && carried[j] > 0) {
+                // the tail has met no full round for a whole tile and holds pairs of the PREVIOUS tile: flush it as a partial round
+                float a_fl[4][MTB];
+                gather(q, 0, left, a_fl);
+                multiply(q, 0, left, a_fl, acc[j]);
+                qn[j] = 0;
+            } else {
+                if (done > 0 && left > 0) {      // move the tail (< 16 entries) to the front of the queue
+                    unsigned te = 0;
+                    if (lane < left) te = q[done + lane];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < left) q[lane] = te;
+                }
+                qn[j] = left;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+        store_tile(buf);                 // tile t + gx -> the buffer last read two tiles ago
+    }
+#pragma unroll
+    for (int j = 0; j < WT_SLOTS; ++j)
+        if (qn[j] > 0) {
+            float a_fl[4][MTB];
+            gather(q_all[wv][j], 0, qn[j], a_fl);
+            multiply(q_all[wv][j], 0, qn[j], a_fl, acc[j]);
+        }
+
+    // D: col = lane & 15 -> cout, row = 4 g + reg -> cin (channel interleave MTB / NTB inside this workgroup's channel block)
+    float* dst = slab + (size_t)gid * CO * WT_K * cin;
+#pragma unroll
+    for (int j = 0; j < WT_SLOTS; ++j) {
+        if (koff[j] < 0) continue;
+#pragma unroll
+        for (int m = 0; m < MTB; ++m)
+#pragma unroll
+            for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int ci = ci_base + MTB * (4 * g + reg) + m;
+                    const int co = NTB * ii + n;
+                    dst[((size_t)co * WT_K + koff[j]) * cin + ci] = acc[j][m][n][reg];
+                }
+    }
+}
+
+// workgroups (= slabs) per channel block of the dout-stationary wgrad: two (32-channel dout) or one per CU
+static int wgrad_tile_groups(int n_out, int cin, int cout) {
+    static const int env_g = getenv("TODA_WG_TILE_GROUPS") ? atoi(getenv("TODA_WG_TILE_GROUPS")) : 0;
+    const int nsub = cin / (cout == 64 ? 32 : cin);   // 64 output channels: input channels in blocks of 32
+    int G = env_g > 0 ? env_g : (cout == 32 ? 512 : 256) / nsub;
+    const int tiles = (n_out + WT_R - 1) / WT_R;
+    while (G > 8 && G > tiles) G -= 8;
+    return (G + 7) / 8 * 8;
+}
+
 // Row chunks per offset: every (chunk, offset) pair is a workgroup and a slab the reduce kernel reads back.  Measured on the
 // C3 / C5 levels: the >= 64-channel kernels (4 waves / SIMD resident) run best with at most 48 chunks (64x64 @ 389k rows 0.606 ->
 // 0.587 ms, @ 227k 0.373 -> 0.338 ms), the 32-channel ones (7 waves / SIMD) with up to 144 (32x32 @ 682k 0.418 -> 0.388 ms).
@@ -2227,6 +2557,47 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
 #undef WG_ROW
 #undef WG
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slab, chunks, elems, dw);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+// dout-stationary wgrad (wgrad_tile_kernel): K = 27, 32 or 64 channels on both sides with cin <= cout, input rows < 2^23
+extern "C" int toda_spconv_wgrad_tiled_supported(int n_in, int n_out, int k_vol, int cin, int cout) {
+    return k_vol == WT_K && n_out > 0 && n_in > 0 && n_in < (1 << 23) && (cin == 32 || cin == 64) && (cout == 32 || cout == 64) && cin <= cout &&
+           (unsigned long long)n_in * cin * 4ull < 0xFFFFFFF0ull && (unsigned long long)n_out * cout * 4ull < 0xFFFFFFF0ull;
+}
+
+extern "C" size_t toda_spconv_wgrad_tiled_workspace_bytes(int n_out, int cin, int cout) {
+    if (!((cin == 32 || cin == 64) && (cout == 32 || cout == 64) && cin <= cout)) return 0;
+    return align_up((size_t)wgrad_tile_groups(n_out, cin, cout) * WT_K * cin * cout * sizeof(float), 256);
+}
+
+extern "C" int toda_spconv_wgrad_tiled(const float* in, int n_in, const float* dout, const int32_t* nbr, int n_out, int k_vol,
+                                       int cin, int cout, float* dw, void* ws, size_t ws_bytes, void* stream) {
+    TODA_CHECK_ARG(toda_spconv_wgrad_tiled_supported(n_in, n_out, k_vol, cin, cout),
+                   "wgrad_tiled: needs K = 27, channels in {32, 64} with cin <= cout, 0 < rows < 2^23 (got K %d, %d -> %d, %d / %d rows)", k_vol, cin,
+                   cout, n_in, n_out);
+    hipStream_t s = (hipStream_t)stream;
+    const long long elems = (long long)cout * k_vol * cin;
+    const int groups = wgrad_tile_groups(n_out, cin, cout);
+    const size_t need = (size_t)groups * elems * sizeof(float);
+    if (ws_bytes < need) {
+        set_error("wgrad_tiled: workspace %zu < required %zu", ws_bytes, need);
+        return TODA_EWORKSPACE;
+    }
+    const int n_tiles = (n_out + WT_R - 1) / WT_R;
+    const int nsub = cin / (cout == 64 ? 32 : cin);
+    float* const slabs = (float*)ws;
+    const dim3 grid(groups * nsub);
+    static const int env_prof = getenv("TODA_WG_TILE_PROFILE") ? atoi(getenv("TODA_WG_TILE_PROFILE")) : -1;
+    const int profile = env_prof >= 0 ? (env_prof & 1) : (cin == 32 ? 0 : 1);
+    if (cout == 32)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_tile_kernel<2, 2>), grid, dim3(WT_BLOCK), 0, s, in, n_in, cin, dout, nbr, n_out, n_tiles,
+                           groups, nsub, profile, slabs);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_tile_kernel<2, 4>), grid, dim3(WT_BLOCK), 0, s, in, n_in, cin, dout, nbr, n_out, n_tiles,
+                           groups, nsub, profile, slabs);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slabs, groups, elems, dw);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

@@ -46,6 +46,9 @@ SIGNATURES = {
     "toda_spconv_gather_gemm_halo": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "toda_spconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "toda_spconv_wgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "toda_spconv_wgrad_tiled_supported": (_i, [_i, _i, _i, _i, _i]),
+    "toda_spconv_wgrad_tiled_workspace_bytes": (_sz, [_i, _i, _i]),
+    "toda_spconv_wgrad_tiled": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_sparse_to_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_sparse_to_dense_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_pillar_scatter_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

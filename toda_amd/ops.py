@@ -22,6 +22,7 @@ def grid_size_xyz(pc_range, voxel_size):
 
 
 # ----------------------------------------------------------------------------- voxelisation
+import os as _os
 import os as _os_early
 import time as _time
 
@@ -490,11 +491,26 @@ def gather_gemm_halo(feat, wp, nbr, c_produce, plan, bias=None, want_stats=False
     return (out, sums) if want_stats else out
 
 
-def wgrad(feat, dout, nbr, wshape):
+# dout-stationary wgrad (toda_spconv_wgrad_tiled): opt-in.  Measured on C3 (profiles/r03_wgrad_tiled.md): 32 -> 32 @ 682 k rows
+# 0.298 ms against 0.277, 64 -> 64 @ 389 k rows 0.68 against 0.54; the step 17.63 (32-channel level only) / 18.29 ms against 17.59.
+WGRAD_TILED = _os.environ.get("TODA_WG_TILE", "0") == "1"
+WGRAD_TILED_MIN_ROWS = int(_os.environ.get("TODA_WG_TILE_MIN_ROWS", "65536"))
+
+
+def wgrad(feat, dout, nbr, wshape, tiled=None):
     lib = L.load()
     K, n_out = nbr.shape
     cout, cin = wshape[0], wshape[-1]
     dw = torch.empty(wshape, dtype=torch.float32, device=feat.device)
+    if tiled is None:
+        tiled = WGRAD_TILED and n_out >= WGRAD_TILED_MIN_ROWS and bool(lib.toda_spconv_wgrad_tiled_supported(feat.shape[0], n_out, K, cin, cout))
+    if tiled:
+        ws_bytes = lib.toda_spconv_wgrad_tiled_workspace_bytes(n_out, cin, cout)
+        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=feat.device)
+        rc = lib.toda_spconv_wgrad_tiled(L.ptr(feat), feat.shape[0], L.ptr(dout), L.ptr(nbr), n_out, K, cin, cout, L.ptr(dw),
+                                         L.ptr(ws), ws_bytes, L.stream())
+        L.check(rc, "toda_spconv_wgrad_tiled")
+        return dw
     ws_bytes = lib.toda_spconv_wgrad_workspace_bytes(n_out, K, cin, cout)
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=feat.device)
     rc = lib.toda_spconv_wgrad(L.ptr(feat), feat.shape[0], L.ptr(dout), L.ptr(nbr), n_out, K, cin, cout, L.ptr(dw),
@@ -502,8 +518,6 @@ def wgrad(feat, dout, nbr, wshape):
     L.check(rc, "toda_spconv_wgrad")
     return dw
 
-
-import os as _os
 
 # mask-sorted row order for gather-GEMM: opt-in.  Measured on C3 it LOSES on the SubM layers (64->64 @ 389k rows 0.536 ->
 # 0.562 ms, 32->32 @ 682k 0.321 -> 0.366 ms: rows of a tile are no longer x-neighbours, so their gathers stop sharing

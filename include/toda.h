@@ -259,7 +259,8 @@ int toda_bn_finalize(const double* sums /*[2c] from toda_rows_moments*/, int n, 
                      float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* Backward of the same pair.  stats = [mean | invstd | scale | shift] (4*c floats, as written by
  * toda_bn_finalize into one buffer).  dz = dy * (x*scale+shift > 0) (relu != 0) or dy;
- * sums[0:c] = sum dz = d(beta), sums[c:2c] = sum dz*xhat = d(gamma) (zeroed and filled by the call);
+ * sums[0:c] = sum dz = d(beta), sums[c:2c] = sum dz*xhat = d(gamma) (zeroed and filled by the call); the same 2c values rounded
+ * to float32 follow at ((float*)(sums + 2c))[0:2c] (what an optimizer wants: no conversion pass);
  * dx = gamma * invstd * (dz - sums[0:c]/n - xhat * sums[c:2c]/n), xhat = (x - mean) * invstd. */
 int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma,
                      int n, int c, int relu, double* sums /*[toda_rows_reduce_doubles(n, c)]*/, float* dx,

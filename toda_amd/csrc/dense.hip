@@ -220,8 +220,11 @@ rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict_
 // pass 2: dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) = k1 * (dz - m1 - (x - mu) * k2)
 __global__ void __launch_bounds__(DN_BLOCK)
 rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x, const f32x4* __restrict__ res,
-                         const float* __restrict__ stats, const float* __restrict__ gamma, const double* __restrict__ sums,
+                         const float* __restrict__ stats, const float* __restrict__ gamma, double* __restrict__ sums,
                          long long n4, int c, int n, int relu, f32x4* __restrict__ dx, f32x4* __restrict__ dres) {
+    // the parameter gradients as float32 for the caller (sum dz = d beta, sum dz * xhat = d gamma): written over the per-block
+    // scratch behind the 2c double results, which the fold has finished with
+    if (blockIdx.x == 0 && threadIdx.x < 2 * c) reinterpret_cast<float*>(sums + 2 * c)[threadIdx.x] = (float)sums[threadIdx.x];
     const long long t0 = (long long)blockIdx.x * DN_BLOCK + threadIdx.x;
     const long long stride = (long long)gridDim.x * DN_BLOCK;
     const int ch = (int)((t0 * 4) % c);
@@ -380,7 +383,7 @@ extern "C" int toda_rows_bn_bwd_res(const float* dy, const float* x, const float
     TODA_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= DN_BLOCK / 2 && DN_BLOCK % c == 0,
                    "rows_bn_bwd: channels must be a multiple of 4 dividing 256, <= 128 (got %d)", c);
     if (n <= 0) {
-        TODA_HIP(hipMemsetAsync(sums, 0, 2 * c * sizeof(double), s));
+        TODA_HIP(hipMemsetAsync(sums, 0, 3 * c * sizeof(double), s));      // results + their float32 copy
         return TODA_OK;
     }
     int blocks, rpb;

@@ -559,6 +559,7 @@ class _SparseConv(torch.autograd.Function):
         else:
             out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, order=rb.order_for(rb.nbr_fwd))
         ctx.halo_plan = plan
+        ctx.set_materialize_grads(False)     # the moments output takes no gradient: no zero-filled double tensor per layer and step
         ctx.save_for_backward(features, weight)
         ctx.rb = rb
         ctx.wp_bwd = wp_bwd          # the dgrad operand when the module packed it with the rest of the backbone
@@ -572,6 +573,8 @@ class _SparseConv(torch.autograd.Function):
     def backward(ctx, gout, *unused):
         features, weight = ctx.saved_tensors
         rb = ctx.rb
+        if gout is None:
+            return None, None, None, None, None, None, None
         gout = gout.contiguous()
         gfeat = gw = gb = None
         need_d, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -746,7 +749,7 @@ class _BNRows(torch.autograd.Function):
         rc = L.load().toda_rows_bn_bwd_res(L.ptr(gy), L.ptr(x), L.ptr(residual), L.ptr(stats), L.ptr(gamma), n, c, int(relu),
                                            L.ptr(sums), L.ptr(gx), L.ptr(gres), L.stream())
         L.check(rc, "toda_rows_bn_bwd_res")
-        gs = sums[:2 * c].to(torch.float32)
+        gs = sums[2 * c:3 * c].view(torch.float32)    # the kernel leaves (float)sums[0:2c] behind the double results
         return gx, gs[c:], gs[:c], None, None, None, None, None, None, gres, None
 
 

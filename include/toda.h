@@ -204,6 +204,15 @@ int toda_spconv_gather_gemm_halo(const float* in, int n, int c_gather, const flo
                                  int c_produce, const float* bias, float* out, const void* plan, size_t plan_bytes,
                                  double* sums, size_t sums_doubles, void* stream);
 
+/* The same contraction for the narrow K = 27 layers (<= 32 gathered, <= 32 produced channels: conv_input, the 16-channel SubM
+ * level, the strided 16 -> 32 and their data gradients - reference pcdet/models/backbones_3d/spconv_backbone.py:92-115): per
+ * offset a wave compacts the rows that have a neighbour, so only real pairs are gathered and multiplied.  w is the PLAIN weight
+ * [w_cout][27][w_cin]; transpose / flip_k as in toda_spconv_pack_weight (data gradient: transpose = 1, flip_k = 1 for SubM). */
+int toda_spconv_gather_gemm_compact_supported(int c_gather, int c_produce, int k_vol);
+int toda_spconv_gather_gemm_compact(const float* in, int n_in, int c_gather, const float* w, int w_cout, int w_cin,
+                                    int transpose, int flip_k, const int32_t* nbr, int n_out, int k_vol, int c_produce,
+                                    const float* bias /*nullable*/, float* out, void* stream);
+
 /* dw[co][k][ci] = sum_o in[nbr[k*n_out+o], ci] * dout[o, co] */
 size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout);
 int toda_spconv_wgrad(const float* in, int n_in, const float* dout, const int32_t* nbr,

@@ -277,6 +277,45 @@ def test_strided_conv_fwd_dgrad_wgrad(ks, st, pd, cin, cout):
     np.testing.assert_allclose(wt.grad.cpu().numpy(), dw0, rtol=1e-4, atol=1e-4 * np.abs(dw0).max())
 
 
+@pytest.mark.parametrize("cg,cp,dense", [(5, 16, False), (4, 16, False), (16, 16, False), (16, 16, True), (16, 32, False), (32, 16, False), (12, 20, False)])
+def test_compacting_narrow_gather_gemm_matches_the_output_stationary_kernel(cg, cp, dense):
+    """toda_spconv_gather_gemm_compact (K = 27, <= 32 gathered, <= 32 produced channels: a wave compacts the rows that have a
+    neighbour at the offset and adds the tile's product to its rows of an LDS accumulator) against toda_spconv_gather_gemm on
+    the same table: forward operand with bias and the transposed / offset-reversed data-gradient operand; a row count that is no
+    multiple of 64, rows with more than 16 pairs per offset and wave (dense = every cell occupied), an empty table; run twice:
+    the same bits."""
+    from toda_amd import ops
+
+    shape, batch = ([6, 24, 30], 1) if dense else ([9, 70, 66], 2)
+    if dense:
+        zz, yy, xx = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), np.arange(shape[2]), indexing="ij")
+        idx = np.stack([np.zeros(zz.size, np.int64), zz.ravel(), yy.ravel(), xx.ravel()], 1).astype(np.int32)
+        feat = np.random.default_rng(1).standard_normal((len(idx), cg)).astype(np.float32)
+    else:
+        idx, feat = H.clustered_sparse(batch, shape, 3100, cg, seed=cg + cp)
+    assert len(idx) % 64 != 0 or dense
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    rng = np.random.default_rng(5)
+    w = dev((rng.standard_normal((cp, 3, 3, 3, cg)) / np.sqrt(27 * cg)).astype(np.float32))
+    bias = dev(rng.standard_normal(cp).astype(np.float32))
+    x = dev(feat)
+    assert ops.gather_gemm_compact_supported(cg, cp, 27) and not ops.gather_gemm_compact_supported(cg, cp, 3) and not ops.gather_gemm_compact_supported(64, 16, 27)
+    ref = ops.gather_gemm(x, ops.pack_weight(w, False, False), rb.nbr_fwd, cp, bias)
+    got = ops.gather_gemm_compact(x, w, rb.nbr_fwd, cp, bias)
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert torch.equal(ops.gather_gemm_compact(x, w, rb.nbr_fwd, cp, bias), got)
+    # data gradient: gathers cp channels, produces cg (supported when the produced side is a multiple of 4)
+    if cg % 4 == 0:
+        g = dev(rng.standard_normal((len(idx), cp)).astype(np.float32))
+        ref = ops.gather_gemm(g, ops.pack_weight(w, True, rb.flip_bwd), rb.nbr_bwd, cg, None)
+        got = ops.gather_gemm_compact(g, w, rb.nbr_bwd, cg, None, True, rb.flip_bwd)
+        assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # nothing to gather: the bias alone
+    none = torch.full_like(rb.nbr_fwd, -1)
+    got = ops.gather_gemm_compact(x, w, none, cp, bias)
+    assert torch.equal(got, bias.expand_as(got))
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
 def test_dout_stationary_wgrad_matches_oracle(cin, cout):
     """toda_spconv_wgrad_tiled (wgrad_tile_kernel; opt-in, TODA_WG_TILE=1; K = 27, 32 / 64 channels: the output-gradient tile staged in
@@ -798,6 +837,7 @@ def test_strided_dgrad_over_class_sorted_rows_is_bit_identical(ks, st, pd, cin, 
     shape, batch = [21, 96, 88], 2
     idx, feat = H.clustered_sparse(batch, shape, 9000, cin, seed=5)
     monkeypatch.setattr(ops, "CLASS_DGRAD_MIN_ROWS", 0)
+    monkeypatch.setattr(ops, "COMPACT", False)      # (the 32 -> 16 data gradient otherwise takes the compacting kernel)
     _, _, rb, _ = ops.build_conv_rulebook(dev(idx), batch, shape, ks, st, pd)
     w = dev((np.random.default_rng(1).standard_normal((cout,) + ks + (cin,)) * 0.05).astype(np.float32))
     g = torch.randn((rb.n_out, cout), device="cuda")

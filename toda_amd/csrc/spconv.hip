@@ -104,6 +104,7 @@ pack_weight_batch_kernel(const PackBatch b) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Buffer resource over a whole fp32 table.  Reads through it are bounds-checked by the hardware:
 // an offset >= bytes returns 0 and touches no memory, which is how "no neighbour" (-1) rows are
@@ -1581,6 +1582,231 @@ wgrad_reduce_kernel(const float* __restrict__ slab, int chunks, long long elems,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Gather-GEMM for the NARROW K = 27 layers (<= 32 gathered channels, 16 produced channels per workgroup):
+// conv_input 5 -> 16, SubM 16 -> 16 and its dgrad, the strided 16 -> 32 and its dgrad 32 -> 16.  On these levels a row has 1.7 -
+// 3.9 of its 27 neighbours, so almost every (16-row tile, offset) of the output-stationary kernel holds at least one pair and is
+// gathered and multiplied at 6 - 14 % occupancy (their time follows the number of vector-memory instructions, not the bytes).
+// Here a wave owns 64 output rows and COMPACTS the rows that have a neighbour at the offset (ballot + prefix popcount into a
+// small LDS queue): one 16-row tile per offset instead of four, every gathered row a real one; one coalesced id load per offset
+// and 64 rows (all 27 issued up front).  The compacted tile's product is added to the wave's rows of an LDS accumulator
+// (ds_add_f32; only the owning wave touches a row and its offsets come in order: deterministic).  All 27 weight slices of the
+// workgroup's 16 output channels sit in LDS (27 / 54 KiB), filled once from the plain [cout][K][cin] tensor, so the offsets need no
+// barrier; the gathers of offset k + CG_DEPTH are issued before the multiplies of offset k (the loop is fully unrolled: static
+// ring positions, the compiler counts vmcnt).  blockIdx.y = block of 16 produced channels (contiguous: 64-byte row segments).
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef TODA_CG_WAVES
+#define TODA_CG_WAVES 4
+#endif
+#ifndef TODA_CG_DEPTH
+#define TODA_CG_DEPTH 3
+#endif
+constexpr int CG_WAVES = TODA_CG_WAVES, CG_BLOCK = CG_WAVES * 64, CG_ROWS = CG_BLOCK, CG_K = 27, CG_DEPTH = TODA_CG_DEPTH;
+
+template <int Q, bool VEC>
+__global__ void __launch_bounds__(CG_BLOCK)
+gather_gemm_compact_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ w, int w_cout, int w_cin, int transpose,
+                           int flip_k, const int* __restrict__ nbr, int n_out, int cp, const float* __restrict__ bias,
+                           float* __restrict__ out) {
+    __shared__ f32x4 w_lds[CG_K * Q * 64];            // [k][q][lane]: B fragments of the 4 MFMA steps of channel group q
+    __shared__ float acc_lds[CG_WAVES * 65 * 16];     // per wave 64 rows + one row that absorbs the empty queue slots
+    __shared__ int q_id[CG_WAVES][CG_DEPTH + 1][64];
+    __shared__ int q_row[CG_WAVES][CG_DEPTH + 1][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int co0 = blockIdx.y * 16;
+    const int row0 = blockIdx.x * CG_ROWS + wv * 64;
+
+    // ids of this lane's row for all 27 offsets: in flight while the weights are staged
+    const __amdgpu_buffer_rsrc_t id_rsrc = table_rsrc(reinterpret_cast<const float*>(nbr), (unsigned)((size_t)CG_K * n_out * 4u));
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cg * 4u);
+    int ids[CG_K];
+    const bool row_ok = row0 + lane < n_out;
+#pragma unroll
+    for (int k = 0; k < CG_K; ++k)
+        ids[k] = __builtin_bit_cast(int, __builtin_amdgcn_raw_buffer_load_b32(id_rsrc, row_ok ? (unsigned)(((size_t)k * n_out + row0 + lane) * 4u) : OOB, 0, 0));
+
+    // weights of the 16 produced channels co0 .. co0 + 15 -> LDS (one 16-byte fragment per (k, q, lane); all loads of a thread
+    // are independent: in flight together); accumulator rows start at the bias
+    {
+        constexpr int FR = CG_K * Q * 64, IT = (FR + CG_BLOCK - 1) / CG_BLOCK;
+        f32x4 frag[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int e = tid + it * CG_BLOCK;
+            const int ln = e & 63, kq = e >> 6;
+            const int q = kq % Q, k = kq / Q;
+            const int g0 = 16 * q + 4 * (ln >> 4), pch = co0 + (ln & 15);
+            const int kk = flip_k ? CG_K - 1 - k : k;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < FR) {
+                if (!transpose) {
+                    if (pch < w_cout) {
+                        const float* src = w + ((size_t)pch * CG_K + kk) * w_cin + g0;
+                        if (VEC && g0 + 3 < w_cin) {
+                            v = *reinterpret_cast<const f32x4*>(src);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (g0 + j < w_cin) v[j] = src[j];
+                        }
+                    }
+                } else if (pch < w_cin) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (g0 + j < w_cout) v[j] = w[((size_t)(g0 + j) * CG_K + kk) * w_cin + pch];
+                }
+            }
+            frag[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+            if (tid + it * CG_BLOCK < FR) w_lds[tid + it * CG_BLOCK] = frag[it];
+    }
+    {
+        const float bv = (bias && co0 + (tid & 15) < cp) ? bias[co0 + (tid & 15)] : 0.f;
+        for (int e = tid; e < CG_WAVES * 65 * 16; e += CG_BLOCK) acc_lds[e] = bv;      // CG_BLOCK is a multiple of 16: e & 15 == tid & 15
+    }
+    __syncthreads();
+
+    // compaction of offset k into queue slot k % (CG_DEPTH + 1) and the gathers of its first tile.  The ring's gathers are inline
+    // asm with hand-counted vmcnt (every prepare issues exactly LOADS of them, out of range = no memory access): left to hipcc, the
+    // loop over a rare offset's further tiles makes every offset wait for vmcnt(0) and nothing is in flight across offsets.
+    struct Stage {
+        f32x4 a[Q];          // VEC: the asm loads' destinations
+        float s[Q][4];       // !VEC: one destination per 4-byte load (an element of a vector register would be a copy made at issue)
+        int cnt;
+    };
+    const unsigned long long in_addr = (unsigned long long)in;
+    const u32x4 in_desc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)in_addr),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(in_addr >> 32) & 0xFFFFu)),
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)n_in * (unsigned)cg * 4u)), 0x00020000u};
+    constexpr int LOADS = VEC ? Q : 4 * Q;
+    auto prepare = [&](int k, Stage& st) {
+        // every lane writes one queue entry: its pair behind the pairs of the lower lanes, or an empty entry (id -1, the wave's
+        // spare accumulator row) behind all pairs - no branch, and the slots past the count never hold an older offset's pairs
+        const int i = row_ok ? ids[k] : -1;
+        const unsigned long long vote = __ballot(i >= 0);
+        int* qi = q_id[wv][k % (CG_DEPTH + 1)];
+        int* qr = q_row[wv][k % (CG_DEPTH + 1)];
+        st.cnt = __popcll(vote);
+        const unsigned long long below = (1ull << lane) - 1;
+        const int pos = i >= 0 ? __popcll(vote & below) : st.cnt + __popcll(~vote & below);
+        qi[pos] = i;
+        qr[pos] = i >= 0 ? lane : 64;
+        __builtin_amdgcn_wave_barrier();
+        const int src = qi[c];
+        const bool ok = src >= 0;
+        const unsigned base = (unsigned)src * (unsigned)cg * 4u;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if constexpr (VEC) {
+                const unsigned off = (ok && 16 * q + 4 * g < cg) ? base + (unsigned)(16 * q + 4 * g) * 4u : OOB;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(st.a[q]) : "v"(off), "s"(in_desc) : "memory");
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned off = (ok && 16 * q + 4 * g + j < cg) ? base + (unsigned)(16 * q + 4 * g + j) * 4u : OOB;
+                    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(st.s[q][j]) : "v"(off), "s"(in_desc) : "memory");
+                }
+            }
+        }
+    };
+    // product of one compacted tile (rows = queue slots 16 tt .. 16 tt + 15) added to the wave's accumulator rows
+    auto multiply_add = [&](int k, int tt, int cnt, const f32x4 (&a)[Q]) {
+        f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const f32x4 b = w_lds[(k * Q + q) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][j], b[j], r, 0, 0, 0);
+        }
+        // D: row 4 g + reg = queue slot, column c.  Plain read-modify-write: only this wave touches its rows, the rows of a tile are
+        // distinct (an LDS float atomic is a 64-cycle instruction here: 120 of them per wave set the pace of the first version); the
+        // empty slots all point at the spare row
+        const i32x4 rows = *reinterpret_cast<const i32x4*>(q_row[wv][k % (CG_DEPTH + 1)] + 16 * tt + 4 * g);
+        float* const acc_w = acc_lds + wv * 65 * 16 + c;
+        float old[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) old[reg] = acc_w[rows[reg] * 16];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc_w[rows[reg] * 16] = old[reg] + r[reg];
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the 27 ids (the compiler has seen its own wait at their first use)
+    float dummy = 0.f;
+    Stage st[CG_DEPTH];
+#pragma unroll
+    for (int k = 0; k < CG_DEPTH; ++k) prepare(k, st[k]);
+#pragma unroll
+    for (int k = 0; k < CG_K; ++k) {
+        Stage& ring = st[k % CG_DEPTH];
+        // offset k's gathers have landed when at most the (CG_DEPTH - 1) x LOADS younger ones are outstanding (fewer near the end)
+        if constexpr (VEC) {
+            if constexpr (Q == 1)
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ring.a[0]) : "n"((CG_DEPTH - 1) * LOADS));
+            else
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ring.a[0]), "+v"(ring.a[1]) : "n"((CG_DEPTH - 1) * LOADS));
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ring.s[q][0]), "+v"(ring.s[q][1]), "+v"(ring.s[q][2]), "+v"(ring.s[q][3]) : "n"((CG_DEPTH - 1) * LOADS));
+        }
+        Stage cur = ring;
+        if constexpr (!VEC) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) cur.a[q] = f32x4{ring.s[q][0], ring.s[q][1], ring.s[q][2], ring.s[q][3]};
+        }
+        if (k + CG_DEPTH < CG_K) {
+            prepare(k + CG_DEPTH, ring);
+        } else {      // keep the count: dummy loads behind the last offset, all into ONE register that stays live up to the final wait
+                      // (a destination the compiler considers dead would be handed to another value and overwritten when the load returns)
+#pragma unroll
+            for (int d = 0; d < LOADS; ++d)
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(dummy) : "v"(OOB), "s"(in_desc) : "memory");
+        }
+        multiply_add(k, 0, cur.cnt, cur.a);
+        // more than 16 pairs at this offset (always the centre of a SubM table): the remaining tiles, not pipelined
+        for (int tt = 1; 16 * tt < cur.cnt; ++tt) {
+            const int src = q_id[wv][k % (CG_DEPTH + 1)][16 * tt + c];
+            const bool ok = src >= 0;
+            const unsigned base = (unsigned)src * (unsigned)cg * 4u;
+            f32x4 a[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if constexpr (VEC) {
+                    a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (ok && 16 * q + 4 * g < cg) ? base + (unsigned)(16 * q + 4 * g) * 4u : OOB, 0, 0));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        a[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (ok && 16 * q + 4 * g + j < cg) ? base + (unsigned)(16 * q + 4 * g + j) * 4u : OOB, 0, 0));
+                }
+            }
+            multiply_add(k, tt, cur.cnt, a);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy)::"memory");      // the dummy loads
+    __builtin_amdgcn_wave_barrier();
+    // the wave's 64 rows x 16 channels: LDS -> out (64-byte row segments at column co0)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 16 + (lane >> 2), c4 = (lane & 3) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&acc_lds[(wv * 65 + r) * 16 + c4]);
+        const int row = row0 + r;
+        if (row < n_out) {
+            float* dst = out + (size_t)row * cp + co0 + c4;
+            if (co0 + c4 + 3 < cp) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (co0 + c4 + j < cp) dst[j] = v[j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // wgrad, dout-stationary form for the wide K = 27 layers (32 -> 32, 64 -> 64, 32 -> 64).  In wgrad_kernel a
 // workgroup is one (row chunk, offset): the 27 offset-blocks of a chunk each fetch the chunk's dout rows again, and every
 // (in, out) pair costs one row of each table through L2 - (cin + cout) * 4 bytes for 2 * cin * cout FLOP, 8 (32 -> 32) or 16
@@ -1842,7 +2068,11 @@ wgrad_tile_kernel(const float* __restrict__ in, int n_in, int cin, const float* 
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummy loads behind the end of the stream
+            // the dummy loads behind the end of the stream: their destinations stay live up to this wait (a register the compiler
+            // considers dead would be handed to another value and overwritten when the load returns)
+#pragma unroll
+            for (int pp = 0; pp < WT_DEPTH; ++pp)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ring_a[pp][0]), "+v"(ring_a[pp][1]), "+v"(ring_a[pp][2]), "+v"(ring_a[pp][3])::"memory");
         }
         if constexpr (!EARLY) {
             fetch_tile(tn);
@@ -2449,6 +2679,41 @@ extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, 
                                        int n_out, int k_vol, int c_produce, const float* bias, float* out,
                                        void* stream) {
     return toda_spconv_gather_gemm_ordered(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, nullptr, stream);
+}
+
+// Narrow K = 27 layers by per-offset compaction (gather_gemm_compact_kernel).  w is the PLAIN weight [w_cout][27][w_cin];
+// transpose / flip_k select the data-gradient operand exactly as toda_spconv_pack_weight would pack it.
+extern "C" int toda_spconv_gather_gemm_compact_supported(int c_gather, int c_produce, int k_vol) {
+    return k_vol == CG_K && c_gather >= 1 && c_gather <= 32 && c_produce >= 1 && c_produce <= 32 && c_produce % 4 == 0;
+}
+
+extern "C" int toda_spconv_gather_gemm_compact(const float* in, int n_in, int c_gather, const float* w, int w_cout, int w_cin, int transpose,
+                                               int flip_k, const int32_t* nbr, int n_out, int k_vol, int c_produce, const float* bias,
+                                               float* out, void* stream) {
+    TODA_CHECK_ARG(toda_spconv_gather_gemm_compact_supported(c_gather, c_produce, k_vol),
+                   "gather_gemm_compact: needs K = 27, <= 32 gathered and <= 32 produced channels (a multiple of 4) (got K %d, %d -> %d)", k_vol, c_gather,
+                   c_produce);
+    TODA_CHECK_ARG((transpose ? w_cout : w_cin) == c_gather && (transpose ? w_cin : w_cout) == c_produce,
+                   "gather_gemm_compact: weight [%d][27][%d] (transpose %d) does not map %d -> %d channels", w_cout, w_cin, transpose, c_gather, c_produce);
+    TODA_CHECK_ARG(n_out >= 0 && n_in >= 0, "gather_gemm_compact: bad sizes");
+    TODA_CHECK_ARG((unsigned long long)n_in * c_gather * 4ull < 0xFFFFFFF0ull, "gather_gemm_compact: gathered table must be < 4 GiB");
+    if (n_out == 0) return TODA_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(cdiv(n_out, CG_ROWS), cdiv(c_produce, 16));
+    const bool vec = c_gather % 4 == 0;
+#define CG_LAUNCH(QQ, VV)                                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_compact_kernel<QQ, VV>), grid, dim3(CG_BLOCK), 0, s, in, n_in, c_gather, w, w_cout, w_cin, \
+                       transpose, flip_k, nbr, n_out, c_produce, bias, out)
+    if (c_gather <= 16) {
+        if (vec) CG_LAUNCH(1, true);
+        else CG_LAUNCH(1, false);
+    } else {
+        if (vec) CG_LAUNCH(2, true);
+        else CG_LAUNCH(2, false);
+    }
+#undef CG_LAUNCH
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
 }
 
 // SubM gather-GEMM over a halo plan (toda_halo_plan_build): forward, and - with the transposed / offset-reversed packed operand - the

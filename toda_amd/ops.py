@@ -428,6 +428,31 @@ def gather_gemm(feat, wp, nbr, c_produce, bias=None, order=None):
     return out
 
 
+# narrow K = 27 layers (conv_input, the 16-channel SubM level, the strided 16 -> 32 and its data gradient) by per-offset compaction:
+# measured on the C3 levels 5 -> 16 80 -> 42 us, 16 -> 16 70 -> 38, 16 -> 32 @ 682 k rows 141 -> 122, 32 -> 16 (dgrad) 69 -> 61
+COMPACT = _os.environ.get("TODA_GG_COMPACT", "1") == "1"
+
+
+def _compact_route(c_gather, c_produce, nbr, order):
+    return (COMPACT and order is None and nbr.shape[0] == 27 and nbr.shape[1] > 0 and c_produce in (16, 32) and c_gather <= 32
+            and (c_gather <= 16 or c_produce == 16))
+
+
+def gather_gemm_compact_supported(c_gather, c_produce, k_vol):
+    return bool(L.load().toda_spconv_gather_gemm_compact_supported(int(c_gather), int(c_produce), int(k_vol)))
+
+
+def gather_gemm_compact(feat, weight, nbr, c_produce, bias=None, transpose=False, flip_k=False):
+    """Narrow K = 27 layers by per-offset compaction (toda_spconv_gather_gemm_compact); weight is the PLAIN [cout][3][3][3][cin] tensor."""
+    lib = L.load()
+    K, n_out = nbr.shape
+    out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
+    rc = lib.toda_spconv_gather_gemm_compact(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(weight), weight.shape[0], weight.shape[-1],
+                                             int(bool(transpose)), int(bool(flip_k)), L.ptr(nbr), n_out, K, c_produce, L.ptr(bias), L.ptr(out), L.stream())
+    L.check(rc, "toda_spconv_gather_gemm_compact")
+    return out
+
+
 def gather_gemm_classed(feat, wp, nbr, c_produce, order, cls_sorted, ksize, stride, padding):
     """Data gradient of a strided convolution over its class-sorted rows (Rulebook.class_order)."""
     lib = L.load()
@@ -546,7 +571,8 @@ class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, weight, bias, rb, wp_fwd, want_stats=False, wp_bwd=None):
         features = features.contiguous()
-        if wp_fwd is None:
+        compact = not want_stats and _compact_route(features.shape[1], weight.shape[0], rb.nbr_fwd, rb.order_for(rb.nbr_fwd))
+        if wp_fwd is None and not compact:
             wp_fwd = pack_weight(weight, False, False)
         sums = None
         plan = rb.halo.get(weight.shape[-1]) if (rb.kind == "subm" and weight.shape[0] == weight.shape[-1] and features.shape[0] == rb.n_out) else None
@@ -556,6 +582,8 @@ class _SparseConv(torch.autograd.Function):
             out = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias)
         elif want_stats:
             out, sums = gather_gemm_with_stats(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
+        elif compact:
+            out = gather_gemm_compact(features, weight.contiguous(), rb.nbr_fwd, weight.shape[0], bias)
         else:
             out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, order=rb.order_for(rb.nbr_fwd))
         ctx.halo_plan = plan
@@ -589,7 +617,9 @@ class _SparseConv(torch.autograd.Function):
             for t in (features, gout, rb.nbr_fwd):
                 t.record_stream(side)
             need_w = False
-        if need_d:
+        if need_d and ctx.halo_plan is None and _compact_route(gout.shape[1], weight.shape[-1], rb.nbr_bwd, rb.order_for(rb.nbr_bwd)):
+            gfeat = gather_gemm_compact(gout, weight.contiguous(), rb.nbr_bwd, weight.shape[-1], None, True, rb.flip_bwd)
+        elif need_d:
             wp_t = ctx.wp_bwd if ctx.wp_bwd is not None else pack_weight(weight, True, rb.flip_bwd)
             co = rb.class_order()
             if ctx.halo_plan is not None:      # SubM: the forward table with the offsets reversed in wp_t - the same plan

@@ -38,7 +38,7 @@ from toda_amd import ops  # noqa: E402
 from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file  # noqa: E402
 from toda_amd.pcdet.datasets import SyntheticLidarDataset  # noqa: E402
 from toda_amd.pcdet.models import build_network, voxelize_on_gpu  # noqa: E402
-from toda_amd.tools.train_utils.optimization import build_optimizer, build_scheduler, clip_grad_norm_  # noqa: E402
+from toda_amd.tools.train_utils.optimization import build_optimizer, build_scheduler, clip_and_step, clip_grad_norm_  # noqa: E402
 
 WORKLOADS = {
     # name: (yaml, samples per GPU, description)
@@ -319,8 +319,7 @@ def run_gpu(args, rank, world, device):
         if ph is not None:
             ph["backward"] += time.perf_counter() - t_ph
             t_ph = time.perf_counter()
-        clip_grad_norm_(params, clip)
-        optimizer.step()
+        clip_and_step(optimizer, params, clip)
         if ph is not None:
             ph["clip+optimizer"] += time.perf_counter() - t_ph
             t_ph = time.perf_counter()
@@ -574,8 +573,7 @@ def cpu_baseline(cfg, workload, n_scenes=5):
                 else:
                     loss = fn(model, dict(batch)).loss
                 loss.backward()
-                clip_grad_norm_(list(model.parameters()), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
-                optimizer.step()
+                clip_and_step(optimizer, list(model.parameters()), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
             say(f"step {i + 1}/{len(batches)} done after {time.perf_counter() - t0:.1f} s")
         dt = time.perf_counter() - t0 + mix_s
     what = {"c2": "forward pass voxel features -> VoxelBackBone8x -> dense BEV (no gradients)",

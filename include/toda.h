@@ -509,6 +509,22 @@ int toda_conv3x3_narrow_wgrad(int n, const float* const* x_host, const float* co
 int toda_timing_begin(int capacity);
 int toda_timing_end(float* ms_out_host, int cap, int* n_out_host);
 
+/* ---------------------------------------------------------------------------------------------
+ * The optimizer step of the reference trainers in two launches (reference tools/train_utils/train_utils.py:55-59:
+ * clip_grad_norm_(model.parameters(), GRAD_NORM_CLIP) + optimizer.step(), the optimizer being
+ * tools/train_utils/optimization/fastai_optim.py:104-236 OptimWrapper(Adam, true_wd) = p *= 1 - lr * wd, then torch's Adam):
+ *   norm = || all gradients ||_2 (returned in norm_out[0]); g *= min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: no clipping);
+ *   p *= 1 - lr * weight_decay; m += (g - m)(1 - beta1); v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).
+ * The n tensors (fp32, contiguous) are given as device arrays of device addresses + element counts; chunk_tensor / chunk_off list
+ * the toda_clip_adam_chunk()-element pieces of all tensors (one workgroup each); partial: n_chunks doubles of scratch.  The partial
+ * sums are folded in index order: deterministic. */
+int toda_clip_adam_chunk(void);
+int toda_clip_adam_step(const unsigned long long* param, const unsigned long long* grad, const unsigned long long* exp_avg,
+                        const unsigned long long* exp_avg_sq, const long long* numel, const int* chunk_tensor,
+                        const long long* chunk_off, int n_chunks, double* partial, float* norm_out, float max_norm,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -864,3 +864,56 @@ def test_strided_dgrad_over_class_sorted_rows_is_bit_identical(ks, st, pd, cin, 
     x = dev(feat).requires_grad_(True)
     ops.sparse_conv(x, w.requires_grad_(True), None, rb).backward(g)
     assert calls and torch.equal(x.grad, plain)
+
+
+def test_fused_clip_decay_adam_step_matches_the_torch_path():
+    """toda_clip_adam_step (OneCycleAdam.clip_and_step: clip_grad_norm_ + decoupled weight decay + Adam in two launches) against the
+    torch path (foreach norms / scale / decay + torch.optim.Adam fused) on the same parameters and gradients for five steps with the
+    one-cycle lr / momentum changing every step: returned norm, parameters, moments, clipped gradients; with and without the clip
+    active; the state dicts are interchangeable (a checkpoint of one path resumes on the other); bit-reproducible."""
+    from toda_amd.tools.train_utils.optimization import OneCycle, OneCycleAdam, clip_and_step
+
+    def make(seed):
+        torch.manual_seed(seed)
+        net = torch.nn.Sequential(torch.nn.Conv2d(5, 33, 3), torch.nn.BatchNorm2d(33), torch.nn.Conv2d(33, 64, 3), torch.nn.Linear(7, 1001),
+                                  torch.nn.Conv2d(64, 128, 3, bias=False)).cuda()       # 1001 x 7: a tensor whose size is no multiple of 4; > 8192-element tensors
+        return net
+
+    a, b = make(0), make(0)
+    oa, ob = OneCycleAdam(a, wd=0.01), OneCycleAdam(b, wd=0.01)
+    assert oa._hip_step
+    ob._hip_step = False
+    sa, sb = OneCycle(oa, 40, 3e-3, [0.95, 0.85], 10, 0.4), OneCycle(ob, 40, 3e-3, [0.95, 0.85], 10, 0.4)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for it in range(5):
+        sa.step(it), sb.step(it)
+        scale = 100.0 if it % 2 == 0 else 1e-3        # clip active / inactive (max_norm 10)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            gr = torch.randn(pa.shape, device="cuda", generator=g) * scale
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        with H.abi_calls("toda_clip_adam_step") as calls:
+            na = clip_and_step(oa, list(a.parameters()), 10.0)
+        assert calls["toda_clip_adam_step"] == 1
+        nb = clip_and_step(ob, list(b.parameters()), 10.0)
+        assert abs(float(na) - float(nb)) <= 1e-6 * float(nb)
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-6 * max(float(pb.detach().abs().max()), 1e-3), (it, n)
+            assert float((pa.grad - pb.grad).abs().max()) <= 2e-6 * float(pb.grad.abs().max()), (it, n)
+            sta, stb = oa.opt.state[pa], ob.opt.state[pb]
+            assert float(sta["step"]) == float(stb["step"]) == it + 1
+            assert float((sta["exp_avg"] - stb["exp_avg"]).abs().max()) <= 2e-6 * float(stb["exp_avg"].abs().max())
+            assert float((sta["exp_avg_sq"] - stb["exp_avg_sq"]).abs().max()) <= 2e-6 * float(stb["exp_avg_sq"].abs().max())
+    # a checkpoint of the torch path resumes on the fused one and vice versa
+    c, d = make(0), make(0)
+    c.load_state_dict(b.state_dict()), d.load_state_dict(a.state_dict())
+    oc, od = OneCycleAdam(c, wd=0.01), OneCycleAdam(d, wd=0.01)
+    od._hip_step = False
+    oc.load_state_dict(ob.state_dict()), od.load_state_dict(oa.state_dict())
+    oc.lr, oc.mom, od.lr, od.mom = 1e-3, 0.9, 1e-3, 0.9
+    for pc, pd in zip(c.parameters(), d.parameters()):
+        gr = torch.randn(pc.shape, device="cuda", generator=g)
+        pc.grad, pd.grad = gr.clone(), gr.clone()
+    clip_and_step(oc, list(c.parameters()), 10.0), clip_and_step(od, list(d.parameters()), 10.0)
+    for pc, pd in zip(c.parameters(), d.parameters()):
+        assert float(oc.opt.state[pc]["step"]) == float(od.opt.state[pd]["step"]) == 6
+        assert float((pc.detach() - pd.detach()).abs().max()) <= 4e-6 * max(float(pd.detach().abs().max()), 1e-3)

@@ -79,6 +79,8 @@ SIGNATURES = {
     "toda_boxes_overlap_bev": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "toda_nms_workspace_bytes": (_sz, [_i]),
     "toda_nms_rotated": (_i, [_vp, _i, C.c_float, _vp, _vp, _vp, _sz, _vp]),
+    "toda_clip_adam_chunk": (_i, []),
+    "toda_clip_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _vp]),
     "toda_points_in_boxes": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "toda_points_sector": (_i, [_vp, _i, _vp, _i, _dbl, _dbl, _vp, _vp]),
     "toda_points_rect": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),

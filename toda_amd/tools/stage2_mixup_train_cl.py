@@ -11,7 +11,7 @@ import time
 
 import torch
 import torch.nn as nn
-from .train_utils.optimization import clip_grad_norm_
+from .train_utils.optimization import clip_and_step, clip_grad_norm_  # noqa: F401
 
 from ..pcdet.config import cfg
 from ..pcdet import datasets as dataset_registry
@@ -43,8 +43,7 @@ def train_one_epoch_cl(model, optimizer, loader, model_func, lr_scheduler, accum
         optimizer.zero_grad()
         loss, tb_dict, _ = model_func(model, adv, org, dist_train)
         loss.backward()
-        clip_grad_norm_(model.parameters(), optim_cfg.GRAD_NORM_CLIP)
-        optimizer.step()
+        clip_and_step(optimizer, model.parameters(), optim_cfg.GRAD_NORM_CLIP)
         if prefetch is not None and it + 1 < n_iters:
             prefetch.kick()
         accumulated_iter += 1

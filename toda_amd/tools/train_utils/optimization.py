@@ -53,6 +53,10 @@ class OneCycleAdam:
         self.true_wd, self.bn_wd = True, True
         self._beta2 = betas[1]
         self.lr, self.mom = lr, betas[0]
+        import os
+
+        self._hip_step = bool(fused) and os.environ.get("TODA_HIP_OPTIMIZER", "1") == "1"
+        self._hip_cache = {}
 
     # hyper-parameters as properties, like the reference wrapper
     @property
@@ -91,11 +95,97 @@ class OneCycleAdam:
                 torch._foreach_mul_(ps, factor)
         self.opt.step()
 
+    # ------------------------------------------------------------------ clip + decay + Adam in two launches (toda_clip_adam_step)
+    def _fused_ready(self, params):
+        return (self._hip_step and len(params) > 0 and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                                                           and p.grad.dtype == torch.float32 and p.grad.device == p.device for p in params)
+                and len({p.device for p in params}) == 1)
+
+    @torch.no_grad()
+    def clip_and_step(self, max_norm):
+        """clip_grad_norm_(parameters, max_norm) followed by step(), as the reference's loop does them
+        (tools/train_utils/train_utils.py:57-58); returns the total gradient norm (a 0-d tensor).  On one GPU with fp32 contiguous
+        tensors both run inside toda_clip_adam_step (the state stays torch.optim.Adam's: exp_avg, exp_avg_sq, step - checkpoints
+        are interchangeable with the torch path, which is what runs otherwise)."""
+        params = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
+        if not self._fused_ready(params):
+            total = clip_grad_norm_(params, max_norm) if max_norm is not None and max_norm > 0 else None
+            self.step()
+            return total
+        from toda_amd import lib as L
+
+        lib = L.load()
+        dev = params[0].device
+        st = self.opt.state
+        fresh = [p for p in params if len(st[p]) == 0]
+        for p in fresh:       # torch.optim.Adam._init_group for fused=True: device step counter, zero moments
+            st[p]["step"] = torch.zeros((), dtype=torch.float32, device=dev)
+            st[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        key = tuple(id(p) for p in params)
+        c = self._hip_cache
+        if c.get("key") != key:
+            chunk = lib.toda_clip_adam_chunk()
+            numel = [p.numel() for p in params]
+            ct, co = [], []
+            for i, n in enumerate(numel):
+                for off in range(0, max(n, 1), chunk):
+                    ct.append(i)
+                    co.append(off)
+            c.clear()
+            c.update(key=key, n=len(params), n_chunks=len(ct),
+                     numel=torch.tensor(numel, dtype=torch.int64, device=dev),
+                     chunk_tensor=torch.tensor(ct, dtype=torch.int32, device=dev),
+                     chunk_off=torch.tensor(co, dtype=torch.int64, device=dev),
+                     partial=torch.empty((len(ct),), dtype=torch.float64, device=dev),
+                     # pinned staging copies of the pointer table: the upload is stream-ordered and may run several steps after
+                     # the host wrote it, so a buffer is rewritten only after its own upload has executed (event)
+                     host=[torch.empty((4, len(params)), dtype=torch.int64).pin_memory() for _ in range(4)],
+                     host_done=[None] * 4, turn=0,
+                     table=torch.empty((4, len(params)), dtype=torch.int64, device=dev),
+                     moments=[(st[p]["exp_avg"], st[p]["exp_avg_sq"]) for p in params],
+                     steps=[st[p]["step"] for p in params],
+                     count=None)
+            if any(not (m.is_contiguous() and v.is_contiguous() and m.dtype == torch.float32) for m, v in c["moments"]):
+                c.clear()
+                self._hip_step = False
+                return self.clip_and_step(max_norm)
+        if c["count"] is None:      # resumed from a checkpoint or first step: one read of the device counter
+            c["count"] = int(c["steps"][0].item())
+        turn = c["turn"]
+        c["turn"] = (turn + 1) % len(c["host"])
+        host = c["host"][turn]
+        if c["host_done"][turn] is not None:
+            c["host_done"][turn].synchronize()
+        # gradient storage is reallocated by zero_grad(set_to_none=True): the table is rebuilt every step (pinned buffer -> device, stream-ordered)
+        tbl = host.numpy()
+        for i, p in enumerate(params):
+            tbl[0, i] = p.data_ptr()
+            tbl[1, i] = p.grad.data_ptr()
+        for i, (m, v) in enumerate(c["moments"]):
+            tbl[2, i] = m.data_ptr()
+            tbl[3, i] = v.data_ptr()
+        c["table"].copy_(host, non_blocking=True)
+        ev = c["host_done"][turn] or torch.cuda.Event()
+        ev.record()
+        c["host_done"][turn] = ev
+        c["count"] += 1
+        torch._foreach_add_(c["steps"], 1)
+        norm = torch.empty((1,), dtype=torch.float32, device=dev)
+        t = c["table"]
+        rc = lib.toda_clip_adam_step(L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.ptr(t[3]), L.ptr(c["numel"]), L.ptr(c["chunk_tensor"]),
+                                     L.ptr(c["chunk_off"]), c["n_chunks"], L.ptr(c["partial"]), L.ptr(norm),
+                                     float(max_norm) if max_norm is not None else 0.0, self._lr, self._mom, self._beta2,
+                                     float(self.opt.param_groups[0]["eps"]), float(self.wd), c["count"], L.stream())
+        L.check(rc, "toda_clip_adam_step")
+        return norm[0]
+
     def state_dict(self):
         return self.opt.state_dict()
 
     def load_state_dict(self, sd):
         self.opt.load_state_dict(sd)
+        self._hip_cache = {}      # new moment tensors, new step count
 
 
 def annealing_cos(start, end, pct):
@@ -173,4 +263,14 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0):
     total = torch.linalg.vector_norm(torch.stack(norms), norm_type)
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
     torch._foreach_mul_(grads, coef)
+    return total
+
+
+def clip_and_step(optimizer, parameters, max_norm):
+    """The two lines of the reference's loop (tools/train_utils/train_utils.py:57-58) - clip_grad_norm_(parameters, max_norm);
+    optimizer.step() - in the optimizer's own fused form where it has one (OneCycleAdam.clip_and_step)."""
+    if hasattr(optimizer, "clip_and_step"):
+        return optimizer.clip_and_step(max_norm)
+    total = clip_grad_norm_(parameters, max_norm)
+    optimizer.step()
     return total

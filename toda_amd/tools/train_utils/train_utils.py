@@ -13,7 +13,7 @@ import time
 
 import torch
 import torch.distributed as dist
-from .optimization import clip_grad_norm_
+from .optimization import clip_and_step, clip_grad_norm_  # noqa: F401
 
 from ...pcdet.utils import common_utils
 
@@ -73,8 +73,7 @@ def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, ac
         loss, tb_dict, disp = model_func(model, batch)
         t_fwd = time.time() - end
         loss.backward()
-        clip_grad_norm_(model.parameters(), optim_cfg.GRAD_NORM_CLIP)
-        optimizer.step()
+        clip_and_step(optimizer, model.parameters(), optim_cfg.GRAD_NORM_CLIP)
         if prefetch is not None and cur_it + 1 < total_it_each_epoch:
             _progress(cur_it + 1)    # the batch built now is the one iteration cur_it + 1 trains on
             prefetch.kick()          # not behind the epoch's last iteration: nothing is fetched that this call does not train on

@@ -302,6 +302,16 @@ int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const float* gamma, 
 int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, int hw, const float* gamma, const float* beta,
                   const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* sync /*nullable*/,
                   unsigned epoch, void* stream);
+/* The same pair with y / dy a CHANNEL SLICE [channel0, channel0 + c) of a wider [batch][channels][hw] tensor: the up-sampling
+ * deblocks of the BEV neck write straight into the concatenated map and read its gradient in place, so torch.cat and the copies
+ * of its backward (reference pcdet/models/backbones_2d/base_bev_backbone.py:104-107) never run. */
+int toda_bn2d_fwd_into(const float* x, int batch, int c, int hw, const float* gamma, const float* beta,
+                       float* running_mean /*nullable*/, float* running_var /*nullable*/, float momentum, float eps, int relu,
+                       float* y, int y_channels, int y_channel0, float* save, void* sync /*nullable*/, unsigned epoch,
+                       void* stream);
+int toda_bn2d_bwd_from(const float* x, const float* dy, int dy_channels, int dy_channel0, int batch, int c, int hw,
+                       const float* gamma, const float* beta, const float* save, int relu, float* dx, float* dgamma,
+                       float* dbeta, void* sync /*nullable*/, unsigned epoch, void* stream);
 
 /* ------------------------------------------------------------------------
  * CenterHead target assignment (pcdet/models/dense_heads/center_head.py:103-219,

@@ -279,3 +279,36 @@ def test_deconv_matches_conv_transpose2d_fp64(b, cin, cout, h, w, s):
     x.grad = wt.grad = None
     ops.deconv(x, wt, s).backward(gy)
     assert torch.equal(g1[0], x.grad) and torch.equal(g1[1], wt.grad)
+
+
+def test_bn2d_cat_equals_batchnorm_relu_cat():
+    """ops.bn2d_cat (toda_bn2d_fwd_into / toda_bn2d_bwd_from: every BatchNorm2d + ReLU writes its channel slice of the concatenated map
+    and reads the slice of its gradient in place) against torch.cat([relu(bn(x))]) in float64: forward, input / weight / bias gradients,
+    running statistics; the per-channel and the per-plane (partner-exchange) kernels (C3's 2 x 256 x 188 x 188 takes the latter)."""
+    from toda_amd import ops
+
+    for shapes in ([(2, 32, 24, 20), (2, 64, 24, 20)], [(2, 256, 188, 188), (2, 256, 188, 188)], [(1, 32, 7, 5), (1, 96, 7, 5), (1, 16, 7, 5)]):
+        torch.manual_seed(len(shapes))
+        xs = [torch.randn(s, device="cuda") * 2 + 0.3 for s in shapes]
+        bns = [torch.nn.BatchNorm2d(s[1], eps=1e-3, momentum=0.01).cuda().train() for s in shapes]
+        refs = [torch.nn.BatchNorm2d(s[1], eps=1e-3, momentum=0.01).cuda().double().train() for s in shapes]
+        for bn, rf in zip(bns, refs):
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.5, 0.5)
+                rf.weight.copy_(bn.weight), rf.bias.copy_(bn.bias)
+        if not all(ops.bn2d_supported(x, bn) for x, bn in zip(xs, bns)):
+            continue
+        xa = [x.clone().requires_grad_(True) for x in xs]
+        xr = [x.double().requires_grad_(True) for x in xs]
+        out = ops.bn2d_cat(list(zip(xa, bns)), relu=True)
+        ref = torch.cat([torch.relu(rf(x)) for rf, x in zip(refs, xr)], dim=1)
+        g = torch.randn_like(out)
+        out.backward(g)
+        ref.backward(g.double())
+        assert float((out.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        for x, r, bn, rf in zip(xa, xr, bns, refs):
+            assert float((x.grad.double() - r.grad).abs().max()) <= 5e-6 * float(r.grad.abs().max())
+            assert float((bn.weight.grad.double() - rf.weight.grad).abs().max()) <= 5e-6 * float(rf.weight.grad.abs().max())
+            assert float((bn.bias.grad.double() - rf.bias.grad).abs().max()) <= 5e-6 * float(rf.bias.grad.abs().max())
+            assert torch.allclose(bn.running_mean.double(), rf.running_mean, rtol=1e-5, atol=1e-7) and torch.allclose(bn.running_var.double(), rf.running_var, rtol=1e-5, atol=1e-7)
+            assert int(bn.num_batches_tracked) == 1

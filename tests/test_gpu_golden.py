@@ -98,7 +98,7 @@ def test_bev_backbone_wide_on_gpu_hits_the_hand_written_kernels():
     from tests.test_golden_reference import check_bev_backbone_wide_scaled
 
     names = ("toda_conv3x3_fwd", "toda_conv3x3_wgrad", "toda_bn2d_fwd", "toda_bn2d_bwd", "toda_conv3x3s2_fwd", "toda_conv3x3s2_dgrad",
-             "toda_conv3x3s2_wgrad", "toda_deconv_fwd", "toda_deconv_dgrad", "toda_deconv_wgrad")
+             "toda_conv3x3s2_wgrad", "toda_deconv_fwd", "toda_deconv_dgrad", "toda_deconv_wgrad", "toda_bn2d_fwd_into", "toda_bn2d_bwd_from")
     with abi_calls(*names) as n:
         errs = check_bev_backbone_wide_scaled("cuda", 2e-5, 5e-5)
     print({k: f"{v:.1e}" for k, v in errs.items()})
@@ -107,6 +107,8 @@ def test_bev_backbone_wide_on_gpu_hits_the_hand_written_kernels():
     # the stride-2 head of block 1 and both deblocks (1x1 and 2x2 / stride 2): no convolution of the neck is left to a library
     assert n["toda_conv3x3s2_fwd"] == 1 and n["toda_conv3x3s2_dgrad"] == 1 and n["toda_conv3x3s2_wgrad"] == 1, n
     assert n["toda_deconv_fwd"] == 2 and n["toda_deconv_dgrad"] == 2 and n["toda_deconv_wgrad"] == 2, n
+    # the BatchNorm2d + ReLU tails of the two deblocks write / read their channel slices of the concatenated map (no torch.cat)
+    assert n["toda_bn2d_fwd_into"] == 2 and n["toda_bn2d_bwd_from"] == 2, n
 
 
 def test_center_head_wide_on_gpu_hits_the_hand_written_kernels():

@@ -73,7 +73,9 @@ template <int V, int BB, int K, bool RELU>
 __global__ void __launch_bounds__(BN2_BLOCK)
 bn2d_fwd_kernel(const float* __restrict__ x, int C, int hwv, const float* __restrict__ gamma, const float* __restrict__ beta,
                 float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                float* __restrict__ y, float* __restrict__ save) {
+                float* __restrict__ y, int yC, float* __restrict__ save) {
+    // y may be a channel slice of a wider tensor (the concatenated BEV map): y points at the slice's first plane, yC is the
+    // channel count of the tensor it lives in (= C for a tensor of its own)
     __shared__ double sh[BN2_BLOCK / 64];
     const int c = blockIdx.x, t = threadIdx.x;
     const unsigned voff = (unsigned)t * (V * 4u);
@@ -117,7 +119,7 @@ bn2d_fwd_kernel(const float* __restrict__ x, int C, int hwv, const float* __rest
     const float shift = beta[c] - mean * scale;
 #pragma unroll
     for (int b = 0; b < BB; ++b) {
-        const __amdgpu_buffer_rsrc_t rs = bn2_plane<V>(y, (size_t)b * C + c, hwv);
+        const __amdgpu_buffer_rsrc_t rs = bn2_plane<V>(y, (size_t)b * yC + c, hwv);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             vec_t o;
@@ -142,7 +144,7 @@ bn2d_fwd_kernel(const float* __restrict__ x, int C, int hwv, const float* __rest
 
 template <int V, int BB, int K, bool RELU>
 __global__ void __launch_bounds__(BN2_BLOCK)
-bn2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C, int hwv, const float* __restrict__ gamma,
+bn2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int gC, int C, int hwv, const float* __restrict__ gamma,
                 const float* __restrict__ beta, const float* __restrict__ save, float* __restrict__ dx,
                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ double sh[BN2_BLOCK / 64];
@@ -156,7 +158,7 @@ bn2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int b = 0; b < BB; ++b) {
-        const __amdgpu_buffer_rsrc_t rx = bn2_plane<V>(x, (size_t)b * C + c, hwv), rg = bn2_plane<V>(dy, (size_t)b * C + c, hwv);
+        const __amdgpu_buffer_rsrc_t rx = bn2_plane<V>(x, (size_t)b * C + c, hwv), rg = bn2_plane<V>(dy, (size_t)b * gC + c, hwv);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             vec_t xv = bn2_load<V, 0>(rx, voff, k);                     // kept in the caches for the second sweep
@@ -260,7 +262,7 @@ template <int V, int K, bool RELU>
 __global__ void __launch_bounds__(BN2_BLOCK)
 bn2d_fwd_split_kernel(const float* __restrict__ x, int C, int P, int hwv, const float* __restrict__ gamma, const float* __restrict__ beta,
                       float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                      float* __restrict__ y, float* __restrict__ save, Bn2Sync* __restrict__ sy, unsigned epoch, unsigned* __restrict__ fault) {
+                      float* __restrict__ y, int yC, float* __restrict__ save, Bn2Sync* __restrict__ sy, unsigned epoch, unsigned* __restrict__ fault) {
     __shared__ double sh[BN2_BLOCK / 64];
     __shared__ double part[2 * BN2_MAX_P];
     int c, b;
@@ -306,7 +308,7 @@ bn2d_fwd_split_kernel(const float* __restrict__ x, int C, int P, int hwv, const 
     const float invstd = 1.0f / sqrtf((float)var_d + eps);
     const float scale = gamma[c] * invstd;
     const float shift = beta[c] - mean * scale;
-    const __amdgpu_buffer_rsrc_t ry = bn2_plane<V>(y, (size_t)b * C + c, hwv);
+    const __amdgpu_buffer_rsrc_t ry = bn2_plane<V>(y, (size_t)b * yC + c, hwv);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         vec_t o;
@@ -330,7 +332,7 @@ bn2d_fwd_split_kernel(const float* __restrict__ x, int C, int P, int hwv, const 
 
 template <int V, int K, bool RELU>
 __global__ void __launch_bounds__(BN2_BLOCK)
-bn2d_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ dy, int C, int P, int hwv, const float* __restrict__ gamma,
+bn2d_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ dy, int gC, int C, int P, int hwv, const float* __restrict__ gamma,
                       const float* __restrict__ beta, const float* __restrict__ save, float* __restrict__ dx,
                       float* __restrict__ dgamma, float* __restrict__ dbeta, Bn2Sync* __restrict__ sy, unsigned epoch, unsigned* __restrict__ fault) {
     __shared__ double sh[BN2_BLOCK / 64];
@@ -345,7 +347,7 @@ bn2d_bwd_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
     typedef typename bn2_vec<V>::type vec_t;
     vec_t g[K], xh[K];         // masked dy and the normalised x of this plane: nothing is read twice
     float s1 = 0.f, s2 = 0.f;
-    const __amdgpu_buffer_rsrc_t rx = bn2_plane<V>(x, (size_t)b * C + c, hwv), rg = bn2_plane<V>(dy, (size_t)b * C + c, hwv);
+    const __amdgpu_buffer_rsrc_t rx = bn2_plane<V>(x, (size_t)b * C + c, hwv), rg = bn2_plane<V>(dy, (size_t)b * gC + c, hwv);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         vec_t xv = bn2_load<V, BN2_NT>(rx, voff, k);
@@ -421,35 +423,35 @@ extern "C" int toda_bn2d_supported(int batch, int c, int hw) {
 
 template <int V, int BB, int K>
 static void bn2_launch_fwd(bool relu, dim3 grid, hipStream_t s, const float* x, int c, int hwv, const float* gamma, const float* beta, float* rm,
-                           float* rv, float momentum, float eps, float* y, float* save) {
+                           float* rv, float momentum, float eps, float* y, int yC, float* save) {
     if constexpr (BB * K * V <= 72) {
-        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_kernel<V, BB, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, c, hwv, gamma, beta, rm, rv, momentum, eps, y, save);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_kernel<V, BB, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, c, hwv, gamma, beta, rm, rv, momentum, eps, y, save);
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_kernel<V, BB, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, c, hwv, gamma, beta, rm, rv, momentum, eps, y, yC, save);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_kernel<V, BB, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, c, hwv, gamma, beta, rm, rv, momentum, eps, y, yC, save);
     }
 }
 template <int V, int BB, int K>
-static void bn2_launch_bwd(bool relu, dim3 grid, hipStream_t s, const float* x, const float* dy, int c, int hwv, const float* gamma,
+static void bn2_launch_bwd(bool relu, dim3 grid, hipStream_t s, const float* x, const float* dy, int gC, int c, int hwv, const float* gamma,
                            const float* beta, const float* save, float* dx, float* dgamma, float* dbeta) {
     if constexpr (BB * K * V <= 72) {
-        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_kernel<V, BB, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_kernel<V, BB, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_kernel<V, BB, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, dy, gC, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_kernel<V, BB, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, gC, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
     }
 }
 // split kernels: BB is the dummy 0 so that the same BN2_BY_K switch serves them; the trailing arguments carry P, sync, epoch
 template <int V, int BB, int K>
 static void bn2_launch_fwd_split(bool relu, dim3 grid, hipStream_t s, const float* x, int c, int P, int hwv, const float* gamma, const float* beta,
-                                 float* rm, float* rv, float momentum, float eps, float* y, float* save, Bn2Sync* sy, unsigned epoch, unsigned* fault) {
+                                 float* rm, float* rv, float momentum, float eps, float* y, int yC, float* save, Bn2Sync* sy, unsigned epoch, unsigned* fault) {
     if constexpr (K * V <= 36) {
-        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, save, sy, epoch, fault);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, save, sy, epoch, fault);
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, yC, save, sy, epoch, fault);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_fwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, c, P, hwv, gamma, beta, rm, rv, momentum, eps, y, yC, save, sy, epoch, fault);
     }
 }
 template <int V, int BB, int K>
-static void bn2_launch_bwd_split(bool relu, dim3 grid, hipStream_t s, const float* x, const float* dy, int c, int P, int hwv, const float* gamma,
+static void bn2_launch_bwd_split(bool relu, dim3 grid, hipStream_t s, const float* x, const float* dy, int gC, int c, int P, int hwv, const float* gamma,
                                  const float* beta, const float* save, float* dx, float* dgamma, float* dbeta, Bn2Sync* sy, unsigned epoch, unsigned* fault) {
     if constexpr (K * V <= 36) {
-        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch, fault);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch, fault);
+        if (relu) hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, true>), grid, dim3(BN2_BLOCK), 0, s, x, dy, gC, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch, fault);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(bn2d_bwd_split_kernel<V, K, false>), grid, dim3(BN2_BLOCK), 0, s, x, dy, gC, c, P, hwv, gamma, beta, save, dx, dgamma, dbeta, sy, epoch, fault);
     }
 }
 
@@ -494,10 +496,16 @@ static int bn2_fault_poll(const char* who) {
     return TODA_EFAULT;
 }
 
-extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const float* gamma, const float* beta, float* running_mean,
-                             float* running_var, float momentum, float eps, int relu, float* y, float* save, void* sync, unsigned epoch,
-                             void* stream) {
+// y = channels [y_channel0, y_channel0 + c) of a [batch][y_channels][hw] tensor (the deblocks of the BEV neck write straight into the
+// concatenated map: reference base_bev_backbone.py:104-107 torch.cat(ups, dim=1))
+extern "C" int toda_bn2d_fwd_into(const float* x, int batch, int c, int hw, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float momentum, float eps, int relu, float* y, int y_channels, int y_channel0,
+                                  float* save, void* sync, unsigned epoch, void* stream) {
     TODA_CHECK_ARG(x && gamma && beta && y && save, "bn2d_fwd: null argument");
+    TODA_CHECK_ARG(y_channel0 >= 0 && y_channel0 + c <= y_channels, "bn2d_fwd: channels [%d, %d) outside the %d channels of y", y_channel0,
+                   y_channel0 + c, y_channels);
+    float* const ys = y + (size_t)y_channel0 * hw;
+    const int yC = y_channels;
     TODA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn2d_fwd: running_mean and running_var go together");
     // forward: the exchange costs 2-3 us, the single workgroup per channel only half-fills the GPU on <= 128 channels - measured
     // 19.1 vs 21.3 us at 2 x 128 x 188 x 188, 9.9 vs 12.6 at 2 x 256 x 94 x 94: one workgroup per channel wherever it fits
@@ -508,15 +516,27 @@ extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const flo
     const int v = (hw & 3) ? 1 : 4, hwv = hw / v;
     const int k = bn2_pick_k(hwv, v);
     hipStream_t s = (hipStream_t)stream;
-    if (split) BN2_DISPATCH_SPLIT(bn2_launch_fwd_split, x, c, batch, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save, (Bn2Sync*)sync, epoch, fault_word_dev());
-    else BN2_DISPATCH(bn2_launch_fwd, x, c, hwv, gamma, beta, running_mean, running_var, momentum, eps, y, save);
+    if (split) BN2_DISPATCH_SPLIT(bn2_launch_fwd_split, x, c, batch, hwv, gamma, beta, running_mean, running_var, momentum, eps, ys, yC, save, (Bn2Sync*)sync, epoch, fault_word_dev());
+    else BN2_DISPATCH(bn2_launch_fwd, x, c, hwv, gamma, beta, running_mean, running_var, momentum, eps, ys, yC, save);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }
 
-extern "C" int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, int hw, const float* gamma, const float* beta,
-                             const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* sync, unsigned epoch, void* stream) {
+extern "C" int toda_bn2d_fwd(const float* x, int batch, int c, int hw, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, int relu, float* y, float* save, void* sync, unsigned epoch,
+                             void* stream) {
+    return toda_bn2d_fwd_into(x, batch, c, hw, gamma, beta, running_mean, running_var, momentum, eps, relu, y, c, 0, save, sync, epoch, stream);
+}
+
+// dy = channels [dy_channel0, dy_channel0 + c) of a [batch][dy_channels][hw] gradient (a slice of the concatenated map's gradient)
+extern "C" int toda_bn2d_bwd_from(const float* x, const float* dy, int dy_channels, int dy_channel0, int batch, int c, int hw, const float* gamma,
+                                  const float* beta, const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* sync,
+                                  unsigned epoch, void* stream) {
     TODA_CHECK_ARG(x && dy && gamma && beta && save && dx && dgamma && dbeta, "bn2d_bwd: null argument");
+    TODA_CHECK_ARG(dy_channel0 >= 0 && dy_channel0 + c <= dy_channels, "bn2d_bwd: channels [%d, %d) outside the %d channels of dy", dy_channel0,
+                   dy_channel0 + c, dy_channels);
+    const float* const gs = dy + (size_t)dy_channel0 * hw;
+    const int gC = dy_channels;
     // backward: per plane when a channel's dy no longer leaves room for anything else in the registers (the channel kernel then
     // spills and reads x twice: 51.6 vs 28.5 us at 2 x 128 x 188 x 188; at 2 x 256 x 94 x 94 it is 12.8 vs 17.7 the other way)
     const int per_channel = bn2_floats_per_thread(batch, hw);
@@ -529,8 +549,13 @@ extern "C" int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, 
     const int v = (hw & 3) ? 1 : 4, hwv = hw / v;
     const int k = bn2_pick_k(hwv, v);
     hipStream_t s = (hipStream_t)stream;
-    if (split) BN2_DISPATCH_SPLIT(bn2_launch_bwd_split, x, dy, c, batch, hwv, gamma, beta, save, dx, dgamma, dbeta, (Bn2Sync*)sync, epoch, fault_word_dev());
-    else BN2_DISPATCH(bn2_launch_bwd, x, dy, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
+    if (split) BN2_DISPATCH_SPLIT(bn2_launch_bwd_split, x, gs, gC, c, batch, hwv, gamma, beta, save, dx, dgamma, dbeta, (Bn2Sync*)sync, epoch, fault_word_dev());
+    else BN2_DISPATCH(bn2_launch_bwd, x, gs, gC, c, hwv, gamma, beta, save, dx, dgamma, dbeta);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
+}
+
+extern "C" int toda_bn2d_bwd(const float* x, const float* dy, int batch, int c, int hw, const float* gamma, const float* beta,
+                             const float* save, int relu, float* dx, float* dgamma, float* dbeta, void* sync, unsigned epoch, void* stream) {
+    return toda_bn2d_bwd_from(x, dy, c, 0, batch, c, hw, gamma, beta, save, relu, dx, dgamma, dbeta, sync, epoch, stream);
 }

@@ -75,6 +75,8 @@ SIGNATURES = {
     "toda_bn2d_sync_bytes": (_sz, []),
     "toda_bn2d_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp, C.c_uint, _vp]),
     "toda_bn2d_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_uint, _vp]),
+    "toda_bn2d_fwd_into": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _i, _i, _vp, _vp, C.c_uint, _vp]),
+    "toda_bn2d_bwd_from": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_uint, _vp]),
     "toda_boxes_iou_bev": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "toda_boxes_overlap_bev": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "toda_nms_workspace_bytes": (_sz, [_i]),

@@ -54,11 +54,22 @@ class BaseBEVBackbone(nn.Module):
         if getattr(self, "dense_channels_last", False):
             x = x.contiguous(memory_format=torch.channels_last)
         h0 = x.shape[2]
-        ups = []
+        ups, pre = [], []
+        # the deblocks end in BatchNorm2d + ReLU (reference :95-102): on the GPU in training mode those tails write their channels of the
+        # concatenated map directly (ops.bn2d_cat), so the deblock is run up to its tail and the cat below never launches
+        tails = [ops.bn_relu_tail(d) for d in self.deblocks[:len(self.blocks)]] if (ops.BN2D_CAT and len(self.blocks) > 1 and len(self.deblocks) >= len(self.blocks)) else []
         for lvl, block in enumerate(self.blocks):
             x = ops.run_dense_sequential(block, x)
             data_dict[f"spatial_features_{int(h0 / x.shape[2])}x"] = x
-            ups.append(ops.run_dense_sequential(self.deblocks[lvl], x) if len(self.deblocks) > 0 else x)
+            if tails and all(t is not None for t in tails):
+                pre.append((ops.run_dense_sequential(tails[lvl][0], x), tails[lvl][1]))
+            else:
+                ups.append(ops.run_dense_sequential(self.deblocks[lvl], x) if len(self.deblocks) > 0 else x)
+        if pre:
+            if all(ops.bn2d_supported(z, bn) for z, bn in pre) and len({z.shape[2:] for z, _ in pre}) == 1:
+                x = ops.bn2d_cat(pre, relu=True)
+            else:       # eval mode, CPU, SyncBatchNorm ...: the tails as modules, then the plain concatenation
+                ups = [torch.relu(ops.run_dense_sequential([bn], z)) for z, bn in pre]
         if len(ups) > 1:
             x = torch.cat(ups, dim=1)
         elif len(ups) == 1:

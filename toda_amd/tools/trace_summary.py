@@ -9,11 +9,12 @@ import sys
 
 def timed_window(rows, steps):
     """[t0, t_end] of the last `steps` training steps of a bench.py kernel trace (rows sorted by start time).  A step ends with
-    the last kernel of its optimizer launch cluster (FusedOptimizer multi-tensor kernels less than 1 ms apart); the window
+    the last kernel of its optimizer launch cluster (toda::clip_adam_update_kernel, or torch's FusedOptimizer multi-tensor kernels less than 1 ms apart); the window
     runs from the end of the step before the first counted one to the end of the last - whatever the step does in between
     (its own voxelisation, or with the input pipeline the NEXT step's on the side stream) is inside."""
     adam = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows
-                  if "FusedOptimizerTensorListMetadata" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower())
+                  if "FusedOptimizerTensorListMetadata" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower()
+                  or "clip_adam_update_kernel" in r["Kernel_Name"])
     if not adam:
         raise SystemExit("no optimizer kernels in the trace: cannot find the step boundaries")
     ends = []

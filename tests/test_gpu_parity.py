@@ -896,6 +896,7 @@ def test_fused_clip_decay_adam_step_matches_the_torch_path():
         assert calls["toda_clip_adam_step"] == 1
         nb = clip_and_step(ob, list(b.parameters()), 10.0)
         assert abs(float(na) - float(nb)) <= 1e-6 * float(nb)
+        oa.state_dict()       # (the device step counters of the two-launch path are brought up to date when the state is asked for)
         for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
             assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-6 * max(float(pb.detach().abs().max()), 1e-3), (it, n)
             assert float((pa.grad - pb.grad).abs().max()) <= 2e-6 * float(pb.grad.abs().max()), (it, n)
@@ -914,6 +915,7 @@ def test_fused_clip_decay_adam_step_matches_the_torch_path():
         gr = torch.randn(pc.shape, device="cuda", generator=g)
         pc.grad, pd.grad = gr.clone(), gr.clone()
     clip_and_step(oc, list(c.parameters()), 10.0), clip_and_step(od, list(d.parameters()), 10.0)
+    oc.state_dict()
     for pc, pd in zip(c.parameters(), d.parameters()):
         assert float(oc.opt.state[pc]["step"]) == float(od.opt.state[pd]["step"]) == 6
         assert float((pc.detach() - pd.detach()).abs().max()) <= 4e-6 * max(float(pd.detach().abs().max()), 1e-3)

@@ -88,6 +88,8 @@ class OneCycleAdam:
 
     @torch.no_grad()
     def step(self):
+        self._sync_steps()
+        self._hip_cache = {}      # the torch path advances the counters itself
         factor = 1.0 - self.wd * self._lr
         for g in self.opt.param_groups:
             ps = [p for p in g["params"] if p.requires_grad]
@@ -108,7 +110,12 @@ class OneCycleAdam:
         tensors both run inside toda_clip_adam_step (the state stays torch.optim.Adam's: exp_avg, exp_avg_sq, step - checkpoints
         are interchangeable with the torch path, which is what runs otherwise)."""
         params = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
-        if not self._fused_ready(params):
+        key = tuple(map(id, params))
+        c = self._hip_cache
+        # (the per-tensor checks and the table of parameter / moment addresses are made once per parameter set: at ~150 tensors they
+        # cost 2 ms of host time per step when repeated; per step only the gradient addresses are read)
+        if c.get("key") != key and not self._fused_ready(params):
+            self._sync_steps()
             total = clip_grad_norm_(params, max_norm) if max_norm is not None and max_norm > 0 else None
             self.step()
             return total
@@ -117,13 +124,13 @@ class OneCycleAdam:
         lib = L.load()
         dev = params[0].device
         st = self.opt.state
-        fresh = [p for p in params if len(st[p]) == 0]
-        for p in fresh:       # torch.optim.Adam._init_group for fused=True: device step counter, zero moments
-            st[p]["step"] = torch.zeros((), dtype=torch.float32, device=dev)
-            st[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        key = tuple(id(p) for p in params)
-        c = self._hip_cache
+        if c.get("key") != key:
+            self._sync_steps()
+            for p in params:
+                if len(st[p]) == 0:       # torch.optim.Adam._init_group for fused=True: device step counter, zero moments
+                    st[p]["step"] = torch.zeros((), dtype=torch.float32, device=dev)
+                    st[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         if c.get("key") != key:
             chunk = lib.toda_clip_adam_chunk()
             numel = [p.numel() for p in params]
@@ -150,27 +157,28 @@ class OneCycleAdam:
                 c.clear()
                 self._hip_step = False
                 return self.clip_and_step(max_norm)
-        if c["count"] is None:      # resumed from a checkpoint or first step: one read of the device counter
-            c["count"] = int(c["steps"][0].item())
-        turn = c["turn"]
-        c["turn"] = (turn + 1) % len(c["host"])
+            fixed = [[p.data_ptr() for p in params], [m.data_ptr() for m, _ in c["moments"]], [v.data_ptr() for _, v in c["moments"]]]
+            for h in c["host"]:       # parameters and moments do not move: rows 0, 2, 3 of every staging copy are written once
+                t = h.numpy()
+                t[0, :], t[2, :], t[3, :] = fixed
+            c["count"] = int(c["steps"][0].item())      # first step / resumed from a checkpoint: one read of the device counter
+        # a staging copy whose upload has executed (the host may be several steps ahead of the GPU: never wait here, grow the pool)
+        turn = next((i for i, ev in enumerate(c["host_done"]) if ev is None or ev.query()), None)
+        if turn is None:
+            h = torch.empty_like(c["host"][0]).pin_memory()
+            h.copy_(c["host"][0])
+            c["host"].append(h)
+            c["host_done"].append(None)
+            turn = len(c["host"]) - 1
         host = c["host"][turn]
-        if c["host_done"][turn] is not None:
-            c["host_done"][turn].synchronize()
-        # gradient storage is reallocated by zero_grad(set_to_none=True): the table is rebuilt every step (pinned buffer -> device, stream-ordered)
-        tbl = host.numpy()
-        for i, p in enumerate(params):
-            tbl[0, i] = p.data_ptr()
-            tbl[1, i] = p.grad.data_ptr()
-        for i, (m, v) in enumerate(c["moments"]):
-            tbl[2, i] = m.data_ptr()
-            tbl[3, i] = v.data_ptr()
+        # gradient storage is reallocated by zero_grad(set_to_none=True): row 1 is rewritten every step (pinned buffer -> device, stream-ordered)
+        host.numpy()[1, :] = [p.grad.data_ptr() for p in params]
         c["table"].copy_(host, non_blocking=True)
         ev = c["host_done"][turn] or torch.cuda.Event()
         ev.record()
         c["host_done"][turn] = ev
-        c["count"] += 1
-        torch._foreach_add_(c["steps"], 1)
+        c["count"] += 1       # the state's device step counters follow lazily (_sync_steps: state_dict, a change of path)
+        c["steps_dirty"] = True
         norm = torch.empty((1,), dtype=torch.float32, device=dev)
         t = c["table"]
         rc = lib.toda_clip_adam_step(L.ptr(t[0]), L.ptr(t[1]), L.ptr(t[2]), L.ptr(t[3]), L.ptr(c["numel"]), L.ptr(c["chunk_tensor"]),
@@ -180,7 +188,17 @@ class OneCycleAdam:
         L.check(rc, "toda_clip_adam_step")
         return norm[0]
 
+    def _sync_steps(self):
+        """Write the host-side step count into the state's device counters (torch.optim.Adam's `step` tensors), which the two-launch
+        path does not touch per step."""
+        c = self._hip_cache
+        if c.get("steps_dirty"):
+            torch._foreach_mul_(c["steps"], 0.0)
+            torch._foreach_add_(c["steps"], float(c["count"]))
+            c["steps_dirty"] = False
+
     def state_dict(self):
+        self._sync_steps()
         return self.opt.state_dict()
 
     def load_state_dict(self, sd):

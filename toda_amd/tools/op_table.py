@@ -28,11 +28,15 @@ class OpTable:
         for name in ("toda_voxelize_hard", "toda_mean_vfe_fwd", "toda_mean_vfe_bwd", "toda_gridindex_from_coords", "toda_gridindex_from_conv",
                      "toda_rulebook_subm", "toda_rulebook_conv", "toda_sparse_to_dense_fwd", "toda_sparse_to_dense_bwd", "toda_rows_moments",
                      "toda_rows_affine_act", "toda_rows_bn_bwd_res", "toda_bn2d_fwd", "toda_bn2d_bwd", "toda_spconv_pack_weight", "toda_conv3x3_transform_weight",
-                     "toda_center_assign"):
-            self._wrap_c(name)
+                     "toda_center_assign", "toda_bn2d_fwd_into", "toda_bn2d_bwd_from", "toda_clip_adam_step", "toda_conv3x3s2_fwd", "toda_conv3x3s2_dgrad",
+                     "toda_conv3x3s2_wgrad", "toda_deconv_fwd", "toda_deconv_dgrad", "toda_deconv_wgrad", "toda_conv3x3_narrow_fwd", "toda_conv3x3_narrow_dgrad",
+                     "toda_conv3x3_narrow_wgrad", "toda_center_loss_fwd", "toda_center_loss_bwd"):
+            if hasattr(self, "_c_" + name):
+                self._wrap_c(name)
         self._wrap_py("gather_gemm", self._cost_gather_gemm)
         self._wrap_py("gather_gemm_with_stats", self._cost_gather_gemm)
         self._wrap_py("gather_gemm_classed", self._cost_gather_gemm_classed)
+        self._wrap_py("gather_gemm_compact", self._cost_gather_gemm_compact)
         self._wrap_py("wgrad", self._cost_wgrad)
         self._wrap_py("conv3x3_run", self._cost_conv3x3)
         self._wrap_py("conv3x3_wgrad", self._cost_conv3x3_wgrad)
@@ -92,7 +96,10 @@ class OpTable:
     def _cost_gather_gemm_classed(self, feat, wp, nbr, c_produce, order, cls_sorted, ksize, stride, padding):
         return self._cost_gather_gemm(feat, wp, nbr, c_produce)
 
-    def _cost_wgrad(self, feat, dout, nbr, wshape):
+    def _cost_gather_gemm_compact(self, feat, weight, nbr, c_produce, bias=None, transpose=False, flip_k=False):
+        return self._cost_gather_gemm(feat, None, nbr, c_produce)
+
+    def _cost_wgrad(self, feat, dout, nbr, wshape, tiled=None):
         K, n_out = nbr.shape
         cout, cin = wshape[0], wshape[-1]
         pk = self._count_pairs(nbr)
@@ -180,6 +187,43 @@ class OpTable:
     def _c_toda_bn2d_bwd(a):
         b, c, hw = a[2], a[3], a[4]
         return (b, c, hw), ("fixed", 12.0 * b * c * hw, 0.0, "x once, dy once, dx once")
+
+    @staticmethod
+    def _c_toda_bn2d_fwd_into(a):
+        b, c, hw = a[1], a[2], a[3]
+        return (b, c, hw, a[12]), ("fixed", 8.0 * b * c * hw, 0.0, "x read once, y written once into its channel slice of the concatenated map")
+
+    @staticmethod
+    def _c_toda_bn2d_bwd_from(a):
+        b, c, hw = a[4], a[5], a[6]
+        return (b, c, hw, a[2]), ("fixed", 12.0 * b * c * hw, 0.0, "x once, dy (a channel slice) once, dx once")
+
+    @staticmethod
+    def _c_toda_clip_adam_step(a):
+        n_chunks = a[7]
+        p = 8192.0 * n_chunks
+        return (n_chunks,), ("fixed", 4.0 * 9 * p, 0.0, "g twice, p / m / v read and written, g written: 36 bytes per parameter (upper bound: whole chunks)")
+
+    @staticmethod
+    def _pix_gemm(a, s, what):
+        b, cin, cout, h, w = a[2], a[3], a[4], a[5], a[6]
+        if what == "conv":       # 3x3 / stride 2: out = (h/2, w/2), 9 taps
+            flops, byts = 2.0 * 9 * cin * cout * b * (h // 2) * (w // 2), 4.0 * b * (cin * h * w + cout * (h // 2) * (w // 2)) + 4.0 * 9 * cin * cout
+        else:                    # transposed conv, kernel = stride s: out = (s h, s w)
+            flops, byts = 2.0 * cin * cout * s * s * b * h * w, 4.0 * b * h * w * (cin + cout * s * s) + 4.0 * cin * cout * s * s
+        return (b, cin, cout, h, w, s), ("fixed", byts, flops, "")
+
+    def _c_toda_conv3x3s2_fwd(self, a):
+        return self._pix_gemm(a, 2, "conv")
+
+    _c_toda_conv3x3s2_dgrad = _c_toda_conv3x3s2_fwd
+    _c_toda_conv3x3s2_wgrad = _c_toda_conv3x3s2_fwd
+
+    def _c_toda_deconv_fwd(self, a):
+        return self._pix_gemm(a, a[7], "deconv")
+
+    _c_toda_deconv_dgrad = _c_toda_deconv_fwd
+    _c_toda_deconv_wgrad = _c_toda_deconv_fwd
 
     @staticmethod
     def _c_toda_spconv_pack_weight(a):

@@ -282,6 +282,8 @@ def run_gpu(args, rank, world, device):
             with torch.no_grad():
                 if prefetch is not None:
                     batch = prefetch.next()
+                    if prefetch.threaded:
+                        prefetch.kick()      # the worker thread prepares the next batch while this thread enqueues the forward
                 else:
                     batch = dict(batches[it % len(batches)])
                     voxelize_on_gpu(batch, dataset.voxel_cfg)
@@ -289,7 +291,7 @@ def run_gpu(args, rank, world, device):
                     batch = m(batch)
                 out = batch["spatial_features"].sum()
                 if prefetch is not None:
-                    prefetch.kick()          # the next batch's voxelisation + rulebooks on the side stream, under this forward
+                    prefetch.kick()          # (same thread: the next batch's voxelisation + rulebooks on the side stream, under this forward)
             return out
         ph = phases if timer.enabled else None          # host-side phase clock of the timed steps (TODA_BENCH_PHASES)
         t_ph = time.perf_counter()

@@ -75,3 +75,29 @@ def test_host_tensors_are_refused():
 
     with pytest.raises(RuntimeError):
         ops.mean_vfe(torch.zeros(2, 3, 4), torch.ones(2))
+
+
+def test_round3_entry_points_validate_before_they_launch():
+    """The entry points added in round 3 (compacting gather-GEMM, dout-stationary wgrad, slice BatchNorm2d, optimizer step):
+    support queries, workspace sizes, argument errors - no GPU needed."""
+    lib = L.load()
+    assert lib.toda_spconv_gather_gemm_compact_supported(16, 16, 27) == 1 and lib.toda_spconv_gather_gemm_compact_supported(5, 16, 27) == 1
+    assert lib.toda_spconv_gather_gemm_compact_supported(64, 16, 27) == 0 and lib.toda_spconv_gather_gemm_compact_supported(16, 16, 3) == 0
+    assert lib.toda_spconv_gather_gemm_compact_supported(16, 18, 27) == 0                                   # produced channels: a multiple of 4
+    assert lib.toda_spconv_gather_gemm_compact(None, 10, 64, None, 16, 64, 0, 0, None, 10, 27, 16, None, None, None) == -1 and b"K = 27" in lib.toda_last_error()
+    assert lib.toda_spconv_gather_gemm_compact(None, 10, 16, None, 32, 16, 1, 0, None, 10, 27, 16, None, None, None) == -1 and b"does not map" in lib.toda_last_error()
+    assert lib.toda_spconv_gather_gemm_compact(None, 10, 16, None, 16, 16, 0, 0, None, 0, 27, 16, None, None, None) == 0       # no output rows: nothing to do
+    assert lib.toda_spconv_wgrad_tiled_supported(100000, 100000, 27, 32, 32) == 1 and lib.toda_spconv_wgrad_tiled_supported(100000, 100000, 27, 64, 32) == 0
+    assert lib.toda_spconv_wgrad_tiled_supported(1 << 23, 100000, 27, 32, 32) == 0                          # queue entries hold 23 bits of input row
+    need = lib.toda_spconv_wgrad_tiled_workspace_bytes(100000, 64, 64)
+    assert need >= 27 * 64 * 64 * 4 * 8 and lib.toda_spconv_wgrad_tiled_workspace_bytes(100000, 64, 32) == 0
+    assert lib.toda_spconv_wgrad_tiled(None, 10, None, None, 10, 3, 64, 64, None, None, 0, None) == -1 and b"K = 27" in lib.toda_last_error()
+    assert lib.toda_spconv_wgrad_tiled(None, 100000, None, None, 100000, 27, 64, 64, None, None, need - 1, None) != 0 and b"workspace" in lib.toda_last_error()
+    one = L.host_f32([0.0])
+    p = L.hptr(one)
+    assert lib.toda_bn2d_fwd_into(p, 2, 64, 100, p, p, None, None, 0.01, 1e-3, 1, p, 96, 40, p, None, 0, None) == -1 and b"outside" in lib.toda_last_error()
+    assert lib.toda_bn2d_bwd_from(p, p, 96, 40, 2, 64, 100, p, p, p, 1, p, p, p, None, 0, None) == -1 and b"outside" in lib.toda_last_error()
+    assert lib.toda_clip_adam_chunk() == 8192
+    assert lib.toda_clip_adam_step(None, None, None, None, None, None, None, 4, None, None, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.01, 1, None) == -1 and b"null" in lib.toda_last_error()
+    assert lib.toda_clip_adam_step(p, p, p, p, p, p, p, 4, p, p, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.01, 0, None) == -1 and b"step" in lib.toda_last_error()
+    assert lib.toda_clip_adam_step(p, p, p, p, p, p, p, 0, p, p, 10.0, 1e-3, 0.9, 0.99, 1e-8, 0.01, 1, None) == 0             # no tensors: nothing to do

@@ -2696,7 +2696,8 @@ extern "C" int toda_spconv_gather_gemm_compact(const float* in, int n_in, int c_
     TODA_CHECK_ARG((transpose ? w_cout : w_cin) == c_gather && (transpose ? w_cin : w_cout) == c_produce,
                    "gather_gemm_compact: weight [%d][27][%d] (transpose %d) does not map %d -> %d channels", w_cout, w_cin, transpose, c_gather, c_produce);
     TODA_CHECK_ARG(n_out >= 0 && n_in >= 0, "gather_gemm_compact: bad sizes");
-    TODA_CHECK_ARG((unsigned long long)n_in * c_gather * 4ull < 0xFFFFFFF0ull, "gather_gemm_compact: gathered table must be < 4 GiB");
+    TODA_CHECK_ARG((unsigned long long)n_in * c_gather * 4ull < 0xFFFFFFF0ull && (unsigned long long)n_out * CG_K * 4ull < 0xFFFFFFF0ull,
+                   "gather_gemm_compact: gathered table and neighbour table must be < 4 GiB each");
     if (n_out == 0) return TODA_OK;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(cdiv(n_out, CG_ROWS), cdiv(c_produce, 16));
@@ -2829,7 +2830,8 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
 // dout-stationary wgrad (wgrad_tile_kernel): K = 27, 32 or 64 channels on both sides with cin <= cout, input rows < 2^23
 extern "C" int toda_spconv_wgrad_tiled_supported(int n_in, int n_out, int k_vol, int cin, int cout) {
     return k_vol == WT_K && n_out > 0 && n_in > 0 && n_in < (1 << 23) && (cin == 32 || cin == 64) && (cout == 32 || cout == 64) && cin <= cout &&
-           (unsigned long long)n_in * cin * 4ull < 0xFFFFFFF0ull && (unsigned long long)n_out * cout * 4ull < 0xFFFFFFF0ull;
+           (unsigned long long)n_in * cin * 4ull < 0xFFFFFFF0ull && (unsigned long long)n_out * cout * 4ull < 0xFFFFFFF0ull &&
+           (unsigned long long)n_out * WT_K * 4ull < 0xFFFFFFF0ull;
 }
 
 extern "C" size_t toda_spconv_wgrad_tiled_workspace_bytes(int n_out, int cin, int cout) {

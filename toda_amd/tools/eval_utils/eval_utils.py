@@ -36,6 +36,8 @@ def run_inference(model, dataloader, on_batch=None):
             try:
                 with torch.no_grad():
                     batch_dict = pre.next()
+                    if pre.threaded:
+                        pre.kick()       # the worker thread prepares the next batch while this one is enqueued and decoded
             except StopIteration:
                 return
             with torch.no_grad():

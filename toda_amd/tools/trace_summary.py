@@ -16,7 +16,11 @@ def timed_window(rows, steps):
                   if "FusedOptimizerTensorListMetadata" in r["Kernel_Name"] or "fused_adam" in r["Kernel_Name"].lower()
                   or "clip_adam_update_kernel" in r["Kernel_Name"])
     if not adam:
-        raise SystemExit("no optimizer kernels in the trace: cannot find the step boundaries")
+        # forward-only workload (BASELINE config 2): a step starts with its MeanVFE launch (one per forward, on the training stream)
+        vfe = sorted(int(r["Start_Timestamp"]) for r in rows if "mean_vfe_fwd_kernel" in r["Kernel_Name"])
+        if len(vfe) <= steps:
+            raise SystemExit("neither optimizer nor MeanVFE kernels delimit enough steps in the trace")
+        return vfe[-steps - 1] - 1, vfe[-1] - 1
     ends = []
     for s, e in adam:
         if ends and s - ends[-1] < 1_000_000:

@@ -89,6 +89,12 @@ timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/r03_kt_c5
 F5=$(find /tmp/r03_kt_c5 -name "*kernel_trace.csv" | head -1)
 python3 $R/toda_amd/tools/trace_summary.py $F5 5 $O/r03_bench_c5_timed_steps.csv > $O/r03_bench_c5_groups.txt
 python3 $R/toda_amd/tools/trace_gaps.py $F5 5 > $O/r03_gaps_c5.txt
+# the forward-only workload (BASELINE config 2): steps delimited by the MeanVFE launch
+rm -rf /tmp/r03_kt_c2
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/r03_kt_c2 -- python3 $R/bench.py --workload c2 --steps 20 --warmup 10 --no-cpu-baseline > $O/r03_kt_c2.log 2>&1
+F2=$(find /tmp/r03_kt_c2 -name "*kernel_trace.csv" | head -1)
+python3 $R/toda_amd/tools/trace_summary.py $F2 20 $O/r03_bench_c2_timed_steps.csv > $O/r03_bench_c2_groups.txt
+python3 $R/toda_amd/tools/trace_gaps.py $F2 20 > $O/r03_gaps_c2.txt
 cd $R
 # the same C3 line once more behind the nine profiler passes (on two boxes the first runs after rocprofv3 threw a 22-28 ms step
 # every fourth or fifth step; both lines are kept)

@@ -162,7 +162,7 @@ def test_backbone_takes_the_halo_kernel_and_keeps_its_bits(monkeypatch):
     # the 64-channel layers sum in another (equally valid) order.  Forward: BatchNorm on its running statistics agrees to rounding
     # (1e-4 of the tensor's scale through 12 layers).  Backward: the ReLU masks are recomputed from pre-activations that differ in
     # the last bits, so an element that sits on the threshold flips and moves single gradient entries by 1e-3 of the tensor's maximum
-    # (scripts/compact_e2e.py: ANY two implementations differ like that here - the packed kernels are 2.5e-3 from the CPU oracle backend
+    # (profiles/scripts/compact_e2e.py: ANY two implementations differ like that here - the packed kernels are 2.5e-3 from the CPU oracle backend
     # on conv3.2.0.weight, the compacting ones 3e-4): gradients are compared in the L2 norm, which a flipped element barely moves.
     # In training mode the moments come out of the epilogues as per-workgroup partial sums whose grouping follows the row blocks, and a
     # train-mode BatchNorm amplifies rounding (tests/test_noise_floor.py: 7e-3 between two runs of the SAME CPU code with permuted rows): 2e-2

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage: pmc_any.sh <python script> <kernel substring> <out json>
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_any; mkdir -p $O
+i=0
+for c in "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE"; do
+  i=$((i+1)); rm -rf /tmp/pa_$i
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pa_$i -- python3 $R/$1 > $O/pass_$i.log 2>&1
+done
+python3 $R/toda_amd/tools/pmc_summary.py "$2" $R/gpurun_out/$3 $(find /tmp/pa_* -name "*counter_collection.csv") > /dev/null
+python3 - <<PY
+import json
+d=json.load(open("$R/gpurun_out/$3"))
+for s in d["launch_shapes"]:
+    print(s["kernel"][:120], {k:(round(v/1e6,3) if isinstance(v,float) and v>1e5 else (round(v,3) if isinstance(v,float) else v)) for k,v in s.items() if k!="kernel"})
+PY

@@ -374,3 +374,55 @@ def test_full_size_stage2_consistency_step_matches_oracle_backend():
     assert err < 2e-3, err
     print(f"stage-2 full size: loss {float(out.loss.detach()):.5f} vs {float(ref.loss.detach()):.5f}, grads {err:.2e}, "
           + ", ".join(f"{k} {float(out.tb_dict[k]):.5f}/{float(ref.tb_dict[k]):.5f}" for k in sorted(ref.tb_dict)))
+
+
+def test_input_prefetcher_worker_thread_hands_out_the_same_batches(monkeypatch):
+    """pcdet.models.InputPrefetcher with the preparation on its worker thread (the default) and on the caller's thread
+    (TODA_PREFETCH_THREAD=0): the same voxels, coordinates and rulebook tables in the same order, StopIteration behind the last
+    batch, and an exception of the batch source surfaces in next()."""
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import InputPrefetcher, build_network
+
+    cfg = small_cfg("centerpoint_voxel_waymo", rng_xy=16.0, n_points=20000)
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    net = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).cuda().train()
+    cols = [ds.collate_batch([ds[2 * i], ds[2 * i + 1]]) for i in range(3)]
+
+    def source(fail_at=None):
+        for i, c in enumerate(cols):
+            if i == fail_at:
+                raise RuntimeError("source failed")
+            yield {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+
+    def drain(threaded):
+        monkeypatch.setenv("TODA_PREFETCH_THREAD", "1" if threaded else "0")
+        pre = InputPrefetcher(source(), net, torch.device("cuda", 0))
+        assert pre.threaded == threaded
+        out = []
+        while True:
+            try:
+                b = pre.next()
+            except StopIteration:
+                break
+            pre.kick()
+            torch.cuda.current_stream().synchronize()
+            plan = b["sparse_index_plan"][0] if "sparse_index_plan" in b else None
+            out.append((b["voxels"].clone(), b["voxel_coords"].clone(), b["voxel_num_points"].clone(), plan))
+        return out
+
+    a, b = drain(True), drain(False)
+    assert len(a) == len(b) == 3
+    for (va, ca, na, pa), (vb, cb, nb, pb) in zip(a, b):
+        assert torch.equal(va, vb) and torch.equal(ca, cb) and torch.equal(na, nb)
+        assert pa is not None and sorted(pa) == sorted(pb) and len(pa) >= 8          # the whole backbone's rulebooks came with the batch
+        for key in pa:
+            ea, eb = pa[key], pb[key]
+            ra = ea["rb"] if isinstance(ea, dict) else getattr(ea, "rb", ea)
+            rbb = eb["rb"] if isinstance(eb, dict) else getattr(eb, "rb", eb)
+            assert torch.equal(ra.nbr_fwd, rbb.nbr_fwd), key
+    monkeypatch.setenv("TODA_PREFETCH_THREAD", "1")
+    pre = InputPrefetcher(source(fail_at=1), net, torch.device("cuda", 0))
+    pre.next()
+    pre.kick()
+    with pytest.raises(RuntimeError, match="source failed"):
+        pre.next()

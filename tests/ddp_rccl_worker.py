@@ -39,9 +39,30 @@ def main():
     ret.loss.backward()
     ones = torch.ones(1, device=dev)
     dist.all_reduce(ones)
+    grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    # the optimizer step of the training loop on the synchronised gradients (bucket views): two launches through toda_clip_adam_step;
+    # every rank must end up with the same parameters, and they must equal the torch path's on a copy of the model
+    from helpers import abi_calls
+    from toda_amd.tools.train_utils.optimization import OneCycleAdam, clip_and_step
+    twin = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).to(dev).train()      # (the stepped model holds its forward's activations: no deepcopy)
+    twin.load_state_dict(model.state_dict())
+    for (_, p), q in zip(model.named_parameters(), twin.parameters()):
+        q.grad = None if p.grad is None else p.grad.detach().clone()
+    opt, opt_t = OneCycleAdam(model, wd=0.01), OneCycleAdam(twin, wd=0.01)
+    opt_t._hip_step = False
+    opt.lr = opt_t.lr = 1e-3
+    with abi_calls("toda_clip_adam_step") as calls:
+        norm = clip_and_step(opt, list(ddp.parameters()), 10.0)
+    clip_and_step(opt_t, list(twin.parameters()), 10.0)
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    flat_t = torch.cat([p.detach().flatten() for p in twin.parameters()])
+    lo, hi = flat.clone(), flat.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     if rank == 0:
-        grads = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
-        torch.save({"loss": ret.loss.detach().cpu(), "grads": grads, "ranks": int(ones.item())}, out)
+        torch.save({"loss": ret.loss.detach().cpu(), "grads": grads, "ranks": int(ones.item()), "fused_calls": calls["toda_clip_adam_step"],
+                    "rank_spread": float((hi - lo).abs().max()), "vs_torch": float((flat - flat_t).abs().max() / flat_t.abs().max()),
+                    "grad_norm": float(norm)}, out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -38,6 +38,9 @@ def test_two_rank_rccl_ddp_equals_single_gpu(tmp_path, backend):
     assert p.returncode == 0, p.stderr[-3000:]
     got = torch.load(out)
     assert got["ranks"] == 2
+    # the two-launch optimizer step ran on the data-parallel model's (bucket-view) gradients, left every rank with the same parameters
+    # and agrees with the torch path
+    assert got["fused_calls"] == 1 and got["rank_spread"] == 0.0 and got["vs_torch"] <= 2e-6 and got["grad_norm"] > 0, got
 
     from tests.test_ddp_gloo import _freeze_bn, _tiny_cfg
     from toda_amd.pcdet.datasets import SyntheticLidarDataset

@@ -116,10 +116,10 @@ class KernelTimer:
         ops.gather_gemm = labelled
         self._orig_stats = ops.gather_gemm_with_stats      # forward convs whose epilogue also takes the BatchNorm moments
 
-        def labelled_stats(feat, wp, nbr, c_produce, bias=None):
+        def labelled_stats(feat, wp, nbr, c_produce, bias=None, **kw):
             if self._enabled and len(self.records) < self.CAPACITY:
                 self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
-            return self._orig_stats(feat, wp, nbr, c_produce, bias)
+            return self._orig_stats(feat, wp, nbr, c_produce, bias, **kw)
 
         ops.gather_gemm_with_stats = labelled_stats
         self._orig_classed = ops.gather_gemm_classed        # data gradient of the strided convs (same dispatch-stamped launches)

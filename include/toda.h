@@ -266,6 +266,12 @@ int toda_bn_finalize(const double* sums /*[2c] from toda_rows_moments*/, int n, 
                      const float* gamma, const float* beta, float* running_mean /*nullable*/,
                      float* running_var /*nullable*/, float momentum, float eps, int training,
                      float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* The same with the fold of the per-workgroup partial sums inside (training mode): toda_spconv_gather_gemm_stats_partials leaves
+ * `blocks` partials per column behind the 2c result slots of `sums`; one launch folds them in the fixed order of the separate
+ * fold, writes the totals to sums[0:2c] and finalises.  Saves one launch per BatchNorm1d of the sparse backbone. */
+int toda_bn_finalize_partials(double* sums, int blocks, int n, int c, const float* gamma, const float* beta,
+                              float* running_mean /*nullable*/, float* running_var /*nullable*/, float momentum, float eps,
+                              float* mean, float* invstd, float* scale, float* shift, void* stream);
 /* Backward of the same pair.  stats = [mean | invstd | scale | shift] (4*c floats, as written by
  * toda_bn_finalize into one buffer).  dz = dy * (x*scale+shift > 0) (relu != 0) or dy;
  * sums[0:c] = sum dz = d(beta), sums[c:2c] = sum dz*xhat = d(gamma) (zeroed and filled by the call); the same 2c values rounded
@@ -406,6 +412,11 @@ size_t toda_spconv_gather_gemm_stats_doubles(int n_out, int c_produce);
 int toda_spconv_gather_gemm_stats(const float* in, int n_in, int c_gather, const float* packed_w, const int32_t* nbr,
                                   int n_out, int k_vol, int c_produce, const float* bias, float* out, double* sums,
                                   size_t sums_doubles, void* stream);
+/* toda_spconv_gather_gemm_stats without the fold of the partial sums: *blocks_out (host memory, written before the call returns)
+ * = number of partials per column, to be handed to toda_bn_finalize_partials. */
+int toda_spconv_gather_gemm_stats_partials(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
+                                           int n_out, int k_vol, int c_produce, const float* bias /*nullable*/, float* out,
+                                           double* sums, size_t sums_doubles, int* blocks_out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Dense 3x3 / stride 1 / pad 1 fp32 convolution of the BEV neck and the dense heads (NCHW), replacing

@@ -250,6 +250,16 @@ def test_conv_epilogue_bn_moments_equal_a_pass_over_the_output(cin, cout, k):
     a = ops.bn_rows(out, bn, True, sums=sums)
     b = ops.bn_rows(out, bn2, True)
     assert float((a - b).abs().max()) < 1e-5 and torch.allclose(bn.running_var, bn2.running_var, rtol=1e-6, atol=1e-7)
+    # the same launch with its partial sums left unfolded + toda_bn_finalize_partials (fold and finalise in one launch, the default
+    # route of the backbone): the same output, totals, normalised rows and running statistics - bit for bit (same fold order)
+    out_p, part, blocks = ops.gather_gemm_with_stats(dev(feat), wp, rb.nbr_fwd, cout, dev(bias), partials=True)
+    assert blocks >= 1 and torch.equal(out_p, out)
+    bn3 = torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01).cuda().train()
+    with H.abi_calls("toda_bn_finalize_partials", "toda_bn_finalize") as calls:
+        c3 = ops.bn_rows(out_p, bn3, True, sums=(part, blocks))
+    assert calls["toda_bn_finalize_partials"] == 1 and calls["toda_bn_finalize"] == 0
+    assert torch.equal(part[:2 * cout], sums[:2 * cout]) and torch.equal(c3, a)
+    assert torch.equal(bn3.running_mean, bn.running_mean) and torch.equal(bn3.running_var, bn.running_var)
 
 
 @pytest.mark.parametrize("ks,st,pd", CONV_GEOMS)

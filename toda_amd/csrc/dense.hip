@@ -292,6 +292,51 @@ bn_finalize_kernel(const double* __restrict__ sums, int n, int c, const float* _
     shift_out[ch] = b - mean * g * invstd;
 }
 
+// fold_partials_kernel + bn_finalize_kernel in one launch (training mode): block ch folds its two columns of per-workgroup
+// partials (sum and sum of squares of channel ch) with EXACTLY fold_partials_kernel's order - thread-strided partial sums, then the
+// LDS tree - leaves the totals in sums[ch] / sums[c + ch] and finalises the channel.  Saves a launch per BatchNorm1d.
+__global__ void __launch_bounds__(DN_BLOCK)
+bn_fold_finalize_kernel(double* __restrict__ sums, int blocks, int n, int c, const float* __restrict__ gamma,
+                        const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+                        float momentum, float eps, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                        float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    __shared__ double part[DN_BLOCK];
+    const int ch = blockIdx.x;
+    double tot[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double* src = sums + 2 * c + (size_t)(q * c + ch) * blocks;
+        double acc = 0.0;
+        for (int g = threadIdx.x; g < blocks; g += DN_BLOCK) acc += src[g];
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = DN_BLOCK / 2; w > 0; w >>= 1) {
+            if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+            __syncthreads();
+        }
+        tot[q] = part[0];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    sums[ch] = tot[0];
+    sums[c + ch] = tot[1];
+    const double m = tot[0] / (double)n;
+    double v = tot[1] / (double)n - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)m, var = (float)v;
+    if (running_mean) {
+        const double unbiased = n > 1 ? v * (double)n / (double)(n - 1) : v;
+        running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * mean;
+        running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)unbiased;
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[ch] : 1.0f, b = beta ? beta[ch] : 0.0f;
+    mean_out[ch] = mean;
+    invstd_out[ch] = invstd;
+    scale_out[ch] = g * invstd;
+    shift_out[ch] = b - mean * g * invstd;
+}
+
 // grid for the grid-stride elementwise kernels: <= EW_BLOCKS blocks and (blocks * 256 * 4) % c == 0
 static int ew_grid(long long n4, int c) {
     long long blocks = (n4 + DN_BLOCK - 1) / DN_BLOCK;
@@ -400,6 +445,21 @@ extern "C" int toda_rows_bn_bwd_res(const float* dy, const float* x, const float
 extern "C" int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int n, int c,
                                 int relu, double* sums, float* dx, void* stream) {
     return toda_rows_bn_bwd_res(dy, x, nullptr, stats, gamma, n, c, relu, sums, dx, nullptr, stream);
+}
+
+// Training-mode toda_bn_finalize over UNFOLDED partials (toda_spconv_gather_gemm_stats_partials): `blocks` partial sums per column
+// behind the 2 c result slots; the totals are left in sums[0:2c] as toda_bn_finalize would have found them.
+extern "C" int toda_bn_finalize_partials(double* sums, int blocks, int n, int c, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                         float* invstd, float* scale, float* shift, void* stream) {
+    TODA_CHECK_ARG(sums && mean && invstd && scale && shift, "bn_finalize_partials: null argument");
+    TODA_CHECK_ARG(c >= 1 && c <= DN_BLOCK && blocks >= 1 && n >= 1, "bn_finalize_partials: channels must be <= 256, blocks and rows >= 1 (got %d, %d, %d)", c,
+                   blocks, n);
+    TODA_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_partials: running_mean and running_var go together");
+    hipLaunchKernelGGL(bn_fold_finalize_kernel, dim3(c), dim3(DN_BLOCK), 0, (hipStream_t)stream, sums, blocks, n, c, gamma, beta, running_mean,
+                       running_var, momentum, eps, mean, invstd, scale, shift);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
 }
 
 extern "C" int toda_bn_finalize(const double* sums, int n, int c, const float* gamma, const float* beta,

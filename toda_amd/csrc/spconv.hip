@@ -2261,6 +2261,21 @@ extern "C" int toda_rulebook_row_order(const int32_t* nbr, int n_out, int k_vol,
     return TODA_OK;
 }
 
+namespace toda {
+__global__ void fold_partials_kernel(double* __restrict__ sums, int blocks, int cols);   // dense.hip
+}
+// The per-workgroup BatchNorm partials of a statistics launch are folded right away (fold_partials_kernel), or - for
+// toda_spconv_gather_gemm_stats_partials - left for toda_bn_finalize_partials, which folds and finalises in one launch; the entry
+// point then reports the number of partials per column through this (thread-local: the call is synchronous on the host) slot.
+static thread_local int* g_stats_blocks_out = nullptr;
+static void fold_or_defer(double* stats, int blocks, int c_produce, hipStream_t s) {
+    if (g_stats_blocks_out) {
+        *g_stats_blocks_out = blocks;
+        return;
+    }
+    hipLaunchKernelGGL(toda::fold_partials_kernel, dim3(2 * c_produce), dim3(256), 0, s, stats, blocks, 2 * c_produce);
+}
+
 static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
                             int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream,
                             const unsigned char* cls_sorted = nullptr, const toda::GatherClasses* cls_table = nullptr);
@@ -2463,6 +2478,25 @@ extern "C" int toda_spconv_gather_gemm_stats(const float* in, int n_in, int c_ga
     return gather_gemm_impl(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, nullptr, sums, stream);
 }
 
+// The same launch without the fold: *blocks_out (host) = partial sums per column in the scratch behind the 2 c result slots, for
+// toda_bn_finalize_partials (one launch folds them in the same fixed order and finalises the statistics).
+extern "C" int toda_spconv_gather_gemm_stats_partials(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,
+                                                      int n_out, int k_vol, int c_produce, const float* bias, float* out, double* sums,
+                                                      size_t sums_doubles, int* blocks_out, void* stream) {
+    TODA_CHECK_ARG(sums != nullptr && blocks_out != nullptr && gg_stats_supported(c_gather, c_produce) && n_out > 0 && n_in > 0,
+                   "gather_gemm_stats_partials: unsupported channel pair (%d -> %d), empty table or null argument", c_gather, c_produce);
+    TODA_CHECK_ARG(sums_doubles >= toda_spconv_gather_gemm_stats_doubles(n_out, c_produce), "gather_gemm_stats_partials: statistics buffer too small");
+    *blocks_out = 0;
+    g_stats_blocks_out = blocks_out;
+    const int rc = gather_gemm_impl(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, nullptr, sums, stream);
+    g_stats_blocks_out = nullptr;
+    if (rc == TODA_OK && *blocks_out <= 0) {
+        set_error("gather_gemm_stats_partials: the launch took no statistics");
+        return TODA_EINVAL;
+    }
+    return rc;
+}
+
 static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
                             int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream,
                             const unsigned char* cls_sorted, const toda::GatherClasses* cls_table) {
@@ -2516,7 +2550,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
                   k_vol, c_produce, bias, out, stats);
         TODA_LAUNCH_CHECK();
         if (stats) {
-            hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c_produce), dim3(256), 0, s, stats, blocks, 2 * c_produce);
+            fold_or_defer(stats, blocks, c_produce, s);
             TODA_LAUNCH_CHECK();
         }
         return TODA_OK;
@@ -2608,7 +2642,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
         if (stats) {      // fold the per-workgroup partial sums of the launch above (same grid arithmetic as GL_RT / GL_ROW)
             const int rr = NT >= 8 ? 1 : ((env_rt == 4 && Q <= 4 && NT <= 4) ? 4 : (env_rt == 1 ? 1 : 2));
             const int blocks = cdiv(cdiv(n_out, 16 * rr), SC_BLOCK / 64);
-            hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c_produce), dim3(256), 0, s, stats, blocks, 2 * c_produce);
+            fold_or_defer(stats, blocks, c_produce, s);
             TODA_LAUNCH_CHECK();
         }
         return TODA_OK;

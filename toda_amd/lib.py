@@ -39,6 +39,7 @@ SIGNATURES = {
     "toda_spconv_gather_gemm_stats_supported": (_i, [_i, _i]),
     "toda_spconv_gather_gemm_stats_doubles": (_sz, [_i, _i]),
     "toda_spconv_gather_gemm_stats": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "toda_spconv_gather_gemm_stats_partials": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "toda_halo_supported": (_i, [_i, _i, _i]),
     "toda_halo_plan_bytes": (_sz, [_i, _i, _i]),
     "toda_halo_plan_workspace_bytes": (_sz, [_i, _i, _vp]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "toda_rows_moments": (_i, [_vp, _i, _i, _vp, _vp]),
     "toda_rows_affine_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "toda_bn_finalize": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp, _vp, _vp]),
+    "toda_bn_finalize_partials": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "toda_rows_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_rows_bn_bwd_res": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "toda_conv3x3s2_supported": (_i, [_i, _i, _i, _i, _i]),

@@ -404,14 +404,22 @@ def gather_gemm_stats_supported(c_gather, c_produce):
     return bool(L.load().toda_spconv_gather_gemm_stats_supported(int(c_gather), int(c_produce)))
 
 
-def gather_gemm_with_stats(feat, wp, nbr, c_produce, bias=None):
+def gather_gemm_with_stats(feat, wp, nbr, c_produce, bias=None, partials=False):
     """Forward gather-GEMM that also returns the BatchNorm moments of its output (sum, sum of squares per channel in
-    sums[:2c], fp64) from the kernel's epilogue - the layout toda_bn_finalize reads."""
+    sums[:2c], fp64) from the kernel's epilogue - the layout toda_bn_finalize reads.  partials=True: the per-workgroup partial
+    sums are left unfolded and (out, sums, blocks) is returned for toda_bn_finalize_partials (one launch less per layer)."""
     lib = L.load()
     K, n_out = nbr.shape
     out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
     nd = lib.toda_spconv_gather_gemm_stats_doubles(n_out, c_produce)
     sums = torch.empty((nd,), dtype=torch.float64, device=feat.device)
+    if partials:
+        import ctypes
+        blocks = ctypes.c_int(0)
+        rc = lib.toda_spconv_gather_gemm_stats_partials(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce,
+                                                        L.ptr(bias), L.ptr(out), L.ptr(sums), nd, ctypes.addressof(blocks), L.stream())
+        L.check(rc, "toda_spconv_gather_gemm_stats_partials")
+        return out, sums, int(blocks.value)
     rc = lib.toda_spconv_gather_gemm_stats(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce,
                                            L.ptr(bias), L.ptr(out), L.ptr(sums), nd, L.stream())
     L.check(rc, "toda_spconv_gather_gemm_stats")
@@ -574,12 +582,14 @@ class _SparseConv(torch.autograd.Function):
         compact = not want_stats and _compact_route(features.shape[1], weight.shape[0], rb.nbr_fwd, rb.order_for(rb.nbr_fwd))
         if wp_fwd is None and not compact:
             wp_fwd = pack_weight(weight, False, False)
-        sums = None
+        sums, blocks = None, 0
         plan = rb.halo.get(weight.shape[-1]) if (rb.kind == "subm" and weight.shape[0] == weight.shape[-1] and features.shape[0] == rb.n_out) else None
         if plan is not None and want_stats:
             out, sums = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias, True)
         elif plan is not None:
             out = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias)
+        elif want_stats and FOLD_IN_FINALIZE:
+            out, sums, blocks = gather_gemm_with_stats(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, partials=True)
         elif want_stats:
             out, sums = gather_gemm_with_stats(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
         elif compact:
@@ -594,7 +604,7 @@ class _SparseConv(torch.autograd.Function):
         ctx.has_bias = bias is not None
         if want_stats:
             ctx.mark_non_differentiable(sums)
-            return out, sums
+            return out, sums, blocks       # blocks > 0: sums holds unfolded per-workgroup partials (toda_bn_finalize_partials)
         return out
 
     @staticmethod
@@ -639,6 +649,7 @@ class _SparseConv(torch.autograd.Function):
 
 
 FUSE_BN_STATS = _os.environ.get("TODA_FUSE_BN_STATS", "1") == "1"
+FOLD_IN_FINALIZE = _os.environ.get("TODA_BN_FOLD_FINALIZE", "1") == "1"     # the fold of the epilogue's partial sums inside the finalise launch
 
 
 def sparse_conv(features, weight, bias, rulebook, packed_weight=None, want_stats=False, packed_dgrad=None):
@@ -650,7 +661,8 @@ def sparse_conv(features, weight, bias, rulebook, packed_weight=None, want_stats
           and features.shape[0] > 0 and rulebook.order_for(rulebook.nbr_fwd) is None)
     if not ok:
         return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, False, packed_dgrad), None
-    return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, True, packed_dgrad)
+    out, sums, blocks = _SparseConv.apply(features, weight, bias, rulebook, packed_weight, True, packed_dgrad)
+    return out, ((sums, blocks) if blocks else sums)
 
 
 # ------------------------------------------------------------------------ sparse <-> dense
@@ -742,6 +754,26 @@ class _BNRows(torch.autograd.Function):
         n, c = x.shape
         dev = x.device
         stats = torch.empty((4, c), dtype=torch.float32, device=dev)  # mean, invstd, scale, shift
+        if isinstance(sums, tuple) and training:      # unfolded partials from the convolution's epilogue: fold + finalise in one launch
+            part, blocks = sums
+            rc = lib.toda_bn_finalize_partials(L.ptr(part), int(blocks), n, c, L.ptr(weight), L.ptr(bias), L.ptr(running_mean), L.ptr(running_var),
+                                               float(momentum), float(eps), L.ptr(stats[0]), L.ptr(stats[1]), L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
+            L.check(rc, "toda_bn_finalize_partials")
+            sums = part
+        else:
+            if isinstance(sums, tuple):
+                sums = None
+            sums = _BNRows._finalize(lib, x, n, c, dev, sums, training, weight, bias, running_mean, running_var, momentum, eps, stats)
+        y = torch.empty_like(x)
+        rc = lib.toda_rows_affine_act(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(residual), n, c, int(bool(relu)), L.ptr(y),
+                                      L.stream())
+        L.check(rc, "toda_rows_affine_act")
+        ctx.save_for_backward(x, stats, weight, residual)
+        ctx.meta = (n, c, bool(relu), bool(training))
+        return y
+
+    @staticmethod
+    def _finalize(lib, x, n, c, dev, sums, training, weight, bias, running_mean, running_var, momentum, eps, stats):
         if sums is None or not training:     # moments not delivered by the producing convolution: one pass over x
             sums = torch.empty((lib.toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=dev)   # [0:2c] result + per-block scratch
             if training:
@@ -750,13 +782,7 @@ class _BNRows(torch.autograd.Function):
                                   float(momentum), float(eps), int(bool(training)), L.ptr(stats[0]), L.ptr(stats[1]),
                                   L.ptr(stats[2]), L.ptr(stats[3]), L.stream())
         L.check(rc, "toda_bn_finalize")
-        y = torch.empty_like(x)
-        rc = lib.toda_rows_affine_act(L.ptr(x), L.ptr(stats[2]), L.ptr(stats[3]), L.ptr(residual), n, c, int(bool(relu)), L.ptr(y),
-                                      L.stream())
-        L.check(rc, "toda_rows_affine_act")
-        ctx.save_for_backward(x, stats, weight, residual)
-        ctx.meta = (n, c, bool(relu), bool(training))
-        return y
+        return sums
 
     @staticmethod
     def backward(ctx, gy):

@@ -86,7 +86,7 @@ class OpTable:
             self._pairs[key] = nbr       # counted after the clock stops (rows())
         return key
 
-    def _cost_gather_gemm(self, feat, wp, nbr, c_produce, bias=None, order=None):
+    def _cost_gather_gemm(self, feat, wp, nbr, c_produce, bias=None, order=None, partials=False):
         K, n_out = nbr.shape
         n_src, cg = feat.shape
         pk = self._count_pairs(nbr)

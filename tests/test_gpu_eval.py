@@ -189,3 +189,49 @@ def test_training_with_gt_sampling_and_world_augmentations(tmp_path):
     np.random.seed(0)
     item = ds[0]
     assert item["augmentation_list"][-3:] == ["random_world_flip", "random_world_rotation", "random_world_scaling"] or "augmentation_list" in item
+
+
+def test_stage2_consistency_helpers_on_the_gpu_match_the_cpu_path():
+    """The GPU forms of the stage-2 helpers - candidates padded to K rows behind a mask instead of boolean-mask indexing, the
+    world rotation with host-built scalars instead of a device tensor (no host synchronisation per sample) - against the CPU
+    forms pinned by the reference fixture (tests/golden/consistency.npz): reverse_transform and both consistency terms, with
+    unselected rows of arbitrary content, an empty sample and a sample with nothing selected on one side."""
+    import os
+
+    from toda_amd.pcdet import models as M
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "consistency.npz"))
+    aug_list = [["random_world_flip", "random_world_rotation", "random_world_scaling"], ["random_world_rotation"], ["gt_sampling", "random_world_flip"]]
+    aug_params = [{"random_world_flip": ["x", "y"], "random_world_rotation": 0.3, "random_world_scaling": 1.04},
+                  {"random_world_rotation": -0.2}, {"gt_sampling": None, "random_world_flip": ["y"]}]
+    meta = {"augmentation_list": aug_list, "augmentation_params": aug_params}
+    fwd_cpu = [{"pred_boxes": torch.from_numpy(z[f"fwd{i}"].copy())} for i in range(3)]
+    fwd_gpu = [{"pred_boxes": torch.from_numpy(z[f"fwd{i}"].copy()).cuda()} for i in range(3)]
+    back_cpu, back_gpu = M.reverse_transform(fwd_cpu, meta), M.reverse_transform(fwd_gpu, meta)
+    for c, g in zip(back_cpu, back_gpu):
+        assert g["pred_boxes"].is_cuda and torch.allclose(g["pred_boxes"].cpu(), c["pred_boxes"], rtol=0, atol=2e-6)
+
+    rng = np.random.default_rng(0)
+
+    def padded(arr, k=24):
+        n = len(arr)
+        rows = rng.uniform(-50, 50, (k, arr.shape[1])).astype(np.float32)      # unselected rows: arbitrary content
+        pos = np.sort(rng.choice(k, n, replace=False))
+        rows[pos] = arr
+        m = np.zeros(k, bool)
+        m[pos] = True
+        return {"pred_boxes": torch.from_numpy(rows).cuda(), "mask": torch.from_numpy(m).cuda()}
+
+    adv = [z[f"adv{i}"] for i in range(3)]
+    org = [z[f"org{i}"] for i in range(3)]
+    ref = M.get_consistency_loss([{"pred_boxes": torch.from_numpy(a.copy())} for a in adv], [{"pred_boxes": torch.from_numpy(o.copy())} for o in org])
+    got = M.get_consistency_loss([padded(a) for a in adv], [padded(o) for o in org])
+    for r, g in zip(ref, got):
+        assert abs(float(g) - float(r)) <= 1e-6 * max(1.0, abs(float(r))), (float(g), float(r))
+    # nothing selected on one side of a sample: that sample contributes nothing, the normalisation still counts it
+    adv2 = adv + [adv[0]]
+    org2 = org + [np.zeros((0, 7), np.float32)]
+    ref = M.get_consistency_loss([{"pred_boxes": torch.from_numpy(a.copy())} for a in adv2], [{"pred_boxes": torch.from_numpy(o.copy())} for o in org2])
+    got = M.get_consistency_loss([padded(a) for a in adv2], [padded(o) for o in org2])
+    for r, g in zip(ref, got):
+        assert abs(float(g) - float(r)) <= 1e-6 * max(1.0, abs(float(r))), (float(g), float(r))

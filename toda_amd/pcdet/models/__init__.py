@@ -177,6 +177,13 @@ def model_fn_decorator():
 # --------------------------------------------------------------------------------------------
 # TODA stage 2: "2 forward + 1 backward" consistency step (reference :88-260).
 # ---------------------------------------------------------------------------------------------
+def common_utils_rot(a):
+    """(r00, r01, r10, r11, angle) of the row-vector rotation [[c, s], [-s, c]] in fp32, as Python floats."""
+    ang = torch.tensor([a], dtype=torch.float32)
+    c, s_ = float(torch.cos(ang)), float(torch.sin(ang))
+    return c, s_, -s_, c, float(ang)
+
+
 def random_world_flip(box_preds, params, reverse=False):
     order = ("y", "x") if reverse else ("x", "y")
     for axis in order:
@@ -192,6 +199,16 @@ def random_world_flip(box_preds, params, reverse=False):
 
 
 def random_world_rotation(box_preds, params, reverse=False):
+    if box_preds.is_cuda:
+        # the same rotation with the matrix built on the host and handed over as kernel scalars: torch.tensor(..., device=cuda) is a
+        # synchronous copy and float(angle) a read-back - each drains the stream (27 of the 54 ms of a stage-2 step sat in them)
+        a = float(-params if reverse else params)
+        rot = common_utils_rot(a)
+        x, y = box_preds[:, 0].clone(), box_preds[:, 1].clone()
+        box_preds[:, 0] = x * rot[0] + y * rot[2]
+        box_preds[:, 1] = x * rot[1] + y * rot[3]
+        box_preds[:, 6] += rot[4]
+        return box_preds
     angle = torch.tensor([-params if reverse else params], dtype=torch.float32, device=box_preds.device)
     c, s_, z, o = torch.cos(angle), torch.sin(angle), angle.new_zeros(1), angle.new_ones(1)
     rot = torch.stack((c, s_, z, -s_, c, z, z, z, o), dim=1).reshape(3, 3)
@@ -234,8 +251,9 @@ def filter_boxes_centerpoint(batch_dict, model):
 
     post = head.model_cfg.POST_PROCESSING
     ref = batch_dict["pred_dicts"][0]["hm"]
-    limit = torch.tensor(post.POST_CENTER_LIMIT_RANGE, dtype=torch.float32, device=ref.device)
-    out = [{"pred_boxes": [], "pred_scores": []} for _ in range(batch_dict["batch_size"])]
+    limit = head._device_const("limit", ref.device, lambda: torch.tensor(post.POST_CENTER_LIMIT_RANGE, dtype=torch.float32))     # uploaded once
+    padded = ref.is_cuda       # on the GPU the K candidates stay in place behind a mask (no row count read back per sample)
+    out = [{"pred_boxes": [], "pred_scores": [], "mask": []} for _ in range(batch_dict["batch_size"])]
     for pred in batch_dict["pred_dicts"]:
         # As the reference (:328): .sigmoid() of whatever pred_dict holds.  In the training step get_loss has already replaced
         # pred["hm"] by its clamped sigmoid in place (center_head.py:233), so the scores here are sigmoid(sigmoid(logit)) in
@@ -245,13 +263,19 @@ def filter_boxes_centerpoint(batch_dict, model):
             heatmap=hm, rot_cos=pred["rot"][:, 0:1], rot_sin=pred["rot"][:, 1:2], center=pred["center"],
             center_z=pred["center_z"], dim=pred["dim"].exp(), vel=None, point_cloud_range=head.point_cloud_range,
             voxel_size=head.voxel_size, feature_map_stride=head.feature_map_stride, K=post.MAX_OBJ_PER_SAMPLE,
-            circle_nms=False, score_thresh=post.SCORE_THRESH, post_center_limit_range=limit)
+            circle_nms=False, score_thresh=post.SCORE_THRESH, post_center_limit_range=limit, padded=padded)
         for k, d in enumerate(decoded):
             out[k]["pred_boxes"].append(d["pred_boxes"])
             out[k]["pred_scores"].append(d["pred_scores"])
+            if padded:
+                out[k]["mask"].append(d["mask"])
     for d in out:
         d["pred_boxes"] = torch.cat(d["pred_boxes"], dim=0)
         d["pred_scores"] = torch.cat(d["pred_scores"], dim=0)
+        if padded:
+            d["mask"] = torch.cat(d["mask"], dim=0)
+        else:
+            del d["mask"]
     return out
 
 
@@ -264,6 +288,22 @@ def get_consistency_loss(adv_boxes, org_boxes):
     for adv, org in zip(adv_boxes, org_boxes):
         a, o = adv["pred_boxes"].detach(), org["pred_boxes"].detach()
         norm += 1
+        if "mask" in adv and "mask" in org:
+            # the same terms over padded candidate lists: a pair counts when both boxes are selected (invalid rows / columns sit at
+            # infinite distance), sums run over the selected rows only, n = number of selected boxes of both passes
+            va, vo = adv["mask"], org["mask"]
+            d2 = ((a[:, None, :3] - o[None, :, :3]) ** 2).sum(-1)
+            d2 = d2.masked_fill(~(va[:, None] & vo[None, :]), float("inf"))
+            d_a, idx_o_of_a = d2.min(1)
+            d_o, idx_a_of_o = d2.min(0)
+            m_o = ((d_a < 1) & va).float().unsqueeze(-1)
+            m_a = ((d_o < 1) & vo).float().unsqueeze(-1)
+            n = (va.sum() + vo.sum()).clamp(min=1).float()
+            centre_terms.append((((a[:, :3] - o[idx_o_of_a, :3]) * m_o).abs().sum()
+                                 + ((o[:, :3] - a[idx_a_of_o, :3]) * m_a).abs().sum()) / n)
+            size_terms.append(((F.mse_loss(o[idx_o_of_a, 3:6], a[:, 3:6], reduction="none") * m_o).sum()
+                               + (F.mse_loss(a[idx_a_of_o, 3:6], o[:, 3:6], reduction="none") * m_a).sum()) / n)
+            continue
         if a.shape[0] == 0 or o.shape[0] == 0:
             continue
         d2 = ((a[:, None, :3] - o[None, :, :3]) ** 2).sum(-1)

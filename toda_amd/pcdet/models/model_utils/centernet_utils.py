@@ -58,7 +58,10 @@ def circle_nms(boxes, min_radius, post_max_size=83):
 
 def decode_bbox_from_heatmap(heatmap, rot_cos, rot_sin, center, center_z, dim, point_cloud_range=None,
                              voxel_size=None, feature_map_stride=None, vel=None, K=100, circle_nms=False,
-                             score_thresh=None, post_center_limit_range=None):
+                             score_thresh=None, post_center_limit_range=None, padded=False):
+    """padded=True (the stage-2 consistency step on the GPU): every sample keeps its K candidates and carries the selection as a
+    boolean "mask" instead of being cut down to the selected rows - boolean-mask indexing has to read the row count back to the
+    host, i.e. it drains the stream once per sample and pass (four times per stage-2 step)."""
     batch_size = heatmap.shape[0]
     if circle_nms:
         heatmap = _nms(heatmap)
@@ -83,6 +86,9 @@ def decode_bbox_from_heatmap(heatmap, rot_cos, rot_sin, center, center_z, dim, p
     out = []
     for k in range(batch_size):
         m = mask[k]
+        if padded:
+            out.append({"pred_boxes": final_box_preds[k], "pred_scores": final_scores[k], "pred_labels": final_class_ids[k], "mask": m})
+            continue
         out.append({"pred_boxes": final_box_preds[k, m], "pred_scores": final_scores[k, m],
                     "pred_labels": final_class_ids[k, m]})
         assert not circle_nms, "circle_nms decode is not wired on this path"

@@ -212,6 +212,14 @@ int toda_spconv_gather_gemm_compact_supported(int c_gather, int c_produce, int k
 int toda_spconv_gather_gemm_compact(const float* in, int n_in, int c_gather, const float* w, int w_cout, int w_cin,
                                     int transpose, int flip_k, const int32_t* nbr, int n_out, int k_vol, int c_produce,
                                     const float* bias /*nullable*/, float* out, void* stream);
+/* The same launch with the following BatchNorm1d's moments from the epilogue (the <= 16-channel layers of the backbone,
+ * reference spconv_backbone.py:21-25): sums = 2 c results + [2 c][workgroups] scratch as toda_spconv_gather_gemm_stats;
+ * blocks_out == NULL: folded by the call, else left for toda_bn_finalize_partials with *blocks_out (host) partials per column. */
+size_t toda_spconv_gather_gemm_compact_stats_doubles(int n_out, int c_produce);
+int toda_spconv_gather_gemm_compact_stats(const float* in, int n_in, int c_gather, const float* w, int w_cout, int w_cin,
+                                          int transpose, int flip_k, const int32_t* nbr, int n_out, int k_vol,
+                                          int c_produce, const float* bias /*nullable*/, float* out, double* sums,
+                                          size_t sums_doubles, int* blocks_out /*nullable*/, void* stream);
 
 /* dw[co][k][ci] = sum_o in[nbr[k*n_out+o], ci] * dout[o, co] */
 size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout);

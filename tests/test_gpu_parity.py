@@ -320,6 +320,19 @@ def test_compacting_narrow_gather_gemm_matches_the_output_stationary_kernel(cg, 
         ref = ops.gather_gemm(g, ops.pack_weight(w, True, rb.flip_bwd), rb.nbr_bwd, cg, None)
         got = ops.gather_gemm_compact(g, w, rb.nbr_bwd, cg, None, True, rb.flip_bwd)
         assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # BatchNorm moments from the epilogue (the <= 16-channel layers' conv -> BatchNorm1d): equal to a float64 pass over the output;
+    # the folded and the unfolded (toda_bn_finalize_partials) routes normalise to the same bits as the separate moments pass does to 1e-5
+    if cp % 4 == 0 and 256 % cp == 0:
+        out_s, part, blocks = ops.gather_gemm_compact(x, w, rb.nbr_fwd, cp, bias, stats=True)
+        assert torch.equal(out_s, ops.gather_gemm_compact(x, w, rb.nbr_fwd, cp, bias)) and blocks == (len(idx) + 255) // 256
+        bn_a = torch.nn.BatchNorm1d(cp, eps=1e-3, momentum=0.01).cuda().train()
+        bn_b = torch.nn.BatchNorm1d(cp, eps=1e-3, momentum=0.01).cuda().train()
+        ya = ops.bn_rows(out_s, bn_a, True, sums=(part, blocks))
+        yb = ops.bn_rows(out_s, bn_b, True)
+        ref64 = out_s.double()
+        np.testing.assert_allclose(part[:cp].cpu().numpy(), ref64.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(part[cp:2 * cp].cpu().numpy(), (ref64 * ref64).sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+        assert float((ya - yb).abs().max()) < 1e-5 and torch.allclose(bn_a.running_var, bn_b.running_var, rtol=1e-6, atol=1e-7)
     # nothing to gather: the bias alone
     none = torch.full_like(rb.nbr_fwd, -1)
     got = ops.gather_gemm_compact(x, w, none, cp, bias)

@@ -1606,7 +1606,7 @@ template <int Q, bool VEC>
 __global__ void __launch_bounds__(CG_BLOCK)
 gather_gemm_compact_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ w, int w_cout, int w_cin, int transpose,
                            int flip_k, const int* __restrict__ nbr, int n_out, int cp, const float* __restrict__ bias,
-                           float* __restrict__ out) {
+                           float* __restrict__ out, double* __restrict__ stats) {
     __shared__ f32x4 w_lds[CG_K * Q * 64];            // [k][q][lane]: B fragments of the 4 MFMA steps of channel group q
     __shared__ float acc_lds[CG_WAVES * 65 * 16];     // per wave 64 rows + one row that absorbs the empty queue slots
     __shared__ int q_id[CG_WAVES][CG_DEPTH + 1][64];
@@ -1787,6 +1787,44 @@ gather_gemm_compact_kernel(const float* __restrict__ in, int n_in, int cg, const
     }
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy)::"memory");      // the dummy loads
     __builtin_amdgcn_wave_barrier();
+    if (stats) {
+        // BatchNorm moments of the layer's output (reference spconv_backbone.py:21-25: the conv is followed by BatchNorm1d), taken
+        // from the LDS accumulator: thread (row group rg, channel ch) sums 16 rows in fp32, 32 threads add the 16 groups in fp64 and
+        // store the workgroup's partial sums -> stats scratch [2 cp][gridDim.x] behind the 2 cp results (fold: fold_partials_kernel or
+        // toda_bn_finalize_partials).  Fixed order: deterministic.
+        __shared__ float st_sh[2][16][16];
+        __syncthreads();                              // every wave's rows are final
+        static_assert(CG_BLOCK % 256 == 0, "one (row group, channel) pair per thread of each 256-thread slice");
+        for (int base = 0; base < CG_ROWS; base += 256) {
+            float sm = 0.f, sq = 0.f;
+            if (tid < 256) {
+                const int ch = tid & 15, rg = tid >> 4;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int R = base + rg * 16 + i;              // row of the workgroup
+                    if (blockIdx.x * CG_ROWS + R < n_out) {
+                        const float v = acc_lds[((R >> 6) * 65 + (R & 63)) * 16 + ch];
+                        sm += v;
+                        sq += v * v;
+                    }
+                }
+                st_sh[0][rg][ch] = sm;
+                st_sh[1][rg][ch] = sq;
+            }
+            __syncthreads();
+            if (tid < 32) {
+                const int qq = tid >> 4, ch = tid & 15;
+                double a = 0.0;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) a += (double)st_sh[qq][rg][ch];
+                if (co0 + ch < cp) {
+                    double* dst = stats + 2 * cp + (size_t)(qq * cp + co0 + ch) * gridDim.x + blockIdx.x;
+                    *dst = base == 0 ? a : *dst + a;
+                }
+            }
+            __syncthreads();
+        }
+    }
     // the wave's 64 rows x 16 channels: LDS -> out (64-byte row segments at column co0)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -2721,9 +2759,9 @@ extern "C" int toda_spconv_gather_gemm_compact_supported(int c_gather, int c_pro
     return k_vol == CG_K && c_gather >= 1 && c_gather <= 32 && c_produce >= 1 && c_produce <= 32 && c_produce % 4 == 0;
 }
 
-extern "C" int toda_spconv_gather_gemm_compact(const float* in, int n_in, int c_gather, const float* w, int w_cout, int w_cin, int transpose,
-                                               int flip_k, const int32_t* nbr, int n_out, int k_vol, int c_produce, const float* bias,
-                                               float* out, void* stream) {
+static int gather_gemm_compact_impl(const float* in, int n_in, int c_gather, const float* w, int w_cout, int w_cin, int transpose,
+                                    int flip_k, const int32_t* nbr, int n_out, int k_vol, int c_produce, const float* bias,
+                                    float* out, double* stats, void* stream) {
     TODA_CHECK_ARG(toda_spconv_gather_gemm_compact_supported(c_gather, c_produce, k_vol),
                    "gather_gemm_compact: needs K = 27, <= 32 gathered and <= 32 produced channels (a multiple of 4) (got K %d, %d -> %d)", k_vol, c_gather,
                    c_produce);
@@ -2738,7 +2776,7 @@ extern "C" int toda_spconv_gather_gemm_compact(const float* in, int n_in, int c_
     const bool vec = c_gather % 4 == 0;
 #define CG_LAUNCH(QQ, VV)                                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gather_gemm_compact_kernel<QQ, VV>), grid, dim3(CG_BLOCK), 0, s, in, n_in, c_gather, w, w_cout, w_cin, \
-                       transpose, flip_k, nbr, n_out, c_produce, bias, out)
+                       transpose, flip_k, nbr, n_out, c_produce, bias, out, stats)
     if (c_gather <= 16) {
         if (vec) CG_LAUNCH(1, true);
         else CG_LAUNCH(1, false);
@@ -2747,6 +2785,37 @@ extern "C" int toda_spconv_gather_gemm_compact(const float* in, int n_in, int c_
         else CG_LAUNCH(2, false);
     }
 #undef CG_LAUNCH
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_spconv_gather_gemm_compact(const float* in, int n_in, int c_gather, const float* w, int w_cout, int w_cin, int transpose,
+                                               int flip_k, const int32_t* nbr, int n_out, int k_vol, int c_produce, const float* bias,
+                                               float* out, void* stream) {
+    return gather_gemm_compact_impl(in, n_in, c_gather, w, w_cout, w_cin, transpose, flip_k, nbr, n_out, k_vol, c_produce, bias, out, nullptr, stream);
+}
+
+// The same launch with the BatchNorm moments of its output from the epilogue (per-channel sum and sum of squares, fp64, in the layout of
+// toda_spconv_gather_gemm_stats: 2 c results + [2 c][workgroups] scratch).  blocks_out == NULL: folded right away; else the partials
+// stay unfolded and *blocks_out (host) = partials per column, for toda_bn_finalize_partials.
+extern "C" size_t toda_spconv_gather_gemm_compact_stats_doubles(int n_out, int c_produce) {
+    return (size_t)2 * c_produce * (1 + (size_t)cdiv(n_out > 0 ? n_out : 1, CG_ROWS));
+}
+
+extern "C" int toda_spconv_gather_gemm_compact_stats(const float* in, int n_in, int c_gather, const float* w, int w_cout, int w_cin,
+                                                     int transpose, int flip_k, const int32_t* nbr, int n_out, int k_vol, int c_produce,
+                                                     const float* bias, float* out, double* sums, size_t sums_doubles, int* blocks_out,
+                                                     void* stream) {
+    TODA_CHECK_ARG(sums != nullptr && n_out > 0, "gather_gemm_compact_stats: null statistics buffer or no output rows");
+    TODA_CHECK_ARG(sums_doubles >= toda_spconv_gather_gemm_compact_stats_doubles(n_out, c_produce), "gather_gemm_compact_stats: statistics buffer too small");
+    const int rc = gather_gemm_compact_impl(in, n_in, c_gather, w, w_cout, w_cin, transpose, flip_k, nbr, n_out, k_vol, c_produce, bias, out, sums, stream);
+    if (rc != TODA_OK) return rc;
+    const int blocks = cdiv(n_out, CG_ROWS);
+    if (blocks_out) {
+        *blocks_out = blocks;
+        return TODA_OK;
+    }
+    hipLaunchKernelGGL(toda::fold_partials_kernel, dim3(2 * c_produce), dim3(256), 0, (hipStream_t)stream, sums, blocks, 2 * c_produce);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

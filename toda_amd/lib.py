@@ -47,6 +47,8 @@ SIGNATURES = {
     "toda_spconv_gather_gemm_halo": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "toda_spconv_gather_gemm_compact_supported": (_i, [_i, _i, _i]),
     "toda_spconv_gather_gemm_compact": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "toda_spconv_gather_gemm_compact_stats_doubles": (_sz, [_i, _i]),
+    "toda_spconv_gather_gemm_compact_stats": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "toda_spconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "toda_spconv_wgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_spconv_wgrad_tiled_supported": (_i, [_i, _i, _i, _i, _i]),

@@ -450,11 +450,22 @@ def gather_gemm_compact_supported(c_gather, c_produce, k_vol):
     return bool(L.load().toda_spconv_gather_gemm_compact_supported(int(c_gather), int(c_produce), int(k_vol)))
 
 
-def gather_gemm_compact(feat, weight, nbr, c_produce, bias=None, transpose=False, flip_k=False):
-    """Narrow K = 27 layers by per-offset compaction (toda_spconv_gather_gemm_compact); weight is the PLAIN [cout][3][3][3][cin] tensor."""
+def gather_gemm_compact(feat, weight, nbr, c_produce, bias=None, transpose=False, flip_k=False, stats=False):
+    """Narrow K = 27 layers by per-offset compaction (toda_spconv_gather_gemm_compact); weight is the PLAIN [cout][3][3][3][cin] tensor.
+    stats=True: also the BatchNorm moments of the output from the epilogue, unfolded: (out, sums, blocks) for toda_bn_finalize_partials."""
     lib = L.load()
     K, n_out = nbr.shape
     out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
+    if stats:
+        import ctypes
+        nd = lib.toda_spconv_gather_gemm_compact_stats_doubles(n_out, c_produce)
+        sums = torch.empty((nd,), dtype=torch.float64, device=feat.device)
+        blocks = ctypes.c_int(0)
+        rc = lib.toda_spconv_gather_gemm_compact_stats(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(weight), weight.shape[0], weight.shape[-1],
+                                                       int(bool(transpose)), int(bool(flip_k)), L.ptr(nbr), n_out, K, c_produce, L.ptr(bias), L.ptr(out),
+                                                       L.ptr(sums), nd, ctypes.addressof(blocks), L.stream())
+        L.check(rc, "toda_spconv_gather_gemm_compact_stats")
+        return out, sums, int(blocks.value)
     rc = lib.toda_spconv_gather_gemm_compact(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(weight), weight.shape[0], weight.shape[-1],
                                              int(bool(transpose)), int(bool(flip_k)), L.ptr(nbr), n_out, K, c_produce, L.ptr(bias), L.ptr(out), L.stream())
     L.check(rc, "toda_spconv_gather_gemm_compact")
@@ -579,12 +590,14 @@ class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, weight, bias, rb, wp_fwd, want_stats=False, wp_bwd=None):
         features = features.contiguous()
-        compact = not want_stats and _compact_route(features.shape[1], weight.shape[0], rb.nbr_fwd, rb.order_for(rb.nbr_fwd))
+        compact = _compact_route(features.shape[1], weight.shape[0], rb.nbr_fwd, rb.order_for(rb.nbr_fwd))
         if wp_fwd is None and not compact:
             wp_fwd = pack_weight(weight, False, False)
         sums, blocks = None, 0
         plan = rb.halo.get(weight.shape[-1]) if (rb.kind == "subm" and weight.shape[0] == weight.shape[-1] and features.shape[0] == rb.n_out) else None
-        if plan is not None and want_stats:
+        if compact and want_stats:
+            out, sums, blocks = gather_gemm_compact(features, weight.contiguous(), rb.nbr_fwd, weight.shape[0], bias, stats=True)
+        elif plan is not None and want_stats:
             out, sums = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias, True)
         elif plan is not None:
             out = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias)
@@ -657,7 +670,8 @@ def sparse_conv(features, weight, bias, rulebook, packed_weight=None, want_stats
     (returns (out, sums) with sums None when it cannot: empty tables, narrow channel pairs, mask-sorted row order)."""
     if not want_stats:
         return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, False, packed_dgrad)
-    ok = (FUSE_BN_STATS and gather_gemm_stats_supported(weight.shape[-1], weight.shape[0]) and rulebook.nbr_fwd.shape[1] > 1
+    narrow = FOLD_IN_FINALIZE and _compact_route(features.shape[1], weight.shape[0], rulebook.nbr_fwd, rulebook.order_for(rulebook.nbr_fwd))
+    ok = (FUSE_BN_STATS and (narrow or gather_gemm_stats_supported(weight.shape[-1], weight.shape[0])) and rulebook.nbr_fwd.shape[1] > 1
           and features.shape[0] > 0 and rulebook.order_for(rulebook.nbr_fwd) is None)
     if not ok:
         return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, False, packed_dgrad), None

@@ -96,7 +96,7 @@ class OpTable:
     def _cost_gather_gemm_classed(self, feat, wp, nbr, c_produce, order, cls_sorted, ksize, stride, padding):
         return self._cost_gather_gemm(feat, wp, nbr, c_produce)
 
-    def _cost_gather_gemm_compact(self, feat, weight, nbr, c_produce, bias=None, transpose=False, flip_k=False):
+    def _cost_gather_gemm_compact(self, feat, weight, nbr, c_produce, bias=None, transpose=False, flip_k=False, stats=False):
         return self._cost_gather_gemm(feat, None, nbr, c_produce)
 
     def _cost_wgrad(self, feat, dout, nbr, wshape, tiled=None):

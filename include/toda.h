@@ -72,6 +72,23 @@ int toda_voxelize_hard(const float* points, int n, int c,
                        int max_pts, int max_voxels,
                        float* voxels, int32_t* coords_zyx, int32_t* num_pts,
                        int32_t* m_dev, void* ws, size_t ws_bytes, void* stream);
+/* The same for a whole batch in three launches: the per-sample voxelisation of the DataLoader workers
+ * (data_processor.py:115-143) AND collate_batch's concatenation with the batch column prepended
+ * (pcdet/datasets/dataset.py:161-178).  points_host[b] is the DEVICE address of sample b's first feature
+ * column, rows `row_stride` floats apart (a [sum N, 1 + C] batch tensor is read in place: address of column 1,
+ * stride 1 + C); n_points_host[b] <= n_cap, the per-sample capacity the workspace is laid out for.  Outputs
+ * are the collated tensors, samples back to back, each clipped at max_voxels: voxels [sum M_b, max_pts, c],
+ * coords_bzyx [sum M_b, 4], num_pts [sum M_b]; room for batch * min(max_voxels, n_cap) rows.
+ * counts_dev [batch + 1] = M_0 .. M_{batch-1}, sum M_b.  ws_clean != 0: the workspace was used by this entry
+ * point before with the same (batch, n_cap) - every call leaves its hash table empty - and nothing else wrote it;
+ * 0: the call clears the table first.  After a failed call pass 0. */
+size_t toda_voxelize_batch_workspace_bytes(int batch, int n_cap);
+int toda_voxelize_batch(const float* const* points_host, const int32_t* n_points_host, int batch, int n_cap,
+                        int c, int row_stride,
+                        const float* range_host, const float* vsize_host, const int32_t* grid_host,
+                        int max_pts, int max_voxels,
+                        float* voxels, int32_t* coords_bzyx, int32_t* num_pts, int32_t* counts_dev,
+                        void* ws, size_t ws_bytes, int ws_clean, void* stream);
 
 /* MeanVFE: pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31.
  * out[v, :] = sum_p voxels[v, p, :] / max(num_pts[v], 1); num_pts is fp32
@@ -95,6 +112,17 @@ size_t toda_gridindex_bytes(int batch, const int32_t* shape_host /*[3] D H W*/);
 int toda_gridindex_from_coords(const int32_t* idx, int n, const int32_t* n_dev,
                                int batch, const int32_t* shape_host,
                                void* gi, int32_t* rowof, void* stream);
+/* The same index for the VOXEL level, in O(sites): rank(coord) is NOT canonical here (ranks are handed out per
+ * occupied 32-cell word by the site that set the word's lowest bit), which is all a level whose rows are in
+ * caller order needs - rowof[rank] = row, toda_rulebook_subm / toda_rulebook_conv read it as before.  No sweep over
+ * the lattice: the bitmap must be all zero on entry (gi_clean != 0: the caller guarantees it, e.g. through
+ * toda_gridindex_clear after the previous use; 0: the call clears all of it first). */
+int toda_gridindex_from_coords_unordered(const int32_t* idx, int n, const int32_t* n_dev,
+                                         int batch, const int32_t* shape_host,
+                                         void* gi, int32_t* rowof, int gi_clean, void* stream);
+/* Put the bitmap words of the listed sites back to zero (O(sites) instead of a memset of the lattice). */
+int toda_gridindex_clear(const int32_t* idx, int n, const int32_t* n_dev, int batch,
+                         const int32_t* shape_host, void* gi, void* stream);
 /* Build the index of the OUTPUT set of a strided sparse convolution
  * (spconv.SparseConv3d, spconv_backbone.py:14-15,113-114) and emit its
  * coordinates in canonical order.  idx_out has room for out_cap rows. */
@@ -104,23 +132,36 @@ int toda_gridindex_from_conv(const int32_t* idx_in, int n_in, const int32_t* n_i
                              const int32_t* pad_host, const int32_t* shape_out_host,
                              void* gi_out, int32_t* idx_out, int32_t* n_out_dev,
                              int out_cap, void* stream);
+/* The same from the INPUT level's grid index instead of its coordinate list: output stationary (one thread per
+ * 32-cell output word ORs the input rows that reach it), no atomics, no clearing of gi_out, two launches; the input
+ * row count never enters, so the levels of a backbone chain without a host round trip. */
+int toda_gridindex_from_bitmap(const void* gi_in, int batch, const int32_t* shape_in_host,
+                               const int32_t* ksize_host, const int32_t* stride_host,
+                               const int32_t* pad_host, const int32_t* shape_out_host,
+                               void* gi_out, int32_t* idx_out, int32_t* n_out_dev,
+                               int out_cap, void* stream);
 
 /* Rulebook of spconv.SubMConv3d (spconv_backbone.py:12,78): out sites = in
  * sites.  nbr[k*n + o] = input row at o + (k - centre) * dilation or -1.
  * rowof may be NULL when rows are already in canonical order.
- * pair_cnt[K] (device) receives the number of valid pairs per offset. */
+ * pair_cnt[K] (device) receives the number of valid pairs per offset (cnt_zeroed != 0: the caller has zeroed it,
+ * e.g. every table's counters of a plan with one memset). */
 int toda_rulebook_subm(const int32_t* idx, int n, int batch, const int32_t* shape_host,
                        const int32_t* ksize_host, const int32_t* dilation_host,
                        const void* gi, const int32_t* rowof,
-                       int32_t* nbr, int32_t* pair_cnt, void* stream);
+                       int32_t* nbr, int32_t* pair_cnt, int cnt_zeroed, void* stream);
 /* Rulebook of spconv.SparseConv3d: nbr_o2i[k*n_out + o] = input row feeding
  * output o through offset k; nbr_i2o[k*n_in + i] = output row fed by input i
- * through offset k (used by dgrad). */
+ * through offset k (used by dgrad).  idx_out / gi_in / rowof_in (optional, NULL = unknown): the output coordinates
+ * and the INPUT level's grid index (+ its rowof when the input rows are not canonical); with them the o2i table is
+ * written output-stationary (complete coalesced rows) instead of a 0xFF fill + scattered stores. */
 int toda_rulebook_conv(const int32_t* idx_in, int n_in, int batch,
                        const int32_t* shape_in_host, const int32_t* ksize_host,
                        const int32_t* stride_host, const int32_t* pad_host,
                        const int32_t* shape_out_host, const void* gi_out, int n_out,
-                       int32_t* nbr_o2i, int32_t* nbr_i2o, int32_t* pair_cnt, void* stream);
+                       int32_t* nbr_o2i, int32_t* nbr_i2o, int32_t* pair_cnt,
+                       const int32_t* idx_out, const void* gi_in, const int32_t* rowof_in,
+                       int cnt_zeroed, void* stream);
 
 /* ------------------------------------------------------------------------
  * Sparse convolution arithmetic (spconv SubMConv3d / SparseConv3d forward and

@@ -21,7 +21,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in include/toda.h but not exported"
         assert s in L.SIGNATURES, f"{s} has no ctypes prototype in toda_amd/lib.py"
     assert sorted(L.SIGNATURES) == syms
-    assert lib.toda_abi_version() == 1
+    assert lib.toda_abi_version() == 2
 
 
 def test_host_side_size_queries_need_no_gpu():

@@ -30,7 +30,7 @@ static GiLayout gi_layout(int batch, const int32_t* shape) {
     l.o_cells = o;
     o += align_up((size_t)l.cells * sizeof(uint2), 256);
     l.o_part = o;
-    o += scan_partials_bytes(l.cells);
+    o += align_up((size_t)(cdiv(l.cells, RB_BLOCK) + 1) * sizeof(int32_t), 256);      // 256-word tiles (>= the scan's 2048-word ones)
     l.o_total = o;
     o += 256;
     l.bytes = o;
@@ -149,6 +149,209 @@ gi_decode_kernel(const uint2* __restrict__ cells, long long n_cells, GridDims g,
     }
 }
 
+// ---- round 4: O(sites) index of an UNORDERED coordinate list (the voxel level) ------------------------------------------
+// The voxel level is the big lattice (Waymo, batch 2: 185 M cells = 46 MB of {bits, prefix} words for 0.3 M sites) and its
+// rows are in voxel order anyway (rowof maps rank -> row), so its ranks need not be canonical: instead of a popcount scan
+// over every word, the site that set the LOWEST bit of a word allocates popc(word) consecutive ranks for it from a counter
+// (one atomic per wave).  mark -> alloc -> rowof touch only the occupied words; gi_clear puts them back to zero afterwards,
+// so neither a memset nor a scan ever sweeps the lattice.  cell.y = first rank of the word, exactly what gi_rank reads.
+__global__ void __launch_bounds__(RB_BLOCK)
+gi_mark_first_kernel(const int4* __restrict__ idx, int n, const int32_t* __restrict__ n_dev, GridDims g,
+                     uint2* __restrict__ cells, int* __restrict__ first, int32_t* __restrict__ counter) {
+    n = eff_n(n, n_dev);
+    const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
+    if (i == 0) *counter = 0;
+    if (i >= n) return;
+    const int4 c = idx[i];
+    int mine = 0;
+    if (in_grid(c, g)) {
+        const long long lin = lin_index(c.x, c.y, c.z, c.w, g);
+        const unsigned bit = 1u << (lin & 31);
+        mine = (atomicOr(&cells[lin >> 5].x, bit) & bit) ? 0 : 1;      // exactly one of several rows with the same coordinate
+    }
+    first[i] = mine;
+}
+
+__global__ void __launch_bounds__(RB_BLOCK)
+gi_alloc_kernel(const int4* __restrict__ idx, int n, const int32_t* __restrict__ n_dev, GridDims g, uint2* __restrict__ cells,
+                const int* __restrict__ first, int32_t* __restrict__ counter) {
+    n = eff_n(n, n_dev);
+    const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
+    int want = 0;
+    long long w = 0;
+    if (i < n && first[i]) {
+        const int4 c = idx[i];
+        const long long lin = lin_index(c.x, c.y, c.z, c.w, g);
+        w = lin >> 5;
+        const unsigned bits = cells[w].x, bit = 1u << (lin & 31);
+        if (!(bits & (bit - 1))) want = __popc(bits);       // this row set the word's lowest bit: it allocates for the word
+    }
+    // one atomic per wave: inclusive scan of the requests, the last lane adds the wave's total
+    int inc = want;
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    const int total = __shfl(inc, 63, 64);
+    int base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    if (want) cells[w].y = (unsigned)(base + inc - want);
+}
+
+struct ClearLevel {
+    const int4* idx;
+    const int32_t* n_dev;
+    uint2* cells;
+    GridDims g;
+    int n;
+};
+constexpr int CLEAR_MAX = 8;
+struct ClearArgs {
+    ClearLevel lv[CLEAR_MAX];
+};
+
+// un-mark: the words of the listed sites back to {0, 0} (plain stores; rows sharing a word store the same value)
+__global__ void __launch_bounds__(RB_BLOCK) gi_clear_kernel(ClearArgs a) {
+    const ClearLevel& l = a.lv[blockIdx.y];
+    const int n = eff_n(l.n, l.n_dev);
+    const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = l.idx[i];
+    if (!in_grid(c, l.g)) return;
+    l.cells[lin_index(c.x, c.y, c.z, c.w, l.g) >> 5] = make_uint2(0u, 0u);
+}
+
+// ---- round 4: output set of a strided convolution from the input BITMAP, no atomics ---------------------------------------
+// gi_mark_conv_kernel sets up to prod(ceil(k / s)) output bits per input site with device atomics (1 M for the voxel level
+// of a Waymo batch; they execute at the memory side at ~20 G/s: 55 us per level on average, the most expensive index kernel
+// of round 3).  Output-stationary instead: one thread per output WORD ORs the input rows (kz, ky) that reach it - read as
+// unaligned bit windows of the input bitmap - and compacts the x axis with the stride.  Every word of the output bitmap is
+// written (zero or not): it needs no clearing, and the block's popcount goes straight to the scan's partial sums.
+__device__ __forceinline__ unsigned bits32_at(const uint2* __restrict__ cells, long long p, long long lo, long long hi) {
+    // 32 bitmap bits starting at linear position p (any alignment); positions outside [lo, hi) read as zero
+    const long long a = p > lo ? p : lo, e = (p + 32) < hi ? (p + 32) : hi;
+    if (a >= e) return 0u;
+    const long long w0 = a >> 5;
+    const unsigned lo_word = cells[w0].x;
+    const unsigned hi_word = ((e - 1) >> 5) > w0 ? cells[w0 + 1].x : 0u;
+    const unsigned long long v = (((unsigned long long)hi_word << 32) | lo_word) >> (a & 31);
+    const unsigned cnt = (unsigned)(e - a);
+    const unsigned m = cnt >= 32u ? ~0u : ((1u << cnt) - 1u);
+    return ((unsigned)v & m) << (unsigned)(a - p);
+}
+
+constexpr int CONV_WIN = 4;      // 32-bit windows per input row segment: (count - 1) * sx + KX <= 128 bits
+
+__global__ void __launch_bounds__(RB_BLOCK)
+gi_conv_bits_kernel(const uint2* __restrict__ cells_in, GridDims gin, ConvGeom cg, uint2* __restrict__ cells_out,
+                    long long n_cells_out, int32_t* __restrict__ partials) {
+    const long long w = (long long)blockIdx.x * RB_BLOCK + threadIdx.x;
+    const GridDims go = cg.out;
+    const long long total_bits = (long long)go.B * go.D * go.H * go.W;
+    unsigned word = 0u;
+    if (w < n_cells_out) {
+        long long pos = w << 5;
+        const long long end = (pos + 32) < total_bits ? (pos + 32) : total_bits;
+        while (pos < end) {
+            // the run of this word inside one output row (b, zo, yo)
+            long long t = pos;
+            const int xo = (int)(t % go.W);
+            t /= go.W;
+            const int yo = (int)(t % go.H);
+            t /= go.H;
+            const int zo = (int)(t % go.D);
+            const int b = (int)(t / go.D);
+            const int room = go.W - xo;
+            const int count = (int)((end - pos) < room ? (end - pos) : room);
+            const int xi0 = xo * cg.st[2] - cg.pd[2];
+            unsigned win[CONV_WIN] = {0u, 0u, 0u, 0u};
+            const int nwin = ((count - 1) * cg.st[2] + cg.ks[2] + 31) >> 5;
+            for (int kz = 0; kz < cg.ks[0]; ++kz) {
+                const int zi = zo * cg.st[0] - cg.pd[0] + kz;
+                if ((unsigned)zi >= (unsigned)gin.D) continue;
+                for (int ky = 0; ky < cg.ks[1]; ++ky) {
+                    const int yi = yo * cg.st[1] - cg.pd[1] + ky;
+                    if ((unsigned)yi >= (unsigned)gin.H) continue;
+                    const long long row = (((long long)b * gin.D + zi) * gin.H + yi) * gin.W;
+#pragma unroll
+                    for (int q = 0; q < CONV_WIN; ++q)
+                        if (q < nwin) win[q] |= bits32_at(cells_in, row + xi0 + 32 * q, row, row + gin.W);
+                }
+            }
+            // output bit j = OR over kx of window bit j * sx + kx
+            unsigned seg = 0u;
+            const unsigned long long lo64 = ((unsigned long long)win[1] << 32) | win[0], hi64 = ((unsigned long long)win[3] << 32) | win[2];
+            if ((lo64 | hi64) && cg.st[2] <= 2 && cg.ks[2] <= 8) {
+                // stride 1 / 2 (every layer of the reference's backbones): shift-OR over the taps, then keep every stride-th bit
+                unsigned long long u = 0ull;
+                for (int kx = 0; kx < cg.ks[2]; ++kx) u |= kx ? ((lo64 >> kx) | (hi64 << (64 - kx))) : lo64;
+                if (cg.st[2] == 2) {
+                    u &= 0x5555555555555555ull;
+                    u = (u | (u >> 1)) & 0x3333333333333333ull;
+                    u = (u | (u >> 2)) & 0x0f0f0f0f0f0f0f0full;
+                    u = (u | (u >> 4)) & 0x00ff00ff00ff00ffull;
+                    u = (u | (u >> 8)) & 0x0000ffff0000ffffull;
+                    u = (u | (u >> 16)) & 0x00000000ffffffffull;
+                }
+                seg = (unsigned)u & (count >= 32 ? ~0u : ((1u << count) - 1u));
+            } else if (lo64 | hi64) {
+                for (int j = 0; j < count; ++j) {
+                    unsigned hit = 0u;
+                    for (int kx = 0; kx < cg.ks[2]; ++kx) {
+                        const int bp = j * cg.st[2] + kx;
+                        hit |= (win[bp >> 5] >> (bp & 31)) & 1u;
+                    }
+                    seg |= hit << j;
+                }
+            }
+            word |= seg << (unsigned)(pos - (w << 5));
+            pos += count;
+        }
+        cells_out[w] = make_uint2(word, 0u);
+    }
+    int tot;
+    block_exclusive_scan(__popc(word), &tot);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+}
+
+// ranks of a bitmap whose per-256-word popcounts are in `partials`: every block sums the partials before it, scans its own
+// words, stores the prefix words and decodes its sites in canonical order; the last thread publishes the total
+__global__ void __launch_bounds__(RB_BLOCK)
+gi_scan_decode_kernel(uint2* __restrict__ cells, long long n_cells, const int32_t* __restrict__ partials, GridDims g,
+                      int4* __restrict__ idx_out, int cap, int32_t* __restrict__ total_dev, int32_t* __restrict__ n_out_dev) {
+    int s = 0;
+    for (int k = threadIdx.x; k < (int)blockIdx.x; k += RB_BLOCK) s += partials[k];
+    int before;
+    block_exclusive_scan(s, &before);
+    const long long w = (long long)blockIdx.x * RB_BLOCK + threadIdx.x;
+    unsigned bits = w < n_cells ? cells[w].x : 0u;
+    int tot;
+    int r = before + block_exclusive_scan(__popc(bits), &tot);
+    if (w < n_cells) cells[w].y = (unsigned)r;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == RB_BLOCK - 1) {
+        const int all = r + __popc(bits);
+        *total_dev = all;
+        if (n_out_dev) *n_out_dev = all;
+    }
+    while (bits) {
+        const int t = __ffs(bits) - 1;
+        bits &= bits - 1;
+        long long lin = (w << 5) + t;
+        if (r < cap) {
+            const int x = (int)(lin % g.W);
+            lin /= g.W;
+            const int y = (int)(lin % g.H);
+            lin /= g.H;
+            const int z = (int)(lin % g.D);
+            const int b = (int)(lin / g.D);
+            idx_out[r] = make_int4(b, z, y, x);
+        }
+        ++r;
+    }
+}
+
 // per-block per-offset pair counters: wave ballots -> LDS -> one global atomic per block and offset
 __device__ __forceinline__ void count_pairs(bool valid, int k, int* s_cnt) {
     const unsigned long long vote = __ballot(valid);
@@ -239,6 +442,8 @@ rb_subm_generic_kernel(const int4* __restrict__ idx, int n, GridDims g, int kz_n
 }
 
 // strided conv rulebook, one thread per input site; same issue-all-loads-first structure.
+// o2i == nullptr: only the input -> output table and the pair counts (the output -> input table then comes from
+// rb_conv_o2i_kernel, output stationary, with complete coalesced stores instead of a 0xFF fill + scattered 4-byte stores)
 template <int KZ, int KY, int KX>
 __global__ void __launch_bounds__(RB_BLOCK)
 rb_conv_kernel(const int4* __restrict__ idx, int n_in, ConvGeom cg, const uint2* __restrict__ cells, int n_out,
@@ -275,12 +480,52 @@ rb_conv_kernel(const int4* __restrict__ idx, int n_in, ConvGeom cg, const uint2*
     for (int k = 0; k < K; ++k) {
         int o = (cell[k].x & bit[k]) ? (int)cell[k].y + __popc(cell[k].x & (bit[k] - 1)) : -1;
         if (o >= n_out) o = -1;
-        if (o >= 0) o2i[(size_t)k * n_out + o] = i;
+        if (o >= 0 && o2i) o2i[(size_t)k * n_out + o] = i;
         if (live) i2o[(size_t)k * n_in + i] = o;
         count_pairs(o >= 0, k, s_cnt);
     }
     __syncthreads();
     if (threadIdx.x < K && s_cnt[threadIdx.x]) atomicAdd(&pair_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+// output -> input table of a strided convolution, one thread per OUTPUT site: the input coordinate behind tap k is
+// o * stride - pad + k; its row comes from the INPUT level's grid index (rank, then rowof for the voxel level).
+template <int KZ, int KY, int KX>
+__global__ void __launch_bounds__(RB_BLOCK)
+rb_conv_o2i_kernel(const int4* __restrict__ idx_out, int n_out, ConvGeom cg, GridDims gin, const uint2* __restrict__ cells_in,
+                   const int* __restrict__ rowof_in, int n_in, int* __restrict__ o2i) {
+    constexpr int K = KZ * KY * KX;
+    const int o = blockIdx.x * RB_BLOCK + threadIdx.x;
+    if (o >= n_out) return;
+    const int4 c = idx_out[o];
+    uint2 cell[K];
+    unsigned bit[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int kz = k / (KY * KX), ky = (k / KX) % KY, kx = k % KX;
+        const int z = c.y * cg.st[0] - cg.pd[0] + kz, y = c.z * cg.st[1] - cg.pd[1] + ky, x = c.w * cg.st[2] - cg.pd[2] + kx;
+        cell[k] = make_uint2(0u, 0u);
+        bit[k] = 0u;
+        if ((unsigned)c.x < (unsigned)gin.B && (unsigned)z < (unsigned)gin.D && (unsigned)y < (unsigned)gin.H &&
+            (unsigned)x < (unsigned)gin.W) {
+            const long long lin = lin_index(c.x, z, y, x, gin);
+            cell[k] = cells_in[lin >> 5];
+            bit[k] = 1u << (lin & 31);
+        }
+    }
+    int r[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        r[k] = (cell[k].x & bit[k]) ? (int)cell[k].y + __popc(cell[k].x & (bit[k] - 1)) : -1;
+        if (r[k] >= n_in) r[k] = -1;
+    }
+    if (rowof_in) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (r[k] >= 0) r[k] = rowof_in[r[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) o2i[(size_t)k * n_out + o] = r[k];
 }
 
 __global__ void __launch_bounds__(RB_BLOCK)
@@ -354,6 +599,47 @@ extern "C" int toda_gridindex_from_coords(const int32_t* idx, int n, const int32
     return TODA_OK;
 }
 
+extern "C" int toda_gridindex_from_coords_unordered(const int32_t* idx, int n, const int32_t* n_dev, int batch,
+                                                    const int32_t* shape_host, void* gi, int32_t* rowof, int gi_clean,
+                                                    void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = check_geom("gridindex_from_coords_unordered", batch, shape_host);
+    if (rc) return rc;
+    TODA_CHECK_ARG(n >= 0 && rowof, "gridindex_from_coords_unordered: n < 0 or no rowof");
+    const GiLayout l = gi_layout(batch, shape_host);
+    char* b = (char*)gi;
+    uint2* cells = (uint2*)(b + l.o_cells);
+    int32_t* counter = (int32_t*)(b + l.o_total);
+    if (!gi_clean) TODA_HIP(hipMemsetAsync(cells, 0, (size_t)l.cells * sizeof(uint2), s));
+    if (n == 0) return TODA_OK;
+    const GridDims g{batch, shape_host[0], shape_host[1], shape_host[2]};
+    const dim3 grid(cdiv(n, RB_BLOCK)), block(RB_BLOCK);
+    // rowof doubles as the "this row set its bit first" flags between mark and alloc (rowof[rank] = row is written last)
+    hipLaunchKernelGGL(gi_mark_first_kernel, grid, block, 0, s, (const int4*)idx, n, n_dev, g, cells, rowof, counter);
+    hipLaunchKernelGGL(gi_alloc_kernel, grid, block, 0, s, (const int4*)idx, n, n_dev, g, cells, (const int*)rowof, counter);
+    hipLaunchKernelGGL(gi_rowof_kernel, grid, block, 0, s, (const int4*)idx, n, n_dev, g, cells, rowof);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_gridindex_clear(const int32_t* idx, int n, const int32_t* n_dev, int batch, const int32_t* shape_host,
+                                    void* gi, void* stream) {
+    int rc = check_geom("gridindex_clear", batch, shape_host);
+    if (rc) return rc;
+    TODA_CHECK_ARG(n >= 0, "gridindex_clear: n < 0");
+    if (n == 0) return TODA_OK;
+    const GiLayout l = gi_layout(batch, shape_host);
+    ClearArgs a;
+    a.lv[0].idx = (const int4*)idx;
+    a.lv[0].n_dev = n_dev;
+    a.lv[0].cells = (uint2*)((char*)gi + l.o_cells);
+    a.lv[0].g = GridDims{batch, shape_host[0], shape_host[1], shape_host[2]};
+    a.lv[0].n = n;
+    hipLaunchKernelGGL(gi_clear_kernel, dim3(cdiv(n, RB_BLOCK), 1), dim3(RB_BLOCK), 0, (hipStream_t)stream, a);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
 static int fill_conv_geom(const char* who, int batch, const int32_t* shape_in, const int32_t* ks, const int32_t* st,
                           const int32_t* pd, const int32_t* shape_out, ConvGeom* cg) {
     for (int a = 0; a < 3; ++a) {
@@ -397,9 +683,39 @@ extern "C" int toda_gridindex_from_conv(const int32_t* idx_in, int n_in, const i
     return TODA_OK;
 }
 
+extern "C" int toda_gridindex_from_bitmap(const void* gi_in, int batch, const int32_t* shape_in_host,
+                                          const int32_t* ksize_host, const int32_t* stride_host, const int32_t* pad_host,
+                                          const int32_t* shape_out_host, void* gi_out, int32_t* idx_out, int32_t* n_out_dev,
+                                          int out_cap, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int rc = check_geom("gridindex_from_bitmap", batch, shape_out_host);
+    if (rc) return rc;
+    rc = check_geom("gridindex_from_bitmap", batch, shape_in_host);
+    if (rc) return rc;
+    ConvGeom cg;
+    rc = fill_conv_geom("gridindex_from_bitmap", batch, shape_in_host, ksize_host, stride_host, pad_host, shape_out_host, &cg);
+    if (rc) return rc;
+    TODA_CHECK_ARG(out_cap >= 0, "gridindex_from_bitmap: negative size");
+    TODA_CHECK_ARG(31 * stride_host[2] + ksize_host[2] <= 32 * CONV_WIN, "gridindex_from_bitmap: x stride %d / kernel %d too wide",
+                   stride_host[2], ksize_host[2]);
+    const GiLayout li = gi_layout(batch, shape_in_host), lo = gi_layout(batch, shape_out_host);
+    const uint2* cells_in = (const uint2*)((const char*)gi_in + li.o_cells);
+    char* b = (char*)gi_out;
+    uint2* cells = (uint2*)(b + lo.o_cells);
+    int32_t* part = (int32_t*)(b + lo.o_part);
+    int32_t* total = (int32_t*)(b + lo.o_total);
+    const GridDims gin{batch, shape_in_host[0], shape_in_host[1], shape_in_host[2]};
+    const int nb = cdiv(lo.cells, RB_BLOCK);
+    hipLaunchKernelGGL(gi_conv_bits_kernel, dim3(nb), dim3(RB_BLOCK), 0, s, cells_in, gin, cg, cells, lo.cells, part);
+    hipLaunchKernelGGL(gi_scan_decode_kernel, dim3(nb), dim3(RB_BLOCK), 0, s, cells, lo.cells, (const int32_t*)part, cg.out,
+                       (int4*)idx_out, out_cap, total, n_out_dev);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
 extern "C" int toda_rulebook_subm(const int32_t* idx, int n, int batch, const int32_t* shape_host,
                                   const int32_t* ksize_host, const int32_t* dilation_host, const void* gi,
-                                  const int32_t* rowof, int32_t* nbr, int32_t* pair_cnt, void* stream) {
+                                  const int32_t* rowof, int32_t* nbr, int32_t* pair_cnt, int cnt_zeroed, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_geom("rulebook_subm", batch, shape_host);
     if (rc) return rc;
@@ -407,7 +723,7 @@ extern "C" int toda_rulebook_subm(const int32_t* idx, int n, int batch, const in
     TODA_CHECK_ARG(K >= 1 && K <= 64, "rulebook_subm: kernel volume %d unsupported", K);
     for (int a = 0; a < 3; ++a)
         TODA_CHECK_ARG(ksize_host[a] % 2 == 1 && dilation_host[a] >= 1, "rulebook_subm: kernel must be odd, dilation >= 1");
-    TODA_HIP(hipMemsetAsync(pair_cnt, 0, K * sizeof(int32_t), s));
+    if (!cnt_zeroed) TODA_HIP(hipMemsetAsync(pair_cnt, 0, K * sizeof(int32_t), s));
     if (n == 0) return TODA_OK;
     const GiLayout l = gi_layout(batch, shape_host);
     const uint2* cells = (const uint2*)((const char*)gi + l.o_cells);
@@ -427,7 +743,8 @@ extern "C" int toda_rulebook_subm(const int32_t* idx, int n, int batch, const in
 extern "C" int toda_rulebook_conv(const int32_t* idx_in, int n_in, int batch, const int32_t* shape_in_host,
                                   const int32_t* ksize_host, const int32_t* stride_host, const int32_t* pad_host,
                                   const int32_t* shape_out_host, const void* gi_out, int n_out, int32_t* nbr_o2i,
-                                  int32_t* nbr_i2o, int32_t* pair_cnt, void* stream) {
+                                  int32_t* nbr_i2o, int32_t* pair_cnt, const int32_t* idx_out, const void* gi_in,
+                                  const int32_t* rowof_in, int cnt_zeroed, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_geom("rulebook_conv", batch, shape_out_host);
     if (rc) return rc;
@@ -435,18 +752,42 @@ extern "C" int toda_rulebook_conv(const int32_t* idx_in, int n_in, int batch, co
     rc = fill_conv_geom("rulebook_conv", batch, shape_in_host, ksize_host, stride_host, pad_host, shape_out_host, &cg);
     if (rc) return rc;
     const int K = ksize_host[0] * ksize_host[1] * ksize_host[2];
-    TODA_HIP(hipMemsetAsync(pair_cnt, 0, K * sizeof(int32_t), s));
-    if (n_out > 0) TODA_HIP(hipMemsetAsync(nbr_o2i, 0xFF, (size_t)K * n_out * sizeof(int32_t), s));
-    if (n_in == 0) return TODA_OK;
+    const bool k333 = ksize_host[0] == 3 && ksize_host[1] == 3 && ksize_host[2] == 3;
+    const bool k311 = ksize_host[0] == 3 && ksize_host[1] == 1 && ksize_host[2] == 1;
+    // output -> input table by its own output-stationary kernel when the caller has the input level's index and the output
+    // coordinates at hand (the index plan does); otherwise 0xFF fill + scattered stores from the input side
+    const bool by_output = idx_out && gi_in && (k333 || k311);
+    if (!cnt_zeroed) TODA_HIP(hipMemsetAsync(pair_cnt, 0, K * sizeof(int32_t), s));
+    if (n_out > 0 && !by_output) TODA_HIP(hipMemsetAsync(nbr_o2i, 0xFF, (size_t)K * n_out * sizeof(int32_t), s));
     const GiLayout l = gi_layout(batch, shape_out_host);
     const uint2* cells = (const uint2*)((const char*)gi_out + l.o_cells);
-    const dim3 grid(cdiv(n_in, RB_BLOCK)), block(RB_BLOCK);
-    if (ksize_host[0] == 3 && ksize_host[1] == 3 && ksize_host[2] == 3)
+    const dim3 block(RB_BLOCK);
+    if (by_output && n_out > 0) {
+        rc = check_geom("rulebook_conv", batch, shape_in_host);
+        if (rc) return rc;
+        const GiLayout li = gi_layout(batch, shape_in_host);
+        const uint2* cells_in = (const uint2*)((const char*)gi_in + li.o_cells);
+        const GridDims gin{batch, shape_in_host[0], shape_in_host[1], shape_in_host[2]};
+        const dim3 grid(cdiv(n_out, RB_BLOCK));
+        if (k333)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_o2i_kernel<3, 3, 3>), grid, block, 0, s, (const int4*)idx_out, n_out, cg, gin,
+                               cells_in, rowof_in, n_in, nbr_o2i);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_o2i_kernel<3, 1, 1>), grid, block, 0, s, (const int4*)idx_out, n_out, cg, gin,
+                               cells_in, rowof_in, n_in, nbr_o2i);
+    }
+    if (n_in == 0) {
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
+    int32_t* o2i = by_output ? nullptr : nbr_o2i;
+    const dim3 grid(cdiv(n_in, RB_BLOCK));
+    if (k333)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_kernel<3, 3, 3>), grid, block, 0, s, (const int4*)idx_in, n_in, cg,
-                           cells, n_out, nbr_o2i, nbr_i2o, pair_cnt);
-    else if (ksize_host[0] == 3 && ksize_host[1] == 1 && ksize_host[2] == 1)
+                           cells, n_out, o2i, nbr_i2o, pair_cnt);
+    else if (k311)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(rb_conv_kernel<3, 1, 1>), grid, block, 0, s, (const int4*)idx_in, n_in, cg,
-                           cells, n_out, nbr_o2i, nbr_i2o, pair_cnt);
+                           cells, n_out, o2i, nbr_i2o, pair_cnt);
     else
         hipLaunchKernelGGL(rb_conv_generic_kernel, grid, block, 0, s, (const int4*)idx_in, n_in, cg, cells, n_out,
                            nbr_o2i, nbr_i2o, pair_cnt);

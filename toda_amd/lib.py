@@ -26,8 +26,13 @@ SIGNATURES = {
     "toda_gridindex_bytes": (_sz, [_i, _vp]),
     "toda_gridindex_from_coords": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "toda_gridindex_from_conv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "toda_rulebook_subm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "toda_rulebook_conv": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "toda_rulebook_subm": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "toda_rulebook_conv": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "toda_voxelize_batch_workspace_bytes": (_sz, [_i, _i]),
+    "toda_voxelize_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "toda_gridindex_from_coords_unordered": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "toda_gridindex_clear": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "toda_gridindex_from_bitmap": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "toda_spconv_packed_weight_floats": (_sz, [_i, _i, _i]),
     "toda_spconv_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "toda_spconv_pack_weights": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -5,6 +5,7 @@ through the C ABI; host tensors raise (toda_amd.lib.ptr).
 import numpy as np
 import torch
 
+from . import arena as _arena
 from . import lib as L
 
 
@@ -61,8 +62,76 @@ def read_counts(counts_dev, while_waiting=None):
     return vals
 
 
+def _alloc(shape, dtype, device):
+    """Output of an index builder: from the current thread's arena slot when the input pipeline set one (toda_amd.arena),
+    else from torch's allocator."""
+    slot = _arena.current_slot()
+    if slot is not None:
+        return slot.take(shape, dtype)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def _persistent(name, meta, nbytes, device, init=None):
+    """(buffer, fresh): a buffer whose CONTENTS carry over between uses when an arena slot is current (fresh = just created
+    and `init`-ialised), else a new one every time (fresh = True, `init` run)."""
+    slot = _arena.current_slot()
+    if slot is not None:
+        return slot.persistent(name, meta, nbytes, init)
+    buf = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+    if init is not None:
+        init(buf)
+    return buf, True
+
+
+def _cloud_list(points_list):
+    """[(tensor, first-column offset in floats, n, c, row stride in floats)] of per-sample [n, c] clouds."""
+    out = []
+    for p in points_list:
+        assert p.dtype == torch.float32 and p.dim() == 2
+        p = p.contiguous()
+        out.append((p, 0, p.shape[0], p.shape[1], p.shape[1]))
+    return out
+
+
+def voxelize_enqueue(clouds, pc_range, voxel_size, max_pts, max_voxels, counts=None, tag=0):
+    """Voxelise + collate a whole batch in three launches, NO host sync (toda_voxelize_batch).  clouds: see _cloud_list (or
+    rows of one [sum N, 1 + C] batch tensor read in place).  Returns cap-sized (voxels, coords_bzyx, num_points) and the device
+    counts [B + 1] = M_0 .. M_{B-1}, sum M (written into `counts[:B + 1]` when given)."""
+    lib = L.load()
+    bsz = len(clouds)
+    dev = clouds[0][0].device
+    c, stride = clouds[0][3], clouds[0][4]
+    assert all(cl[3] == c and cl[4] == stride for cl in clouds)
+    ns = [int(cl[2]) for cl in clouds]
+    slot = _arena.current_slot()
+    # per-sample capacity of the workspace layout: sticky per slot, so that batches of different sizes (C5: 180 k / 35 k
+    # clouds) keep ONE layout and the hash table stays clean between calls
+    n_cap = max(ns + [1])
+    if slot is not None:
+        n_cap = max(n_cap, slot.state.get(("vox_ncap", tag), 0))
+        n_cap = (n_cap + 16383) // 16384 * 16384
+        slot.state[("vox_ncap", tag)] = n_cap
+    ws_bytes = lib.toda_voxelize_batch_workspace_bytes(bsz, n_cap)
+    ws, fresh = _persistent(("vox_ws", tag), (bsz, n_cap), ws_bytes, dev)
+    rows = sum(min(int(max_voxels), n) for n in ns)
+    voxels = _alloc((max(rows, 1), int(max_pts), c), torch.float32, dev)
+    coords = _alloc((max(rows, 1), 4), torch.int32, dev)
+    num = _alloc((max(rows, 1),), torch.int32, dev)
+    if counts is None:
+        counts = _alloc((bsz + 1,), torch.int32, dev)
+    rng, vs = L.host_f32(pc_range), L.host_f32(voxel_size)
+    grid = L.host_i32(grid_size_xyz(pc_range, voxel_size))
+    addrs = L.host_addrs([cl[0].data_ptr() + 4 * cl[1] for cl in clouds])
+    rc = lib.toda_voxelize_batch(addrs, L.hptr(L.host_i32(ns)), bsz, n_cap, c, stride, L.hptr(rng), L.hptr(vs), L.hptr(grid),
+                                 int(max_pts), int(max_voxels), L.ptr(voxels), L.ptr(coords), L.ptr(num), L.ptr(counts),
+                                 L.ptr(ws), ws.numel(), 0 if fresh else 1, L.stream())
+    L.check(rc, "toda_voxelize_batch")
+    return voxels, coords, num, counts
+
+
 def voxelize_raw(points, pc_range, voxel_size, max_pts, max_voxels):
-    """One sample, no host sync.  Returns buffers sized for the cap and the device-side count."""
+    """One sample through the single-sample entry point (spconv's own layout: coords (z, y, x)), no host sync.  Returns
+    buffers sized for the cap and the device-side count."""
     lib = L.load()
     assert points.dtype == torch.float32 and points.dim() == 2
     n, c = points.shape
@@ -91,19 +160,16 @@ def voxelize(points, pc_range, voxel_size, max_pts, max_voxels):
 
 
 def voxelize_batch(points_list, pc_range, voxel_size, max_pts, max_voxels):
-    """All samples of a batch with ONE host sync.  Mirrors voxelise + collate_batch
+    """All samples of a batch in three launches and ONE host sync.  Mirrors voxelise + collate_batch
     (reference dataset.py:161-178): coords gain the batch column -> (b, z, y, x)."""
-    raws = [voxelize_raw(p, pc_range, voxel_size, max_pts, max_voxels) for p in points_list]
-    counts = read_counts(torch.cat([r[3] for r in raws]))  # the one sync
-    vox, coords, nums = [], [], []
-    for b, ((v, c, n, _), m) in enumerate(zip(raws, counts)):
-        vox.append(v[:m])
-        nums.append(n[:m])
-        cb = torch.empty((m, 4), dtype=torch.int32, device=c.device)
-        cb[:, 0] = b
-        cb[:, 1:] = c[:m]
-        coords.append(cb)
-    return torch.cat(vox), torch.cat(coords), torch.cat(nums)
+    if len(points_list) > 32:      # the kernel's sample table; larger batches in groups
+        parts = [voxelize_batch(points_list[i:i + 32], pc_range, voxel_size, max_pts, max_voxels) for i in range(0, len(points_list), 32)]
+        for g, (_, cb, _) in enumerate(parts):
+            cb[:, 0] += 32 * g
+        return tuple(torch.cat([p[k] for p in parts]) for k in range(3))
+    voxels, coords, num, counts = voxelize_enqueue(_cloud_list(points_list), pc_range, voxel_size, max_pts, max_voxels)
+    m = read_counts(counts)[-1]      # the one sync
+    return voxels[:m], coords[:m], num[:m]
 
 
 class _MeanVFE(torch.autograd.Function):
@@ -137,15 +203,18 @@ def mean_vfe(voxels, num_points):
 class GridIndex:
     """Bitmap + rank dictionary of one sparse level (device workspace)."""
 
-    def __init__(self, batch, shape, device):
+    def __init__(self, batch, shape, device, buf=None):
         self.batch, self.shape = int(batch), [int(s) for s in shape]
         self._shape_c = L.host_i32(self.shape)
         nbytes = L.load().toda_gridindex_bytes(self.batch, L.hptr(self._shape_c))
-        self.buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.nbytes = nbytes
+        self.buf = buf if buf is not None else torch.empty((nbytes,), dtype=torch.uint8, device=device)
         self.rowof = None  # None = rows already in canonical order
 
     @classmethod
     def from_coords(cls, indices, batch, shape):
+        """Canonical ranks (popcount scan over the lattice): for coordinate lists whose index is also DECODED or ranked in
+        canonical order (lazy single-layer builds, the halo plan)."""
         gi = cls(batch, shape, indices.device)
         n = indices.shape[0]
         gi.rowof = torch.empty((max(n, 1),), dtype=torch.int32, device=indices.device)
@@ -153,6 +222,47 @@ class GridIndex:
                                                  L.ptr(gi.rowof), L.stream())
         L.check(rc, "toda_gridindex_from_coords")
         return gi
+
+    @classmethod
+    def unordered_begin(cls, batch, shape, device, name="gi0"):
+        """First half of from_coords_unordered: fetch the bitmap - inside an arena slot a persistent buffer that the slot keeps
+        all-zero between uses (the previous use's marks are taken off when the slot is re-acquired)."""
+        lib = L.load()
+        shape_c = L.host_i32([int(v) for v in shape])
+        nbytes = lib.toda_gridindex_bytes(int(batch), L.hptr(shape_c))
+        slot = _arena.current_slot()
+        buf, fresh = _persistent(name, (int(batch), tuple(int(v) for v in shape)), nbytes, device)
+        gi = cls(batch, shape, device, buf=buf)
+        gi._name, gi._clean = name, 0
+        if slot is not None and not fresh and name in slot.clean:       # ArenaSlot.reset ran the previous use's toda_gridindex_clear
+            slot.clean.discard(name)
+            gi._clean = 1
+        return gi
+
+    def unordered_build(self, indices, n_dev=None):
+        n = indices.shape[0]
+        self.rowof = _alloc((max(n, 1),), torch.int32, indices.device)
+        rc = L.load().toda_gridindex_from_coords_unordered(L.ptr(indices), n, L.ptr(n_dev), self.batch, L.hptr(self._shape_c), L.ptr(self.buf),
+                                                           L.ptr(self.rowof), self._clean, L.stream())
+        L.check(rc, "toda_gridindex_from_coords_unordered")
+        slot = _arena.current_slot()
+        if slot is not None:
+            # how to clean up: the listed words back to zero.  `indices` / `n_dev` are views into this slot's chunks, intact until
+            # the next use carves them again - ArenaSlot.reset enqueues this before that.
+            lib, buf, bt, shp = L.load(), self.buf, self.batch, self._shape_c
+
+            def clear():
+                L.check(lib.toda_gridindex_clear(L.ptr(indices), n, L.ptr(n_dev), bt, L.hptr(shp), L.ptr(buf), L.stream()), "toda_gridindex_clear")
+
+            slot.marks[self._name] = clear
+        return self
+
+    @classmethod
+    def from_coords_unordered(cls, indices, batch, shape, n_dev=None, name="gi0"):
+        """The voxel level in O(sites) (toda_gridindex_from_coords_unordered): no memset, no scan over the lattice.  Inside an
+        arena slot the bitmap is a persistent buffer kept all-zero between uses: the words the PREVIOUS build of this slot
+        marked are cleared first, from the coordinate list that build left behind."""
+        return cls.unordered_begin(batch, shape, indices.device, name).unordered_build(indices, n_dev)
 
 
 class Rulebook:
@@ -193,8 +303,8 @@ class Rulebook:
         if self._class_order is None:
             lib = L.load()
             dev = self.in_indices.device
-            order = torch.empty((self.n_in,), dtype=torch.int32, device=dev)
-            cls = torch.empty((self.n_in,), dtype=torch.uint8, device=dev)
+            order = _alloc((self.n_in,), torch.int32, dev)
+            cls = _alloc((self.n_in,), torch.uint8, dev)
             st, pd = L.host_i32(self.geom["stride"]), L.host_i32(self.geom["padding"])
             L.check(lib.toda_rulebook_class_order(L.ptr(self.in_indices), self.n_in, L.hptr(st), L.hptr(pd), L.ptr(order), L.ptr(cls), L.stream()),
                     "toda_rulebook_class_order")
@@ -209,22 +319,52 @@ def conv_out_shape(shape, ksize, stride, padding):
     return [(int(s) + 2 * p - k) // t + 1 for s, k, t, p in zip(shape, ksize, stride, padding)]
 
 
-def build_subm_rulebook(indices, batch, shape, ksize=3, dilation=1, grid_index=None):
+def build_subm_rulebook(indices, batch, shape, ksize=3, dilation=1, grid_index=None, pair_cnt=None):
+    """pair_cnt: a zeroed [K] int32 view to count into (the plan zeroes every table's counters with one fill)."""
     lib = L.load()
     ks, dl = _triple(ksize), _triple(dilation)
     indices = indices.contiguous()
     assert indices.dtype == torch.int32 and indices.shape[1] == 4
     n = indices.shape[0]
     if grid_index is None:
-        grid_index = GridIndex.from_coords(indices, batch, shape)
+        grid_index = GridIndex.from_coords_unordered(indices, batch, shape, name=("gi_lazy", tuple(int(v) for v in shape)))
     K = ks[0] * ks[1] * ks[2]
-    nbr = torch.empty((K, n), dtype=torch.int32, device=indices.device)
-    cnt = torch.empty((K,), dtype=torch.int32, device=indices.device)
+    nbr = _alloc((K, n), torch.int32, indices.device)
+    zeroed = pair_cnt is not None
+    cnt = pair_cnt if zeroed else torch.empty((K,), dtype=torch.int32, device=indices.device)
     ks_c, dl_c = L.host_i32(ks), L.host_i32(dl)
     rc = lib.toda_rulebook_subm(L.ptr(indices), n, int(batch), L.hptr(grid_index._shape_c), L.hptr(ks_c), L.hptr(dl_c),
-                                L.ptr(grid_index.buf), L.ptr(grid_index.rowof), L.ptr(nbr), L.ptr(cnt), L.stream())
+                                L.ptr(grid_index.buf), L.ptr(grid_index.rowof), L.ptr(nbr), L.ptr(cnt), int(zeroed), L.stream())
     L.check(rc, "toda_rulebook_subm")
     return Rulebook("subm", ks, n, n, nbr, nbr, True, cnt, dilation=dl), grid_index
+
+
+def _conv_tables(indices, n_in, idx_out, n_out, batch, shape, out_shape, ks, st, pd, gi_out, gi_in=None, pair_cnt=None):
+    """Both neighbour tables of a strided convolution whose output set is known (toda_rulebook_conv)."""
+    lib = L.load()
+    dev = indices.device
+    K = ks[0] * ks[1] * ks[2]
+    o2i = _alloc((K, n_out), torch.int32, dev)
+    i2o = _alloc((K, n_in), torch.int32, dev)
+    zeroed = pair_cnt is not None
+    cnt = pair_cnt if zeroed else torch.empty((K,), dtype=torch.int32, device=dev)
+    hs = [L.host_i32(v) for v in (shape, ks, st, pd, out_shape)]
+    rc = lib.toda_rulebook_conv(L.ptr(indices), n_in, int(batch), L.hptr(hs[0]), L.hptr(hs[1]), L.hptr(hs[2]), L.hptr(hs[3]),
+                                L.hptr(hs[4]), L.ptr(gi_out.buf), n_out, L.ptr(o2i), L.ptr(i2o), L.ptr(cnt),
+                                L.ptr(idx_out) if gi_in is not None else None, L.ptr(gi_in.buf) if gi_in is not None else None,
+                                L.ptr(gi_in.rowof) if gi_in is not None else None, int(zeroed), L.stream())
+    L.check(rc, "toda_rulebook_conv")
+    rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=st, padding=pd)
+    rb.in_indices = indices
+    return rb
+
+
+def _conv_cap(n_upper, batch, out_shape, ks, st):
+    """Upper bound of a strided convolution's output rows: every input reaches at most prod(ceil(k/s)) outputs; also the lattice."""
+    per_in = 1
+    for k, s_ in zip(ks, st):
+        per_in *= -(-k // s_)
+    return int(min(n_upper * per_in, batch * out_shape[0] * out_shape[1] * out_shape[2]))
 
 
 def build_conv_rulebook(indices, batch, shape, ksize, stride, padding):
@@ -238,11 +378,7 @@ def build_conv_rulebook(indices, batch, shape, ksize, stride, padding):
     out_shape = conv_out_shape(shape, ks, st, pd)
     dev = indices.device
     gi_out = GridIndex(batch, out_shape, dev)
-    # every input reaches at most prod(ceil(k/s)) outputs per axis; also bounded by the lattice
-    per_in = 1
-    for k, s in zip(ks, st):
-        per_in *= -(-k // s)
-    cap = int(min(n_in * per_in, batch * out_shape[0] * out_shape[1] * out_shape[2]))
+    cap = _conv_cap(n_in, batch, out_shape, ks, st)
     idx_out = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
     n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
     shi, sho = L.host_i32(shape), L.host_i32(out_shape)
@@ -255,19 +391,90 @@ def build_conv_rulebook(indices, batch, shape, ksize, stride, padding):
     if n_out > cap:
         raise RuntimeError(f"strided rulebook: {n_out} outputs exceed the bound {cap}")
     idx_out = idx_out[:n_out]
-    K = ks[0] * ks[1] * ks[2]
-    o2i = torch.empty((K, n_out), dtype=torch.int32, device=dev)
-    i2o = torch.empty((K, n_in), dtype=torch.int32, device=dev)
-    cnt = torch.empty((K,), dtype=torch.int32, device=dev)
-    rc = lib.toda_rulebook_conv(L.ptr(indices), n_in, int(batch), L.hptr(shi), L.hptr(ks_c), L.hptr(st_c), L.hptr(pd_c),
-                                L.hptr(sho), L.ptr(gi_out.buf), n_out, L.ptr(o2i), L.ptr(i2o), L.ptr(cnt), L.stream())
-    L.check(rc, "toda_rulebook_conv")
-    rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=st, padding=pd)
-    rb.in_indices = indices
+    rb = _conv_tables(indices, n_in, idx_out, n_out, batch, shape, out_shape, ks, st, pd, gi_out)
     return idx_out, out_shape, rb, gi_out
 
 
-def build_index_plan(indices, batch, shape, steps, while_waiting=None):
+def _plan_enqueue(level0, batch, shape, steps, counts, c0, gi0=None):
+    """Phase A of an index plan, no host sync: the voxel level's index (O(sites)) and the output index set of every strided
+    convolution, each derived from the bitmap of the level before it (toda_gridindex_from_bitmap: output stationary, no
+    atomics, the input row count never enters).  level0 = (indices [n_upper, 4], n_upper, n_dev or None).  counts: int32 device
+    vector, slot c0 + l receives the row count of the l-th strided level.  Returns the level list."""
+    lib = L.load()
+    idx0, n_upper, n_dev = level0
+    dev = idx0.device
+    slot = _arena.current_slot()
+    tag = slot.plans if slot is not None else 0
+    if gi0 is None:
+        gi0 = GridIndex.unordered_begin(batch, shape, dev, name=("gi0", tag))
+    gi0.unordered_build(idx0, n_dev)
+    levels = [{"idx": idx0, "n_upper": n_upper, "shape": [int(v) for v in shape], "gi": gi0}]
+    li = 0
+    for st in steps:
+        if st["kind"] != "conv":
+            continue
+        cur = levels[-1]
+        ks, sd, pd = _triple(st["ksize"]), _triple(st["stride"]), _triple(st["padding"])
+        out_shape = conv_out_shape(cur["shape"], ks, sd, pd)
+        cap = _conv_cap(cur["n_upper"], batch, out_shape, ks, sd)
+        li += 1
+        shape_c = L.host_i32(out_shape)
+        buf, _ = _persistent(("gi", tag, li), (int(batch), tuple(out_shape)), lib.toda_gridindex_bytes(int(batch), L.hptr(shape_c)), dev)
+        gi_out = GridIndex(batch, out_shape, dev, buf=buf)
+        idx_out = _alloc((max(cap, 1), 4), torch.int32, dev)
+        hs = [L.host_i32(v) for v in (cur["shape"], ks, sd, pd, out_shape)]
+        rc = lib.toda_gridindex_from_bitmap(L.ptr(cur["gi"].buf), int(batch), L.hptr(hs[0]), L.hptr(hs[1]), L.hptr(hs[2]), L.hptr(hs[3]),
+                                            L.hptr(hs[4]), L.ptr(gi_out.buf), L.ptr(idx_out), counts.data_ptr() + 4 * (c0 + li - 1),
+                                            cap, L.stream())
+        L.check(rc, "toda_gridindex_from_bitmap")
+        levels.append({"idx": idx_out, "n_upper": cap, "shape": out_shape, "gi": gi_out, "cap": cap, "step": st})
+    if slot is not None:
+        slot.plans += 1
+    return levels
+
+
+def _plan_tables(levels, level_counts, batch, steps, training):
+    """Phase B: every neighbour table at its exact size.  level_counts[l] = rows of level l (l = 0: the voxel level)."""
+    dev = levels[0]["idx"].device
+    for lv, n in zip(levels, level_counts):
+        if lv.get("cap") is not None and n > lv["cap"]:
+            raise RuntimeError(f"strided rulebook {lv['step']['key']}: {n} outputs exceed the bound {lv['cap']}")
+        lv["n"] = int(n)
+        lv["idx"] = lv["idx"][:int(n)]
+    keys = []
+    for st in steps:
+        if st["key"] not in keys:
+            keys.append(st["key"])
+    cnts = _alloc((len(keys), 64), torch.int32, dev)
+    cnts.zero_()                        # the pair counters of every table: one fill
+    out = {}
+    li = 0
+    for st in steps:
+        cur = levels[li]
+        if st["kind"] == "subm":
+            if st["key"] in out:
+                continue
+            ks = _triple(st["ksize"])
+            rb, gi = build_subm_rulebook(cur["idx"], batch, cur["shape"], st["ksize"], st.get("dilation", 1), grid_index=cur["gi"],
+                                         pair_cnt=cnts[keys.index(st["key"])][:ks[0] * ks[1] * ks[2]])
+            out[st["key"]] = {"kind": "subm", "rb": rb, "n_in": cur["n"]}
+            for ch in st.get("halo_channels", ()):      # layers on this table that take the LDS-staged halo kernel
+                if cur["n"] >= HALO_MIN_ROWS and halo_supported(ch, ch, rb.k_vol):
+                    build_halo_plan(rb, cur["idx"], batch, cur["shape"], ch)
+        else:
+            nxt = levels[li + 1]
+            ks, sd, pd = _triple(st["ksize"]), _triple(st["stride"]), _triple(st["padding"])
+            rb = _conv_tables(cur["idx"], cur["n"], nxt["idx"], nxt["n"], batch, cur["shape"], nxt["shape"], ks, sd, pd, nxt["gi"],
+                              gi_in=cur["gi"], pair_cnt=cnts[keys.index(st["key"])][:ks[0] * ks[1] * ks[2]])
+            if training:
+                rb.class_order()        # the data gradient's row order, here instead of on the training stream
+            out[st["key"]] = {"kind": "conv", "rb": rb, "n_in": cur["n"], "out_indices": nxt["idx"],
+                              "out_shape": nxt["shape"], "gi": nxt["gi"]}
+            li += 1
+    return out
+
+
+def build_index_plan(indices, batch, shape, steps, while_waiting=None, training=None):
     """All rulebooks of a sequential sparse backbone with ONE host sync.
 
     while_waiting: optional callable run between the request for the level counts and the wait for them - work that does not
@@ -276,78 +483,38 @@ def build_index_plan(indices, batch, shape, steps, while_waiting=None):
 
     steps (forward order): {'kind': 'subm', 'key', 'ksize', 'dilation'} or
     {'kind': 'conv', 'key', 'ksize', 'stride', 'padding'}.  The output index sets of the strided
-    convolutions are built back-to-back on the device (each level reads its input row count from
-    device memory, buffers are sized by an upper bound), then the counts are read once and the
-    neighbour tables are filled at their exact sizes.  Returns {key: indice_dict entry}."""
-    lib = L.load()
-    dev = indices.device
+    convolutions are built back-to-back on the device (each from the bitmap of the level before it; buffers are sized by an
+    upper bound), then the counts are read once and the neighbour tables are filled at their exact sizes.
+    Returns {key: indice_dict entry}."""
     indices = indices.contiguous()
-    level = {"idx": indices, "n_upper": indices.shape[0], "n_dev": None, "shape": [int(v) for v in shape], "gi": None,
-             "n_out_dev": None}
-    levels = [level]
-    conv_steps = []
-    for st in steps:
-        if st["kind"] != "conv":
-            continue
-        cur = levels[-1]
-        ks, sd, pd = _triple(st["ksize"]), _triple(st["stride"]), _triple(st["padding"])
-        out_shape = conv_out_shape(cur["shape"], ks, sd, pd)
-        per_in = 1
-        for k, s_ in zip(ks, sd):
-            per_in *= -(-k // s_)
-        cap = int(min(cur["n_upper"] * per_in, batch * out_shape[0] * out_shape[1] * out_shape[2]))
-        gi_out = GridIndex(batch, out_shape, dev)
-        idx_out = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
-        n_out_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
-        hs = [L.host_i32(v) for v in (cur["shape"], ks, sd, pd, out_shape)]
-        rc = lib.toda_gridindex_from_conv(L.ptr(cur["idx"]), cur["n_upper"], L.ptr(cur["n_dev"]), int(batch), L.hptr(hs[0]),
-                                          L.hptr(hs[1]), L.hptr(hs[2]), L.hptr(hs[3]), L.hptr(hs[4]), L.ptr(gi_out.buf),
-                                          L.ptr(idx_out), L.ptr(n_out_dev), cap, L.stream())
-        L.check(rc, "toda_gridindex_from_conv")
-        nxt = {"idx": idx_out, "n_upper": cap, "n_dev": n_out_dev, "shape": out_shape, "gi": gi_out, "cap": cap}
-        conv_steps.append((st, cur, nxt, hs))
-        levels.append(nxt)
-    if conv_steps:
-        counts = read_counts(torch.cat([c[2]["n_dev"] for c in conv_steps]), while_waiting)  # the one sync
-        for (st, cur, nxt, hs), n_out in zip(conv_steps, counts):
-            if n_out > nxt["cap"]:
-                raise RuntimeError(f"strided rulebook {st['key']}: {n_out} outputs exceed the bound {nxt['cap']}")
-            nxt["idx"] = nxt["idx"][:n_out]
-            nxt["n"] = n_out
-    levels[0]["n"] = indices.shape[0]
-    out = {}
-    li = 0
-    for st in steps:
-        cur = levels[li]
-        if st["kind"] == "subm":
-            if st["key"] in out:
-                continue
-            rb, gi = build_subm_rulebook(cur["idx"], batch, cur["shape"], st["ksize"], st.get("dilation", 1),
-                                         grid_index=cur["gi"])
-            cur["gi"] = gi
-            out[st["key"]] = {"kind": "subm", "rb": rb, "n_in": cur["n"]}
-            for ch in st.get("halo_channels", ()):      # layers on this table that take the LDS-staged halo kernel
-                if cur["n"] >= HALO_MIN_ROWS and halo_supported(ch, ch, rb.k_vol):
-                    build_halo_plan(rb, cur["idx"], batch, cur["shape"], ch)
-        else:
-            nxt = levels[li + 1]
-            ks, sd, pd = _triple(st["ksize"]), _triple(st["stride"]), _triple(st["padding"])
-            K = ks[0] * ks[1] * ks[2]
-            n_in, n_out = cur["n"], nxt["n"]
-            o2i = torch.empty((K, n_out), dtype=torch.int32, device=dev)
-            i2o = torch.empty((K, n_in), dtype=torch.int32, device=dev)
-            cnt = torch.empty((K,), dtype=torch.int32, device=dev)
-            hs = [L.host_i32(v) for v in (cur["shape"], ks, sd, pd, nxt["shape"])]
-            rc = lib.toda_rulebook_conv(L.ptr(cur["idx"]), n_in, int(batch), L.hptr(hs[0]), L.hptr(hs[1]), L.hptr(hs[2]),
-                                        L.hptr(hs[3]), L.hptr(hs[4]), L.ptr(nxt["gi"].buf), n_out, L.ptr(o2i), L.ptr(i2o),
-                                        L.ptr(cnt), L.stream())
-            L.check(rc, "toda_rulebook_conv")
-            rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=sd, padding=pd)
-            rb.in_indices = cur["idx"]
-            out[st["key"]] = {"kind": "conv", "rb": rb, "n_in": n_in, "out_indices": nxt["idx"],
-                              "out_shape": nxt["shape"], "gi": nxt["gi"]}
-            li += 1
-    return out
+    n_conv = sum(1 for st in steps if st["kind"] == "conv")
+    counts = _alloc((max(n_conv, 1),), torch.int32, indices.device)
+    levels = _plan_enqueue((indices, indices.shape[0], None), batch, shape, steps, counts, 0)
+    got = read_counts(counts, while_waiting) if n_conv else []
+    if training is None:
+        training = torch.is_grad_enabled()
+    return _plan_tables(levels, [indices.shape[0]] + list(got[:n_conv]), batch, steps, training)
+
+
+def build_input_plan(clouds, voxel_cfg, batch, shape, steps, training=True, while_waiting=None):
+    """Voxelisation + collation + every rulebook of a sequential sparse backbone with ONE host sync (round 3: two, and two
+    concatenations): the voxeliser's device-side counts feed the voxel level's index, each strided level follows from the
+    bitmap before it, and one read-back returns [M_0 .. M_{B-1}, sum M, n_1 .. n_L].
+    Returns (voxels [M, P, C], coords [M, 4] int32 (b, z, y, x), num_points [M] int32, plan)."""
+    n_conv = sum(1 for st in steps if st["kind"] == "conv")
+    bsz = len(clouds)
+    dev = clouds[0][0].device
+    slot = _arena.current_slot()
+    gi0 = GridIndex.unordered_begin(batch, shape, dev, name=("gi0", slot.plans if slot is not None else 0))
+    counts = _alloc((bsz + 1 + n_conv,), torch.int32, dev)
+    voxels, coords, num, _ = voxelize_enqueue(clouds, voxel_cfg["point_cloud_range"], voxel_cfg["voxel_size"],
+                                              voxel_cfg["max_points_per_voxel"], voxel_cfg["max_num_voxels"], counts=counts,
+                                              tag=slot.plans if slot is not None else 0)
+    levels = _plan_enqueue((coords, coords.shape[0], counts[bsz:bsz + 1]), batch, shape, steps, counts, bsz + 1, gi0=gi0)
+    got = read_counts(counts, while_waiting)      # the one sync
+    m = got[bsz]
+    plan = _plan_tables(levels, [m] + list(got[bsz + 1:bsz + 1 + n_conv]), batch, steps, training)
+    return voxels[:m], levels[0]["idx"], num[:m], plan
 
 
 # --------------------------------------------------------------------------- sparse conv

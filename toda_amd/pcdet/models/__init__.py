@@ -52,9 +52,13 @@ def prepare_batch_on_gpu(batch_dict, net, voxel_cfg=None):
     The reference does this part (voxelisation) in DataLoader workers, concurrently with the previous training step
     (pcdet/datasets/processor/data_processor.py:115-143); InputPrefetcher below does it on a side stream."""
     load_data_to_gpu(batch_dict)
-    if "voxels" not in batch_dict and "points" in batch_dict:
-        voxelize_on_gpu(batch_dict, voxel_cfg if voxel_cfg is not None else net.dataset.voxel_cfg)
     backbone = getattr(net, "backbone_3d", None)
+    if "voxels" not in batch_dict and "points" in batch_dict:
+        cfg = voxel_cfg if voxel_cfg is not None else net.dataset.voxel_cfg
+        # voxels AND rulebooks behind one host sync when the backbone can plan from raw points
+        if backbone is not None and hasattr(backbone, "plan_input") and backbone.plan_input(batch_dict, cfg):
+            return batch_dict
+        voxelize_on_gpu(batch_dict, cfg)
     if backbone is not None and hasattr(backbone, "plan") and "voxel_coords" in batch_dict and batch_dict["voxel_coords"].is_cuda:
         backbone.plan(batch_dict)
     return batch_dict
@@ -104,6 +108,13 @@ class InputPrefetcher:
         # older than this point.
         self.side.wait_stream(torch.cuda.current_stream(device))
         self.pending = None
+        # Device memory of the prepared batches: rotating arena slots (toda_amd.arena) instead of the caching allocator - what the
+        # side stream produces is consumed on the caller's stream a step later, the worst case for a stream-aware allocator (round 3:
+        # hipMalloc calls inside steady-state steps).  TODA_PREFETCH_ARENA=0 goes back to the allocator.
+        from ... import arena as _arena
+        self._arena_mod = _arena
+        self.arena = _arena.IndexArena(device, int(os.environ.get("TODA_PREFETCH_SLOTS", "3"))) if os.environ.get("TODA_PREFETCH_ARENA", "1") == "1" else None
+        self._in_use = None          # slot of the batch the caller is consuming
         # The preparation runs on a worker thread (TODA_PREFETCH_THREAD=0: on the caller's), so its two host syncs and its ~150
         # launches overlap the caller's own enqueueing instead of following it: the forward-only workload is host-bound otherwise
         # (69 launches of the backbone + 155 of the next batch's index plan per 3.2 ms of GPU work: 907 -> 1144 samples/s); the
@@ -124,13 +135,15 @@ class InputPrefetcher:
                 batch = next(self.it)        # inside the side-stream context: a source that mixes / collates on the device runs there too
             except StopIteration:
                 return None
-            if isinstance(batch, (tuple, list)):      # the (adversarial, original) pair of the stage-2 consistency step
-                batch = tuple(prepare_batch_on_gpu(b, self.net, self.voxel_cfg) for b in batch)
-            else:
-                batch = prepare_batch_on_gpu(batch, self.net, self.voxel_cfg)
+            slot = self.arena.acquire(self.side) if self.arena is not None else None      # the side stream waits for the slot's last consumer
+            with self._arena_mod.use_slot(slot):
+                if isinstance(batch, (tuple, list)):      # the (adversarial, original) pair of the stage-2 consistency step
+                    batch = tuple(prepare_batch_on_gpu(b, self.net, self.voxel_cfg) for b in batch)
+                else:
+                    batch = prepare_batch_on_gpu(batch, self.net, self.voxel_cfg)
             ev = torch.cuda.Event()
             ev.record(self.side)
-        return batch, ev
+        return batch, ev, slot
 
     def kick(self):
         if self.pending is not None:
@@ -144,8 +157,12 @@ class InputPrefetcher:
         self.pending = None
         if got is None:
             raise StopIteration
-        batch, ev = got
+        batch, ev, slot = got
         main = torch.cuda.current_stream()
+        if self._in_use is not None:
+            # everything that reads the PREVIOUS batch (forward, backward, optimizer) has been enqueued on this stream by now
+            self.arena.release(self._in_use, main)
+        self._in_use = slot
         main.wait_event(ev)
         _record_stream(batch, main)
         return batch

@@ -90,6 +90,33 @@ class _Backbone8xBase(nn.Module):
         batch_dict["sparse_index_plan"] = (probe.indice_dict, probe.grid_index)
         return batch_dict
 
+    def plan_input(self, batch_dict, voxel_cfg, training=None):
+        """Raw points -> voxels / voxel_coords / voxel_num_points AND every rulebook of the backbone, three voxeliser launches and
+        ONE host sync for the lot (ops.build_input_plan) - what the reference's DataLoader workers (voxelisation,
+        pcdet/datasets/processor/data_processor.py:115-143) and spconv's lazy indice-pair builds do per sample and per layer.
+        Returns False when this batch cannot take that route (no points on the GPU)."""
+        pts = batch_dict.get("points")
+        if not hasattr(spconv, "plan_input") or pts is None or not torch.is_tensor(pts) or not pts.is_cuda or pts.dtype != torch.float32:
+            return False
+        bs = int(batch_dict["batch_size"])
+        if bs > 32 or int(voxel_cfg["max_points_per_voxel"]) > 64:
+            return False
+        counts = batch_dict.get("points_per_sample")
+        if counts is None:
+            counts = torch.bincount(pts[:, 0].long(), minlength=bs).tolist()
+        pts = pts.contiguous()
+        width = pts.shape[1]
+        clouds, start = [], 0
+        for n in counts:        # the batch tensor [sum N, 1 + C] is read in place: column 1 on, rows 1 + C floats apart
+            clouds.append((pts, start * width + 1, int(n), width - 1, width))
+            start += int(n)
+        got = spconv.plan_input(clouds, voxel_cfg, bs, self.sparse_shape, self, self.training if training is None else training)
+        if got is None:
+            return False
+        batch_dict["voxels"], batch_dict["voxel_coords"], batch_dict["voxel_num_points"], plan = got
+        batch_dict["sparse_index_plan"] = (plan, None)
+        return True
+
     def forward(self, batch_dict):
         x = self._input_tensor(batch_dict)
         ready = batch_dict.get("sparse_index_plan")

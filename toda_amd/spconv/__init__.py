@@ -9,7 +9,7 @@ from . import conv, utils  # noqa: F401
 from .conv import SparseConv3d, SparseConvolution, SparseInverseConv3d, SubMConv3d  # noqa: F401
 from .core import SparseConvTensor  # noqa: F401
 from .modules import SparseModule, SparseSequential  # noqa: F401
-from .plan import plan_indices  # noqa: F401
+from .plan import plan_indices, plan_input  # noqa: F401
 from .conv import prepack  # noqa: F401
 
 __version__ = "2.1.0+toda_amd"

@@ -31,19 +31,41 @@ def conv_steps(module):
     return steps
 
 
+def ordered_steps(module):
+    """conv_steps(module) with one step per table, or None when the module cannot be planned as a sequential chain."""
+    steps = module.__dict__.get("_plan_steps", False)
+    if steps is not False:
+        return steps
+    steps = conv_steps(module)
+    ordered = None
+    if steps:
+        seen, ordered = set(), []
+        for st in steps:
+            if st["kind"] == "conv" and st["key"] in seen:
+                ordered = None  # a strided rulebook reused by two layers: leave it to the lazy path
+                break
+            if st["kind"] == "conv" or st["key"] not in seen:
+                ordered.append(st)
+            seen.add(st["key"])
+    module.__dict__["_plan_steps"] = ordered      # the module tree is fixed after construction: derived once
+    return ordered
+
+
 def plan_indices(x, module, while_waiting=None):
     """Populate x.indice_dict for every sparse convolution under `module` (sequential topology).  while_waiting: see
     ops.build_index_plan."""
-    steps = conv_steps(module)
-    if not steps or not x.indices.is_cuda:
+    ordered = ordered_steps(module)
+    if not ordered or not x.indices.is_cuda:
         return x
-    seen, ordered = set(), []
-    for st in steps:
-        if st["kind"] == "conv" and st["key"] in seen:
-            return x  # a strided rulebook reused by two layers: leave it to the lazy path
-        if st["kind"] == "conv" or st["key"] not in seen:
-            ordered.append(st)
-        seen.add(st["key"])
     plan = ops.build_index_plan(x.indices, x.batch_size, x.spatial_shape, ordered, while_waiting)
     x.indice_dict.update(plan)
     return x
+
+
+def plan_input(clouds, voxel_cfg, batch_size, spatial_shape, module, training=True):
+    """Voxelise + collate the batch AND build every rulebook of `module` with one host round trip (ops.build_input_plan).
+    Returns (voxels, voxel_coords, voxel_num_points, indice_dict) or None when the module cannot be planned."""
+    ordered = ordered_steps(module)
+    if not ordered:
+        return None
+    return ops.build_input_plan(clouds, voxel_cfg, batch_size, spatial_shape, ordered, training=training)

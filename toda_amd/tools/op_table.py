@@ -25,7 +25,8 @@ class OpTable:
         self.cost = {}                                    # key -> (bytes, flops, note)
         self._pairs = {}
         self._orig = {}
-        for name in ("toda_voxelize_hard", "toda_mean_vfe_fwd", "toda_mean_vfe_bwd", "toda_gridindex_from_coords", "toda_gridindex_from_conv",
+        for name in ("toda_voxelize_hard", "toda_voxelize_batch", "toda_gridindex_from_coords_unordered", "toda_gridindex_from_bitmap", "toda_gridindex_clear",
+                     "toda_rulebook_class_order", "toda_mean_vfe_fwd", "toda_mean_vfe_bwd", "toda_gridindex_from_coords", "toda_gridindex_from_conv",
                      "toda_rulebook_subm", "toda_rulebook_conv", "toda_sparse_to_dense_fwd", "toda_sparse_to_dense_bwd", "toda_rows_moments",
                      "toda_rows_affine_act", "toda_rows_bn_bwd_res", "toda_bn2d_fwd", "toda_bn2d_bwd", "toda_spconv_pack_weight", "toda_conv3x3_transform_weight",
                      "toda_center_assign", "toda_bn2d_fwd_into", "toda_bn2d_bwd_from", "toda_clip_adam_step", "toda_conv3x3s2_fwd", "toda_conv3x3s2_dgrad",
@@ -126,6 +127,37 @@ class OpTable:
         n, c, max_pts, cap = a[1], a[2], a[6], a[7]
         m = min(cap, n)
         return (n, c, max_pts), ("fixed", 4.0 * n * c + 2 * 4.0 * m * max_pts * c + 20.0 * m, 0.0, "M bounded by min(cap, points)")
+
+    @staticmethod
+    def _host_i32(arg, n):
+        import ctypes
+        addr = arg.value if hasattr(arg, "value") else int(arg)
+        return list(ctypes.cast(addr, ctypes.POINTER(ctypes.c_int32))[0:n])
+
+    @classmethod
+    def _c_toda_voxelize_batch(cls, a):
+        batch, c, max_pts, cap = a[2], a[4], a[9], a[10]
+        ns = cls._host_i32(a[1], batch)
+        byts = sum(4.0 * n * c + 2 * 4.0 * min(cap, n) * max_pts * c + 20.0 * min(cap, n) for n in ns)
+        return (batch, sum(ns), c, max_pts), ("fixed", byts, 0.0, "whole batch (3 launches): per sample 4NC + 8MPC + 20M, M bounded by min(cap, points)")
+
+    def _c_toda_gridindex_from_coords_unordered(self, a):
+        n = a[1]
+        return (n,), ("fixed", 16.0 * n + 8.0 * n, 0.0, "16 B coordinate row + one 8-byte cell per site; n = upper bound (cap) of the rows")
+
+    _c_toda_gridindex_clear = _c_toda_gridindex_from_coords_unordered
+
+    @classmethod
+    def _c_toda_gridindex_from_bitmap(cls, a):
+        batch = a[1]
+        di, do = cls._host_i32(a[2], 3), cls._host_i32(a[6], 3)
+        ci, co = batch * di[0] * di[1] * di[2] / 32.0, batch * do[0] * do[1] * do[2] / 32.0
+        return (batch, *do), ("fixed", 8.0 * ci + 8.0 * co, 0.0, "one pass over the input bitmap's and the output bitmap's 8-byte words (output rows not counted)")
+
+    @staticmethod
+    def _c_toda_rulebook_class_order(a):
+        n = a[1]
+        return (n,), ("fixed", 16.0 * n + 5.0 * n, 0.0, "16 B coordinate row in, order + class out")
 
     @staticmethod
     def _c_toda_mean_vfe_fwd(a):

@@ -140,6 +140,14 @@ class KernelTimer:
             return self._orig_halo(feat, wp, nbr, c_produce, *rest, **kw)
 
         ops.gather_gemm_halo = labelled_halo
+        self._orig_subm = ops.gather_gemm_subm              # 64 -> 64 / 32 -> 32 SubM layers on the line kernel (same dispatch-stamped launches)
+
+        def labelled_subm(feat, wp, nbr, c_produce, *rest, **kw):
+            if self._enabled and len(self.records) < self.CAPACITY:
+                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+            return self._orig_subm(feat, wp, nbr, c_produce, *rest, **kw)
+
+        ops.gather_gemm_subm = labelled_subm
 
     @property
     def enabled(self):
@@ -344,12 +352,15 @@ def run_gpu(args, rank, world, device):
     gc.disable()
     for it in range(args.warmup):
         loss = step(it)
+    # everything the timed region needs is set up BEFORE the synchronisation (1024 + K events, the library's dispatch stamps): the GPU
+    # should idle for microseconds, not milliseconds, between the last warm-up kernel and the first timed one (an idle GPU drops its
+    # clocks; the first timed step of a run measured 1-1.6 ms longer than the steps after it)
+    timer.enabled = True
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     cpu0 = time.thread_time()
     marks[0].record()
@@ -594,6 +605,30 @@ def _free_port():
     return port
 
 
+def _allowed_cpus():
+    try:
+        return sorted(os.sched_getaffinity(0))
+    except AttributeError:      # pragma: no cover
+        return list(range(os.cpu_count() or 1))
+
+
+def place_rank(local_rank, world):
+    """Pin this rank to its share of the CPUs the job may use (contiguous block per LOCAL_RANK) BEFORE anything touches the GPU:
+    the HIP runtime's threads and the prefetch worker inherit the mask, and eight ranks stop migrating over each other's cores.
+    TODA_BENCH_AFFINITY=0 leaves the mask alone.  Returns the CPUs of this rank."""
+    cpus = _allowed_cpus()
+    if os.environ.get("TODA_BENCH_AFFINITY", "1") != "1" or world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return cpus
+    per = max(1, len(cpus) // world)
+    mine = cpus[(local_rank * per) % len(cpus):][:per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:             # a cgroup that refuses: keep the inherited mask
+        return cpus
+    torch.set_num_threads(max(1, min(per, int(os.environ.get("OMP_NUM_THREADS", per)))))
+    return mine
+
+
 def launch_ranks(args, argv):
     """--gpus N > 1 without a rank environment: this process never touches the GPU.  It starts one fresh process per GPU
     through torch.distributed.run (the same command line the driver uses), lets their output through (rank 0 prints the
@@ -607,7 +642,9 @@ def launch_ranks(args, argv):
             return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL needs it)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    # host budget per rank: the CPUs this process may run on, dealt evenly (a GPU box exposes every core of the host, its share per
+    # GPU is 16; 8 ranks of a node therefore live on 2 cores each: main thread + prefetch worker)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(_allowed_cpus()) // max(args.gpus, 1))))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
     return subprocess.run(cmd, env=env).returncode
@@ -623,8 +660,10 @@ def dry_run(args, rank, world):
     ones = torch.ones(1)
     dist.all_reduce(ones)
     dist.barrier()
+    cpus = [None] * world
+    dist.all_gather_object(cpus, sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else [])
     line = {"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "comm": {"ranks": int(ones.item()), "backend": "gloo"}}
+            "comm": {"ranks": int(ones.item()), "backend": "gloo"}, "rank_cpus": cpus}
     spec = os.environ.get("TODA_BENCH_DRYRUN_REHEARSAL")
     if spec:
         import importlib
@@ -716,6 +755,7 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    rank_cpus = place_rank(local_rank, world)      # before any GPU call
     if os.environ.get("TODA_BENCH_DRYRUN") == "1":
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
@@ -760,6 +800,7 @@ def main(argv=None):
                        "alloc_retries": int(torch.cuda.memory_stats(device).get("num_alloc_retries", 0)),
                        "reserved_gib": round(torch.cuda.memory_reserved(device) / 2 ** 30, 2),
                        "device_allocs_in_timed_steps": int(sum(res["device_allocs"])),
+                       "rank0_cpus": len(rank_cpus),
                        "slowest_step_ms": round(max(step_ms), 3) if step_ms else None,
                        "slowest_step_host_enqueue_ms": round(res["host_step_ms"][int(np.argmax(step_ms))], 3) if step_ms else None},
             # per-step GPU time between events recorded at the step boundaries of rank 0 (no sync inside the region)

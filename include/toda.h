@@ -189,6 +189,18 @@ int toda_spconv_pack_weights(int n, const float* const* w_host, const int32_t* c
 int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp,
                             const int32_t* nbr, int n_out, int k_vol, int c_produce,
                             const float* bias /*nullable*/, float* out, void* stream);
+/* The same over the table of a SUBMANIFOLD 3 x 3 x 3 convolution (toda_rulebook_subm; spconv.SubMConv3d,
+ * pcdet/models/backbones_3d/spconv_backbone.py:12,78-105) - forward, or the data gradient over the same table with the
+ * reversed operand.  The caller vouches for the table's kind: nbr[12] / nbr[14] are then a row's x-neighbours, and where
+ * such a neighbour is the adjacent row of the 16-row tile the kernel takes the outer offsets' operands of a stencil line from
+ * the centre offset's gather by a lane shift instead of gathering them again (64 -> 64 and 32 -> 32; other shapes run the
+ * kernels of toda_spconv_gather_gemm).  Bit-identical results.  sums / blocks_out: NULL, or as
+ * toda_spconv_gather_gemm_stats / _stats_partials. */
+int toda_spconv_gather_gemm_subm(const float* in, int n_in, int c_gather, const float* wp,
+                                 const int32_t* nbr, int n_out, int k_vol, int c_produce,
+                                 const float* bias, float* out, double* sums, size_t sums_doubles,
+                                 int* blocks_out, void* stream);
+
 /* Same, visiting the output rows in the order `order[n_out]` (a permutation, nullable = canonical): results are
  * identical, only the assignment of rows to waves changes.  toda_rulebook_row_order builds the order that sorts
  * rows by their K-bit neighbour mask inside blocks of 2048 canonical rows, which lets whole (32-row tile, offset)

@@ -60,3 +60,33 @@ def test_two_rank_rehearsal_of_the_n_gpu_bench_path(reducer):
     for key in ("allreduce_ms_standalone", "ms_per_step_without_allreduce", "allreduce_exposed_ms", "allreduce_hidden_ms"):
         assert comm[key] >= 0.0
     assert comm["ms_per_step_without_allreduce"] > 0 and line["ms_per_step"] > 0 and line["value"] > 0
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("reducer", ["own", "torch"])
+def test_world_8_rehearsal_places_every_rank_and_all_eight_answer(reducer):
+    """The shape of the driver's N = 8 run (reference tools/scripts/dist_train.sh:18, tools/train.py:65-74,143) on eight
+    gloo ranks of this container: one JSON line, comm.ranks == 8, both reducers, and every rank pinned to its own slice of the allowed
+    CPUs before it does anything else (8 cores here: one each; on the GPU box 16: two each - main thread + prefetch worker)."""
+    p = _run({"TODA_BENCH_DRYRUN_REHEARSAL": "tests.bench_rehearsal:make", "TODA_DDP": reducer, "PYTHONPATH": ROOT},
+             "--gpus", "8", "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["comm"]["ranks"] == 8
+    assert line["comm"]["reducer"] == ("DataParallel" if reducer == "own" else "DistributedDataParallel")
+    cpus = line["rank_cpus"]
+    allowed = sorted(os.sched_getaffinity(0))
+    per = max(1, len(allowed) // 8)
+    assert len(cpus) == 8 and all(len(c) == per for c in cpus), cpus
+    if len(allowed) >= 8:
+        flat = [c for rank in cpus for c in rank]
+        assert len(set(flat)) == len(flat), f"ranks share CPUs: {cpus}"
+
+
+@pytest.mark.timeout(900)
+def test_missing_rank_line_is_a_failure_at_world_8():
+    """A rank that dies takes the launcher's exit status with it at N = 8 too (no JSON line is accepted from a partial job)."""
+    p = _run({"TODA_BENCH_DRYRUN_FAIL_RANK": "5"}, "--gpus", "8")
+    assert p.returncode != 0

@@ -287,7 +287,8 @@ def test_strided_conv_fwd_dgrad_wgrad(ks, st, pd, cin, cout):
     np.testing.assert_allclose(wt.grad.cpu().numpy(), dw0, rtol=1e-4, atol=1e-4 * np.abs(dw0).max())
 
 
-@pytest.mark.parametrize("cg,cp,dense", [(5, 16, False), (4, 16, False), (16, 16, False), (16, 16, True), (16, 32, False), (32, 16, False), (12, 20, False)])
+@pytest.mark.parametrize("cg,cp,dense", [(5, 16, False), (4, 16, False), (16, 16, False), (16, 16, True), (16, 32, False), (32, 16, False), (12, 20, False),
+                                         (18, 16, False), (22, 32, False)])      # the last two: gather_gemm_compact_kernel<2, false> (every instantiation)
 def test_compacting_narrow_gather_gemm_matches_the_output_stationary_kernel(cg, cp, dense):
     """toda_spconv_gather_gemm_compact (K = 27, <= 32 gathered, <= 32 produced channels: a wave compacts the rows that have a
     neighbour at the offset and adds the tile's product to its rows of an LDS accumulator) against toda_spconv_gather_gemm on
@@ -314,6 +315,9 @@ def test_compacting_narrow_gather_gemm_matches_the_output_stationary_kernel(cg, 
     got = ops.gather_gemm_compact(x, w, rb.nbr_fwd, cp, bias)
     assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     assert torch.equal(ops.gather_gemm_compact(x, w, rb.nbr_fwd, cp, bias), got)
+    # ... and the oracle itself (the kernel's ring loads are hand-counted inline asm: every instantiation <1|2, vec|dword> is pinned here)
+    y0 = O.spconv_fwd(feat, w.cpu().numpy(), rb.nbr_fwd.cpu().numpy(), bias.cpu().numpy())
+    np.testing.assert_allclose(got.cpu().numpy(), y0, rtol=0, atol=1e-4 * np.abs(y0).max())
     # data gradient: gathers cp channels, produces cg (supported when the produced side is a multiple of 4)
     if cg % 4 == 0:
         g = dev(rng.standard_normal((len(idx), cp)).astype(np.float32))
@@ -942,3 +946,39 @@ def test_fused_clip_decay_adam_step_matches_the_torch_path():
     for pc, pd in zip(c.parameters(), d.parameters()):
         assert float(oc.opt.state[pc]["step"]) == float(od.opt.state[pd]["step"]) == 6
         assert float((pc.detach() - pd.detach()).abs().max()) <= 4e-6 * max(float(pd.detach().abs().max()), 1e-3)
+
+
+def test_fused_optimizer_handles_a_parameter_that_sits_out_a_step_like_the_torch_path():
+    """a parameter without a gradient in some steps.  The reference's wrapper decays EVERY requires_grad parameter
+    (OptimWrapper.step) and Adam keeps a step counter per parameter; the two-launch kernel has one count and one table, so such steps -
+    and every later step while the counters disagree - run on the torch path.  Parameters, moments and counters equal a wrapper that
+    never used the kernel."""
+    from toda_amd.tools.train_utils.optimization import OneCycleAdam, clip_and_step
+
+    def make():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Linear(9, 40), torch.nn.Linear(40, 12), torch.nn.Linear(12, 3)).cuda()
+
+    a, b = make(), make()
+    oa, ob = OneCycleAdam(a, wd=0.01), OneCycleAdam(b, wd=0.01)
+    ob._hip_step = False
+    oa.lr, oa.mom, ob.lr, ob.mom = 2e-3, 0.9, 2e-3, 0.9
+    g = torch.Generator(device="cuda").manual_seed(9)
+    fused = []
+    for it in range(6):
+        for k, (pa, pb) in enumerate(zip(a.parameters(), b.parameters())):
+            if it in (2, 3) and k >= 4:          # the last layer sits out steps 2 and 3
+                pa.grad = pb.grad = None
+                continue
+            gr = torch.randn(pa.shape, device="cuda", generator=g)
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        with H.abi_calls("toda_clip_adam_step") as calls:
+            clip_and_step(oa, list(a.parameters()), 10.0)
+        fused.append(calls["toda_clip_adam_step"])
+        clip_and_step(ob, list(b.parameters()), 10.0)
+        oa.state_dict()
+        for (n, pa), pb in zip(a.named_parameters(), b.parameters()):
+            assert float((pa.detach() - pb.detach()).abs().max()) <= 2e-6 * max(float(pb.detach().abs().max()), 1e-3), (it, n)
+            if pb in ob.opt.state and len(ob.opt.state[pb]):
+                assert float(oa.opt.state[pa]["step"]) == float(ob.opt.state[pb]["step"]), (it, n)
+    assert fused[:2] == [1, 1] and fused[2:] == [0, 0, 0, 0], fused      # counters differ after the gap: torch path from then on

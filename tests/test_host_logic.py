@@ -302,3 +302,28 @@ def test_grad_bucket_reducer_single_rank_keeps_gradients_and_views(tmp_path):
             assert torch.allclose(p.grad, a + b)
     finally:
         dist.destroy_process_group()
+
+
+def test_consistency_loss_ignores_inf_and_nan_in_unselected_candidate_rows():
+    """the padded form of get_consistency_loss (reference pcdet/models/__init__.py:216-260) keeps unselected candidate rows
+    behind a mask; such a row may hold inf / nan (dim.exp() of a wild regression output) and must not reach the loss."""
+    import torch
+    from toda_amd.pcdet.models import get_consistency_loss
+
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(12, 7, generator=g)
+    o = a + 0.05 * torch.randn(12, 7, generator=g)
+    va = torch.tensor([True] * 8 + [False] * 4)
+    vo = torch.tensor([True] * 9 + [False] * 3)
+    clean = get_consistency_loss([{"pred_boxes": a.clone(), "mask": va}], [{"pred_boxes": o.clone(), "mask": vo}])
+    a_bad, o_bad = a.clone(), o.clone()
+    a_bad[9] = float("inf")
+    a_bad[10, 3:6] = float("nan")
+    o_bad[11] = float("-inf")
+    dirty = get_consistency_loss([{"pred_boxes": a_bad, "mask": va}], [{"pred_boxes": o_bad, "mask": vo}])
+    for c, d in zip(clean, dirty):
+        assert torch.isfinite(d) and float(c) == float(d)
+    # and the unpadded form (selected rows only) gives the same numbers
+    plain = get_consistency_loss([{"pred_boxes": a[va]}], [{"pred_boxes": o[vo]}])
+    for c, p in zip(clean, plain):
+        assert abs(float(c) - float(p)) < 1e-6

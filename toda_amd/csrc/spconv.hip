@@ -599,8 +599,9 @@ gather_gemm_ws_kernel(const float* __restrict__ in, int n_in, int cg, const floa
 #ifndef GG_XCD_CHUNK
 #define GG_XCD_CHUNK 32
 #endif
+__device__ int d_xcd_chunk = GG_XCD_CHUNK;      // TODA_GG_XCD_CHUNK overrides it (experiments: the chunk sweep per launch shape)
 __device__ __forceinline__ int xcd_chunked_block(int b, int nblk) {
-    constexpr int C = GG_XCD_CHUNK;
+    const int C = d_xcd_chunk;
     if (C <= 0) return b;
     const int per = 8 * C, full = (nblk / per) * per;
     if (b >= full) return b;
@@ -878,6 +879,312 @@ gather_gemm_lds_kernel(const float* __restrict__ in, int n_in, int cg, const flo
                     if (NT * r + n < cp) dst[n] = acc[rt][n][reg];
             }
         }
+    }
+}
+
+// ---- round 4: x-run operand reuse for submanifold tables ("line" kernel) -----------------------------------------------------
+// The 27 offsets of a 3x3x3 submanifold stencil are 9 LINES (dz, dy) of three offsets dx = -1, 0, +1.  If the site one cell to the
+// left of output row i is itself an output row j (nbr[(0,0,-1)][i] == j), then the input row that i reads through (dz, dy, -1) is the
+// one j reads through (dz, dy, 0): both are the site at (z + dz, y + dy, x - 1).  Rows come in x-runs (canonical order), so j is
+// usually row i - 1, i.e. LANE r - 1 of the same 16-row MFMA tile: the A fragment of offset (dz, dy, -1) is the fragment of
+// (dz, dy, 0) moved one lane up inside each 16-lane row (DPP row_shr:1), and (dz, dy, +1) one lane down.  Per line the wave
+// therefore gathers the centre offset's rows completely and, for the two outer offsets, only the rows whose x-neighbour is not
+// the adjacent lane (run ends, tile edges) - those lanes' loads carry an out-of-range offset and cost no memory traffic.  The
+// per-offset kernel gathers 3 x 16 rows per line and tile; this one 16 + the run ends (25-30 on the C3 levels).  Same operands,
+// same MFMA order: bit-identical to gather_gemm_lds_kernel.  Everything else (LDS weight slices, barrier per offset, tile
+// skipping, statistics epilogue, XCD chunking) is that kernel's.
+__device__ __forceinline__ float dpp_row_shr1(float v) {      // lane r <- lane r - 1 within its row of 16 (lane 0 of a row: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_row_shl1(float v) {      // lane r <- lane r + 1 within its row of 16 (lane 15: 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));
+}
+
+template <int Q, int NT, int RT>
+__global__ void __launch_bounds__(SC_BLOCK, (Q * NT <= 4) ? 4 : 3)
+gather_gemm_line_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
+                        int n_out, int cp, const float* __restrict__ bias, float* __restrict__ out, double* __restrict__ stats) {
+    constexpr int BLK = SC_BLOCK;
+    constexpr int SLICE = Q * NT * 64;                    // float4 per offset
+    constexpr int PER_THREAD = (SLICE + BLK - 1) / BLK;
+    static_assert(SLICE % BLK == 0, "the slice is staged in whole 1 KiB wave pieces");
+    __shared__ f32x4 wl[2][SLICE];
+    const int lane = threadIdx.x & 63;
+    const int blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const int wave = blk * (BLK / 64) + (threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = wave * (16 * RT);
+    const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        float b = 0.0f;
+        if (bias && NT * r + n < cp) b = bias[NT * r + n];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][n] = f32x4{b, b, b, b};
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cg * 4u);
+    int rows[RT];
+    bool live[RT], adjL[RT], adjR[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        live[rt] = row0 + rt * 16 + r < n_out;
+        rows[rt] = live[rt] ? row0 + rt * 16 + r : n_out - 1;
+        // x-neighbours that are the adjacent rows of this tile (offsets 12 = (0, 0, -1) and 14 = (0, 0, +1))
+        const int left = nbr[(size_t)12 * n_out + rows[rt]], right = nbr[(size_t)14 * n_out + rows[rt]];
+        adjL[rt] = live[rt] && r > 0 && left == rows[rt] - 1;
+        adjR[rt] = live[rt] && r < 15 && right == rows[rt] + 1;
+    }
+#pragma unroll
+    for (int t = 0; t < PER_THREAD; ++t) {
+        const int e = t * BLK + threadIdx.x;
+        if (e < SLICE) wl[0][e] = wp4[e];
+    }
+    int idn[3][RT];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) idn[d][rt] = __builtin_nontemporal_load(nbr + (size_t)d * n_out + rows[rt]);
+    __syncthreads();
+
+    // next offset's weight slice: global -> LDS by LDS-DMA (16 B per lane, lane-linear: exactly the slice's layout), no staging
+    // registers - this kernel holds two operand sets (centre + run ends) where the per-offset kernel holds one
+    const int wave_base = threadIdx.x & ~63;
+    auto stage_dma = [&](int kn, int buf) {
+#pragma unroll
+        for (int t = 0; t < PER_THREAD; ++t) {
+            const int e = t * BLK + threadIdx.x;
+            if (SLICE % BLK == 0 || e < SLICE)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(wp4 + (size_t)kn * SLICE + e),
+                                                 reinterpret_cast<float*>(&wl[buf][t * BLK + wave_base]), 16, 0, 0);
+        }
+    };
+    auto mma = [&](int buf, const f32x4 (&a)[RT][Q], const bool (&hit)[RT]) {
+        // per accumulator the products arrive in the per-offset kernel's order (q, then j): same bits.  n outside j keeps one B
+        // fragment live at a time; consecutive MFMAs still alternate between the two row tiles' accumulators.
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 b = wl[buf][(q * NT + n) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+                        if (hit[rt]) acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][q][j], b[j], acc[rt][n], 0, 0, 0);
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int line = 0; line < 9; ++line) {
+        const int k0 = 3 * line;
+        int s0[RT], s1[RT], s2[RT], f0[RT], f2[RT];
+        bool hit0[RT], hit1[RT], hit2[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            s0[rt] = live[rt] ? idn[0][rt] : -1;
+            s1[rt] = live[rt] ? idn[1][rt] : -1;
+            s2[rt] = live[rt] ? idn[2][rt] : -1;
+            hit0[rt] = __any(s0[rt] >= 0);
+            hit1[rt] = __any(s1[rt] >= 0);
+            hit2[rt] = __any(s2[rt] >= 0);
+            f0[rt] = adjL[rt] ? -1 : s0[rt];      // rows whose left neighbour is not the lane next door gather for themselves
+            f2[rt] = adjR[rt] ? -1 : s2[rt];
+        }
+        f32x4 a1[RT][Q], f[RT][Q];
+        // ---- dx = -1
+        {
+            gather_rows<Q, RT, true>(in_rsrc, cg, g, s1, a1);      // the centre offset's rows first: both outer offsets take most lanes from them
+            gather_rows<Q, RT, true>(in_rsrc, cg, g, f0, f);
+            stage_dma(k0 + 1, (k0 & 1) ^ 1);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float sh = dpp_row_shr1(a1[rt][q][j]);
+                        f[rt][q][j] = adjL[rt] ? sh : f[rt][q][j];
+                    }
+            mma(k0 & 1, f, hit0);
+            __syncthreads();
+        }
+        // ---- dx = 0 (the run ends of dx = +1 are requested first and arrive under this offset's matrix work)
+        {
+            gather_rows<Q, RT, true>(in_rsrc, cg, g, f2, f);
+            stage_dma(k0 + 2, (k0 + 2) & 1);
+            mma((k0 + 1) & 1, a1, hit1);
+            __syncthreads();
+        }
+        // ---- dx = +1
+        {
+            if (line < 8) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) idn[d][rt] = __builtin_nontemporal_load(nbr + (size_t)(k0 + 3 + d) * n_out + rows[rt]);
+                stage_dma(k0 + 3, (k0 + 3) & 1);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float sh = dpp_row_shl1(a1[rt][q][j]);
+                        f[rt][q][j] = adjR[rt] ? sh : f[rt][q][j];
+                    }
+            mma((k0 + 2) & 1, f, hit2);
+            __syncthreads();
+        }
+    }
+    if (row0 >= n_out && !stats) return;
+
+    if (stats) {      // BatchNorm moments of the output rows (see gather_gemm_lds_kernel)
+        __shared__ float st_sh[BLK / 64][2][16 * NT];
+        float sm[NT], sq[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            sm[n] = sq[n] = 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (row0 + rt * 16 + 4 * g + reg < n_out) {
+                        const float v = acc[rt][n][reg];
+                        sm[n] += v;
+                        sq[n] += v * v;
+                    }
+            sm[n] += __shfl_xor(sm[n], 16, 64);
+            sq[n] += __shfl_xor(sq[n], 16, 64);
+            sm[n] += __shfl_xor(sm[n], 32, 64);
+            sq[n] += __shfl_xor(sq[n], 32, 64);
+            if (g == 0) {
+                st_sh[threadIdx.x >> 6][0][NT * r + n] = sm[n];
+                st_sh[threadIdx.x >> 6][1][NT * r + n] = sq[n];
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * cp) {
+            const int qq = threadIdx.x / cp, ch = threadIdx.x - qq * cp;
+            double a2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < BLK / 64; ++w) a2 += (double)st_sh[w][qq][ch];
+            stats[2 * cp + (size_t)(qq * cp + ch) * gridDim.x + blk] = a2;
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = row0 + rt * 16 + 4 * g + reg;
+            if (row >= n_out) continue;
+            float* dst = out + (size_t)row * cp + NT * r;
+            if constexpr (NT == 2) {
+                *reinterpret_cast<float2*>(dst) = make_float2(acc[rt][0][reg], acc[rt][1][reg]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NT; n += 4)
+                    *reinterpret_cast<f32x4*>(dst + n) = f32x4{acc[rt][n][reg], acc[rt][n + 1][reg], acc[rt][n + 2][reg], acc[rt][n + 3][reg]};
+            }
+        }
+    }
+}
+
+// ---- round 4: 128 -> 128 (VoxelResBackBone8x stride-8 level): half slices by LDS-DMA, double buffered --------------------------
+// The 64 KiB weight slice of an offset does not fit twice into a workgroup's LDS share, so gather_gemm_lds_kernel<8, 8, 1, .., DB =
+// false, 512> keeps ONE buffer: per offset every thread holds 128 bytes of the next slice in registers (32 VGPRs), and between
+// two barriers all 8 waves stop multiplying while the slice is copied registers -> LDS.  Here the slice is cut into its two
+// halves of 64 produced channels (n tiles 0-3 / 4-7 are contiguous 4 KiB pieces of the packed operand): two 32 KiB buffers, the
+// NEXT half always in flight by LDS-DMA (global_load_lds, no registers) while the current one is multiplied - one barrier per
+// half, no copy phase, 32 registers fewer.  A wave gathers its 16 rows once per offset and uses them for both halves; per
+// accumulator the products arrive in the per-offset kernel's order: bit-identical.
+template <int BLK>
+__global__ void __launch_bounds__(BLK, 4)
+gather_gemm_wide_kernel(const float* __restrict__ in, int n_in, int cg, const float* __restrict__ wp, const int* __restrict__ nbr,
+                        int n_out, int K, int cp, const float* __restrict__ bias, float* __restrict__ out) {
+    constexpr int Q = 8, NT = 8, HN = 4;                 // 128 gathered, 128 produced channels; 4 n tiles per half
+    constexpr int HALF = Q * HN * 64;                    // float4 per half slice (32 KiB)
+    constexpr int PER_THREAD = HALF / BLK;
+    static_assert(HALF % BLK == 0 && 256 % 64 == 0, "a wave's 1 KiB DMA piece stays inside one (q, half) run of the packed operand");
+    __shared__ f32x4 wl[2][HALF];
+    const int lane = threadIdx.x & 63;
+    const int blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const int wave = blk * (BLK / 64) + (threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int row0 = wave * 16;
+    const f32x4* __restrict__ wp4 = reinterpret_cast<const f32x4*>(wp);
+    const int wave_base = threadIdx.x & ~63;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        float b = 0.0f;
+        if (bias && NT * r + n < cp) b = bias[NT * r + n];
+        acc[n] = f32x4{b, b, b, b};
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cg * 4u);
+    const bool live = row0 + r < n_out;
+    const int row = live ? row0 + r : n_out - 1;
+
+    // half h of offset k: for every q the 256 float4 at ((k * Q + q) * NT + 4 h) * 64 of the packed operand -> wl[buf][q * 256 ..]
+    auto dma_half = [&](int k, int h, int buf) {
+#pragma unroll
+        for (int t = 0; t < PER_THREAD; ++t) {
+            const int e = t * BLK + threadIdx.x;          // 0 .. HALF: q = e / 256
+            const size_t src = ((size_t)(k * Q + (e >> 8)) * NT + HN * h) * 64 + (e & 255);
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(wp4 + src), reinterpret_cast<float*>(&wl[buf][t * BLK + wave_base]), 16,
+                                             0, 0);
+        }
+    };
+    auto mma_half = [&](int buf, int h, const f32x4 (&a)[Q]) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            f32x4 b[HN];
+#pragma unroll
+            for (int n = 0; n < HN; ++n) b[n] = wl[buf][(q * HN + n) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < HN; ++n)
+                    acc[HN * h + n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][j], b[n][j], acc[HN * h + n], 0, 0, 0);
+        }
+    };
+
+    dma_half(0, 0, 0);
+    int id_next = __builtin_nontemporal_load(nbr + row);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const int src = live ? id_next : -1;
+        const int kn = k + 1 < K ? k + 1 : K - 1;
+        id_next = __builtin_nontemporal_load(nbr + (size_t)kn * n_out + row);
+        const bool hit = __any(src >= 0);
+        f32x4 a[Q];
+        {
+            const int s1[1] = {src};
+            f32x4 a1[1][Q];
+            gather_rows<Q, 1, true>(in_rsrc, cg, g, s1, a1);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) a[q] = a1[0][q];
+        }
+        dma_half(k, 1, 1);                    // behind the gathers in issue order: the wait for the rows leaves it in flight
+        if (hit) mma_half(0, 0, a);
+        __syncthreads();                      // half 1 has landed; everybody is done with half 0
+        if (k + 1 < K) dma_half(k + 1, 0, 0);
+        if (hit) mma_half(1, 1, a);
+        __syncthreads();
+    }
+    if (row0 >= n_out) return;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int orow = row0 + 4 * g + reg;
+        if (orow >= n_out) continue;
+        float* dst = out + (size_t)orow * cp + NT * r;
+#pragma unroll
+        for (int n = 0; n < NT; n += 4) *reinterpret_cast<f32x4*>(dst + n) = f32x4{acc[n][reg], acc[n + 1][reg], acc[n + 2][reg], acc[n + 3][reg]};
     }
 }
 
@@ -2535,6 +2842,8 @@ extern "C" int toda_spconv_gather_gemm_stats_partials(const float* in, int n_in,
     return rc;
 }
 
+static thread_local bool g_subm_table = false;      // set by toda_spconv_gather_gemm_subm around its launch
+
 static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
                             int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream,
                             const unsigned char* cls_sorted, const toda::GatherClasses* cls_table) {
@@ -2553,6 +2862,14 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     }
     const int Q = tiles_pow2(c_gather), NT = tiles_pow2(c_produce);
     hipStream_t s = (hipStream_t)stream;
+    static const bool chunk_set = [] {
+        if (const char* e = getenv("TODA_GG_XCD_CHUNK")) {
+            const int v = atoi(e);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(toda::d_xcd_chunk), &v, sizeof(int));
+        }
+        return true;
+    }();
+    (void)chunk_set;
     // tuning knobs for experiments: TODA_GG_RT in {1,2,4} (0 = built-in choice), TODA_GG_PF in {0,1}
     static const int env_rt = getenv("TODA_GG_RT") ? atoi(getenv("TODA_GG_RT")) : 0;
     static const int env_pf = getenv("TODA_GG_PF") ? atoi(getenv("TODA_GG_PF")) : 0;
@@ -2561,7 +2878,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     static const int env_lds_raw = getenv("TODA_GG_LDS") ? atoi(getenv("TODA_GG_LDS")) : 1;
     const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);
     const bool vec_ok = (c_gather & 3) == 0;
-    static const int env_lds88 = getenv("TODA_GG_LDS88") ? atoi(getenv("TODA_GG_LDS88")) : 3;  // 1: RT=1 single-buffer LDS (0.67 ms), 2: RT=2 (0.76), 0: registers-only RT=2 (0.70) on 97.5k x 27 x 128 x 128
+    const int env_lds88 = getenv("TODA_GG_LDS88") ? atoi(getenv("TODA_GG_LDS88")) : 3;      // (read per call: tests and A/B runs flip it inside one process)  // 1: RT=1 single-buffer LDS (0.67 ms), 2: RT=2 (0.76), 0: registers-only RT=2 (0.70) on 97.5k x 27 x 128 x 128
     if (env_lds88 && vec_ok && Q == 8 && NT == 8 && !cls_sorted) {
         if (env_lds88 == 2)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)),
@@ -2569,6 +2886,9 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
         else if (env_lds88 == 3)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 1, true, false, 512>), dim3(cdiv(cdiv(n_out, 16), 8)),
                                dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats);
+        else if (env_lds88 == 5 && c_gather == 128 && c_produce == 128 && order == nullptr && !stats)
+            GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_wide_kernel<512>), dim3(cdiv(cdiv(n_out, 16), 8)), dim3(512), 0, s, in, n_in, c_gather, wp, nbr,
+                      n_out, k_vol, c_produce, bias, out);
         else if (env_lds88 == 4)
             GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<8, 8, 2, true, false, 512>), dim3(cdiv(cdiv(n_out, 32), 8)),
                                dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats);
@@ -2641,10 +2961,32 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
+    // submanifold tables (toda_spconv_gather_gemm_subm): x-run operand reuse
+    if (g_subm_table && k_vol == 27 && vec_ok && !cls_sorted && order == nullptr && Q == NT && (Q == 2 || Q == 4) && c_gather == 16 * Q &&
+        c_produce == 16 * NT && n_out >= 64) {
+        const int blocks = cdiv(cdiv(n_out, 32), SC_BLOCK / 64);
+        if (Q == 4)
+            GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_line_kernel<4, 4, 2>), dim3(blocks), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out,
+                      c_produce, bias, out, stats);
+        else
+            GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_line_kernel<2, 2, 2>), dim3(blocks), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out,
+                      c_produce, bias, out, stats);
+        TODA_LAUNCH_CHECK();
+        if (stats) {
+            fold_or_defer(stats, blocks, c_produce, s);
+            TODA_LAUNCH_CHECK();
+        }
+        return TODA_OK;
+    }
     static const int env_pfl = getenv("TODA_GG_LDS_PF") ? atoi(getenv("TODA_GG_LDS_PF")) : 0;   // 64 -> 64: register-pipelined gathers (experiment)
+    static const int env_blk512 = getenv("TODA_GG_BLK512") ? atoi(getenv("TODA_GG_BLK512")) : 0;   // 64 -> 64: 8 waves share a weight slice (experiment)
     if ((env_lds || stats) && !cls_sorted && vec_ok && Q * NT <= 32) {  // weight slice <= 32 KiB per buffer
 #define GL(QQ, NN, RR)                                                                                                   \
-    if (env_pfl && QQ == 4 && NN == 4 && RR == 2)                                                                        \
+    if (env_blk512 && QQ == 4 && NN == 4 && RR == 2)                                                                     \
+        GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<4, 4, 2, true, true, 512, false, true>),                        \
+                  dim3(cdiv(cdiv(n_out, 16 * RR), 8)), dim3(512), 0, s, in, n_in, c_gather, wp, nbr, n_out,               \
+                  k_vol, c_produce, bias, out, order, stats);                                                            \
+    else if (env_pfl && QQ == 4 && NN == 4 && RR == 2)                                                                   \
         GG_LAUNCH(HIP_KERNEL_NAME(gather_gemm_lds_kernel<4, 4, 2, true, true, SC_BLOCK, true>),                          \
                   dim3(cdiv(cdiv(n_out, 16 * RR), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, c_gather, wp, nbr, n_out, \
                   k_vol, c_produce, bias, out, order, stats);                                                            \
@@ -2679,7 +3021,7 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
         TODA_LAUNCH_CHECK();
         if (stats) {      // fold the per-workgroup partial sums of the launch above (same grid arithmetic as GL_RT / GL_ROW)
             const int rr = NT >= 8 ? 1 : ((env_rt == 4 && Q <= 4 && NT <= 4) ? 4 : (env_rt == 1 ? 1 : 2));
-            const int blocks = cdiv(cdiv(n_out, 16 * rr), SC_BLOCK / 64);
+            const int blocks = cdiv(cdiv(n_out, 16 * rr), (env_blk512 && Q == 4 && NT == 4 && rr == 2) ? 8 : SC_BLOCK / 64);
             fold_or_defer(stats, blocks, c_produce, s);
             TODA_LAUNCH_CHECK();
         }
@@ -2745,6 +3087,27 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
 #undef GG
     TODA_LAUNCH_CHECK();
     return TODA_OK;
+}
+
+// Gather-GEMM over the table of a SUBMANIFOLD convolution (toda_rulebook_subm, 3 x 3 x 3: nbr[12] / nbr[14] are a row's x-neighbours):
+// the 64 -> 64 and 32 -> 32 layers take gather_gemm_line_kernel, every other shape the kernels of toda_spconv_gather_gemm.  sums
+// (nullable): BatchNorm moments as toda_spconv_gather_gemm_stats; blocks_out (nullable, host): leave the partial sums unfolded as
+// toda_spconv_gather_gemm_stats_partials.  The data gradient of a submanifold layer runs over the same table (reversed weights).
+extern "C" int toda_spconv_gather_gemm_subm(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out,
+                                            int k_vol, int c_produce, const float* bias, float* out, double* sums, size_t sums_doubles,
+                                            int* blocks_out, void* stream) {
+    if (sums) {
+        TODA_CHECK_ARG(gg_stats_supported(c_gather, c_produce) && n_out > 0 && n_in > 0,
+                       "gather_gemm_subm: statistics on an unsupported channel pair (%d -> %d) or an empty table", c_gather, c_produce);
+        TODA_CHECK_ARG(sums_doubles >= toda_spconv_gather_gemm_stats_doubles(n_out, c_produce), "gather_gemm_subm: statistics buffer too small");
+    }
+    if (blocks_out) *blocks_out = 0;
+    g_subm_table = true;
+    g_stats_blocks_out = sums ? blocks_out : nullptr;
+    const int rc = gather_gemm_impl(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, nullptr, sums, stream);
+    g_stats_blocks_out = nullptr;
+    g_subm_table = false;
+    return rc;
 }
 
 extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,

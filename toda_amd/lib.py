@@ -37,6 +37,7 @@ SIGNATURES = {
     "toda_spconv_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "toda_spconv_pack_weights": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "toda_spconv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "toda_spconv_gather_gemm_subm": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "toda_rulebook_row_order": (_i, [_vp, _i, _i, _vp, _vp]),
     "toda_spconv_gather_gemm_ordered": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "toda_rulebook_class_order": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),

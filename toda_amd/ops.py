@@ -603,6 +603,44 @@ def gather_gemm(feat, wp, nbr, c_produce, bias=None, order=None):
     return out
 
 
+# x-run operand reuse for the 64 -> 64 / 32 -> 32 submanifold layers (gather_gemm_line_kernel): OPT-IN.  Bit-identical to the
+# per-offset kernel and 35-45 % fewer gathered rows, but SLOWER on every C3 level (round 4, same box, same run: 64 -> 64 @ 389 k rows
+# 0.616 against 0.578 ms, @ 117 k 0.250 against 0.208, 32 -> 32 @ 682 k 0.345 against 0.310; step 115.3 against 118.7 samples/s):
+# two operand sets (167 VGPRs: 3 waves per SIMD instead of 4) and a lane shift + select per operand register cost more than the
+# L2 -> L1 traffic they save - these kernels are not bound by gather bytes.
+LINE = _os.environ.get("TODA_GG_LINE", "0") == "1"
+
+
+def _line_route(c_gather, c_produce, rb, nbr):
+    return (LINE and rb.kind == "subm" and rb.k_vol == 27 and c_gather == c_produce and c_gather in (32, 64) and nbr.shape[1] >= 64
+            and all(int(d) == 1 for d in rb.geom.get("dilation", (1, 1, 1))))
+
+
+def gather_gemm_subm(feat, wp, nbr, c_produce, bias=None, stats=None):
+    """Gather-GEMM over a SUBMANIFOLD table (toda_spconv_gather_gemm_subm): forward, or the data gradient with the reversed operand.
+    stats: None | "fold" (returns (out, sums)) | "partials" (returns (out, sums, blocks) for toda_bn_finalize_partials)."""
+    lib = L.load()
+    K, n_out = nbr.shape
+    out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
+    if stats is None:
+        rc = lib.toda_spconv_gather_gemm_subm(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce, L.ptr(bias),
+                                              L.ptr(out), None, 0, None, L.stream())
+        L.check(rc, "toda_spconv_gather_gemm_subm")
+        return out
+    import ctypes
+    nd = lib.toda_spconv_gather_gemm_stats_doubles(n_out, c_produce)
+    sums = torch.empty((nd,), dtype=torch.float64, device=feat.device)
+    blocks = ctypes.c_int(0)
+    rc = lib.toda_spconv_gather_gemm_subm(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce, L.ptr(bias),
+                                          L.ptr(out), L.ptr(sums), nd, ctypes.addressof(blocks) if stats == "partials" else None, L.stream())
+    L.check(rc, "toda_spconv_gather_gemm_subm")
+    if stats == "partials":
+        if blocks.value <= 0:
+            raise RuntimeError("toda_spconv_gather_gemm_subm: the launch took no statistics")
+        return out, sums, int(blocks.value)
+    return out, sums
+
+
 # narrow K = 27 layers (conv_input, the 16-channel SubM level, the strided 16 -> 32 and its data gradient) by per-offset compaction:
 # measured on the C3 levels 5 -> 16 80 -> 42 us, 16 -> 16 70 -> 38, 16 -> 32 @ 682 k rows 141 -> 122, 32 -> 16 (dgrad) 69 -> 61
 COMPACT = _os.environ.get("TODA_GG_COMPACT", "1") == "1"
@@ -762,7 +800,15 @@ class _SparseConv(torch.autograd.Function):
             wp_fwd = pack_weight(weight, False, False)
         sums, blocks = None, 0
         plan = rb.halo.get(weight.shape[-1]) if (rb.kind == "subm" and weight.shape[0] == weight.shape[-1] and features.shape[0] == rb.n_out) else None
-        if compact and want_stats:
+        line = plan is None and not compact and features.shape[0] == rb.n_out and _line_route(features.shape[1], weight.shape[0], rb, rb.nbr_fwd)
+        if line and want_stats:
+            if FOLD_IN_FINALIZE:
+                out, sums, blocks = gather_gemm_subm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, stats="partials")
+            else:
+                out, sums = gather_gemm_subm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, stats="fold")
+        elif line:
+            out = gather_gemm_subm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
+        elif compact and want_stats:
             out, sums, blocks = gather_gemm_compact(features, weight.contiguous(), rb.nbr_fwd, weight.shape[0], bias, stats=True)
         elif plan is not None and want_stats:
             out, sums = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias, True)
@@ -814,6 +860,8 @@ class _SparseConv(torch.autograd.Function):
             co = rb.class_order()
             if ctx.halo_plan is not None:      # SubM: the forward table with the offsets reversed in wp_t - the same plan
                 gfeat = gather_gemm_halo(gout, wp_t, rb.nbr_bwd, weight.shape[-1], ctx.halo_plan)
+            elif gout.shape[0] == rb.n_out and _line_route(gout.shape[1], weight.shape[-1], rb, rb.nbr_bwd):
+                gfeat = gather_gemm_subm(gout, wp_t, rb.nbr_bwd, weight.shape[-1])
             elif co is not None:
                 gfeat = gather_gemm_classed(gout, wp_t, rb.nbr_bwd, weight.shape[-1], co[0], co[1], rb.ksize, rb.geom["stride"], rb.geom["padding"])
             else:

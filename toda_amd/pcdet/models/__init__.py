@@ -167,6 +167,33 @@ class InputPrefetcher:
         _record_stream(batch, main)
         return batch
 
+    def close(self):
+        """Stop the worker: a pending preparation is waited for and dropped (its side-stream work and pinned buffers would otherwise
+        stay alive until interpreter exit - one prefetcher per epoch and per evaluation).  Idempotent."""
+        pend, self.pending = self.pending, None
+        if self.pool is not None:
+            if pend is not None:
+                try:
+                    pend.result()
+                except Exception:       # the loop that owned this prefetcher is already unwinding
+                    pass
+            self.pool.shutdown(wait=True, cancel_futures=True)
+            self.pool = None
+        self.it = iter(())
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     @property
     def threaded(self):
         """True when kick() only hands the preparation to the worker thread: a caller may then kick right behind next() (the worker
@@ -313,13 +340,16 @@ def get_consistency_loss(adv_boxes, org_boxes):
             d2 = d2.masked_fill(~(va[:, None] & vo[None, :]), float("inf"))
             d_a, idx_o_of_a = d2.min(1)
             d_o, idx_a_of_o = d2.min(0)
-            m_o = ((d_a < 1) & va).float().unsqueeze(-1)
-            m_a = ((d_o < 1) & vo).float().unsqueeze(-1)
+            m_o = ((d_a < 1) & va).unsqueeze(-1)
+            m_a = ((d_o < 1) & vo).unsqueeze(-1)
             n = (va.sum() + vo.sum()).clamp(min=1).float()
-            centre_terms.append((((a[:, :3] - o[idx_o_of_a, :3]) * m_o).abs().sum()
-                                 + ((o[:, :3] - a[idx_a_of_o, :3]) * m_a).abs().sum()) / n)
-            size_terms.append(((F.mse_loss(o[idx_o_of_a, 3:6], a[:, 3:6], reduction="none") * m_o).sum()
-                               + (F.mse_loss(a[idx_a_of_o, 3:6], o[:, 3:6], reduction="none") * m_a).sum()) / n)
+            # unselected candidate rows are SELECTED away, not multiplied by zero: such a row may hold inf / nan (dim.exp() of a wild
+            # regression output) and 0 * inf is nan; the unpadded path drops these rows by boolean indexing
+            zero = a.new_zeros(())
+            centre_terms.append((torch.where(m_o, (a[:, :3] - o[idx_o_of_a, :3]).abs(), zero).sum()
+                                 + torch.where(m_a, (o[:, :3] - a[idx_a_of_o, :3]).abs(), zero).sum()) / n)
+            size_terms.append((torch.where(m_o, F.mse_loss(o[idx_o_of_a, 3:6], a[:, 3:6], reduction="none"), zero).sum()
+                               + torch.where(m_a, F.mse_loss(a[idx_a_of_o, 3:6], o[:, 3:6], reduction="none"), zero).sum()) / n)
             continue
         if a.shape[0] == 0 or o.shape[0] == 0:
             continue

@@ -131,6 +131,11 @@ class CenterHead(nn.Module):
             cache[key] = build().to(device)
         return cache[key]
 
+    def _device_const_like(self, key, ref, build):
+        """The same keyed on the dtype of `ref` as well (a head used in fp64 and then in fp32 must not hand the fp64 constant to the
+        fp32 loss: the product would silently promote - ADVICE r3)."""
+        return self._device_const((key, str(ref.dtype)), ref.device, build)
+
     def assign_targets(self, gt_boxes, feature_map_size=None, **kwargs):
         """gt_boxes [B, G, code+1]; feature_map_size (H, W).  Returns the reference's dict of
         per-head lists: heatmaps [B,C,H,W], target_boxes [B,500,code], inds, masks [B,500] int64."""
@@ -177,7 +182,7 @@ class CenterHead(nn.Module):
             pred_boxes = torch.cat([pred[name] for name in self.separate_head_cfg.HEAD_ORDER], dim=1)
             reg = self.reg_loss_func(pred_boxes, target_dicts["masks"][idx], target_dicts["inds"][idx],
                                      target_dicts["target_boxes"][idx])
-            loc_loss = (reg * self._device_const("code_weights", reg.device, lambda: torch.tensor(weights["code_weights"], dtype=reg.dtype))).sum() * weights["loc_weight"]
+            loc_loss = (reg * self._device_const_like("code_weights", reg, lambda: torch.tensor(weights["code_weights"], dtype=reg.dtype))).sum() * weights["loc_weight"]
             loss = loss + hm_loss + loc_loss
             tb_dict[f"hm_loss_head_{idx}"] = hm_loss.detach()
             tb_dict[f"loc_loss_head_{idx}"] = loc_loss.detach()

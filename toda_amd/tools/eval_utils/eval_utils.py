@@ -32,18 +32,21 @@ def run_inference(model, dataloader, on_batch=None):
         from toda_amd.pcdet.models import InputPrefetcher
         with torch.no_grad():
             pre = InputPrefetcher(iter(dataloader), net, first.device, eager=False, voxel_cfg=getattr(dataset, "voxel_cfg", None))
-        while True:
-            try:
+        try:
+            while True:
+                try:
+                    with torch.no_grad():
+                        batch_dict = pre.next()
+                        if pre.threaded:
+                            pre.kick()       # the worker thread prepares the next batch while this one is enqueued and decoded
+                except StopIteration:
+                    return
                 with torch.no_grad():
-                    batch_dict = pre.next()
-                    if pre.threaded:
-                        pre.kick()       # the worker thread prepares the next batch while this one is enqueued and decoded
-            except StopIteration:
-                return
-            with torch.no_grad():
-                pred_dicts, ret_dict = model(batch_dict)
-                pre.kick()
-            yield batch_dict, pred_dicts, ret_dict
+                    pred_dicts, ret_dict = model(batch_dict)
+                    pre.kick()
+                yield batch_dict, pred_dicts, ret_dict
+        finally:
+            pre.close()                      # also when the consumer abandons the generator
     for batch_dict in dataloader:
         load_data_to_gpu(batch_dict)
         if "voxels" not in batch_dict and "points" in batch_dict:

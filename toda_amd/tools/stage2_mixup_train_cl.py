@@ -36,6 +36,16 @@ def train_one_epoch_cl(model, optimizer, loader, model_func, lr_scheduler, accum
         net = getattr(net, "onepass", net)
         if hasattr(net, "dataset"):
             prefetch = InputPrefetcher(source, net, first.device, eager=False)
+    try:
+        return _stage2_iterations(model, optimizer, model_func, lr_scheduler, accumulated_iter, optim_cfg, rank, logger, log_interval, dist_train,
+                                  n_iters, source, prefetch)
+    finally:
+        if prefetch is not None:
+            prefetch.close()
+
+
+def _stage2_iterations(model, optimizer, model_func, lr_scheduler, accumulated_iter, optim_cfg, rank, logger, log_interval, dist_train, n_iters,
+                       source, prefetch):
     for it in range(n_iters):
         adv, org = prefetch.next() if prefetch is not None else next(source)
         lr_scheduler.step(accumulated_iter)

@@ -109,7 +109,17 @@ class OneCycleAdam:
         (tools/train_utils/train_utils.py:57-58); returns the total gradient norm (a 0-d tensor).  On one GPU with fp32 contiguous
         tensors both run inside toda_clip_adam_step (the state stays torch.optim.Adam's: exp_avg, exp_avg_sq, step - checkpoints
         are interchangeable with the torch path, which is what runs otherwise)."""
-        params = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None]
+        every = [p for g in self.opt.param_groups for p in g["params"] if p.requires_grad]
+        params = [p for p in every if p.grad is not None]
+        if len(params) != len(every):
+            # a parameter without a gradient this step: the reference's wrapper (OptimWrapper.step) still DECAYS it and Adam leaves its
+            # moments and step counter alone - per-parameter behaviour the two-launch kernel (one step count, one table) does not
+            # model.  The torch path does exactly that (ADVICE r3).
+            self._sync_steps()
+            self._hip_cache = {}
+            total = clip_grad_norm_(params, max_norm) if max_norm is not None and max_norm > 0 and params else None
+            self.step()
+            return total
         key = tuple(map(id, params))
         c = self._hip_cache
         # (the per-tensor checks and the table of parameter / moment addresses are made once per parameter set: at ~150 tensors they
@@ -161,7 +171,16 @@ class OneCycleAdam:
             for h in c["host"]:       # parameters and moments do not move: rows 0, 2, 3 of every staging copy are written once
                 t = h.numpy()
                 t[0, :], t[2, :], t[3, :] = fixed
-            c["count"] = int(c["steps"][0].item())      # first step / resumed from a checkpoint: one read of the device counter
+            # first step / resumed from a checkpoint: ONE read of the device counters.  The kernel applies one bias correction to every
+            # tensor, so the counters must agree (they differ when a parameter sat out earlier steps on the torch path): otherwise
+            # this parameter set stays on the torch path for good.
+            counts = torch.stack([t.reshape(()).float() for t in c["steps"]])
+            lo, hi = (float(v) for v in torch.stack([counts.min(), counts.max()]).tolist())
+            if lo != hi:
+                c.clear()
+                self._hip_step = False
+                return self.clip_and_step(max_norm)
+            c["count"] = int(lo)
         # a staging copy whose upload has executed (the host may be several steps ahead of the GPU: never wait here, grow the pool)
         turn = next((i for i, ev in enumerate(c["host_done"]) if ev is None or ev.query()), None)
         if turn is None:

@@ -58,6 +58,16 @@ def train_one_epoch(model, optimizer, train_loader, model_func, lr_scheduler, ac
         if total_epoch:
             train_loader.dataset.train_percent = (cur_epoch * total_it_each_epoch + it) / (total_epoch * total_it_each_epoch)
 
+    try:
+        return _train_iterations(model, optimizer, train_loader, model_func, lr_scheduler, accumulated_iter, optim_cfg, rank, tbar, total_it_each_epoch,
+                                 tb_log, logger, log_interval, prefetch, _next_host_batch, _progress, data_time, forward_time, batch_time, disp_dict)
+    finally:
+        if prefetch is not None:
+            prefetch.close()       # the worker thread, its side-stream work and its arena slots end with the epoch
+
+
+def _train_iterations(model, optimizer, train_loader, model_func, lr_scheduler, accumulated_iter, optim_cfg, rank, tbar, total_it_each_epoch,
+                      tb_log, logger, log_interval, prefetch, _next_host_batch, _progress, data_time, forward_time, batch_time, disp_dict):
     for cur_it in range(total_it_each_epoch):
         end = time.time()
         if cur_it == 0 or prefetch is None:

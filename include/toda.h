@@ -48,6 +48,11 @@ extern "C" {
 const char* toda_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int toda_abi_version(void);
+/* 1 when the library was built with the opt-in kernel variants (make VARIANTS=1: halo tiles, dout-stationary wgrad, mask-sorted row
+ * order and the experiment kernels behind the TODA_GG_* knobs), 0 for the default build, in which the entry points of those families
+ * (toda_halo_*, toda_spconv_gather_gemm_halo, toda_spconv_wgrad_tiled*, toda_rulebook_row_order) report "not supported" /
+ * TODA_EINVAL.  No reference counterpart. */
+int toda_variants_built(void);
 /* Reads and clears the fault word (host-mapped memory: no device synchronisation).  TODA_OK, or TODA_EFAULT with the
  * kernels named in toda_last_error().  toda_bn2d_* and toda_conv3x3_fwd poll it on entry as well, so a fault raised by
  * one launch is reported by the next call of that family at the latest; call it after a synchronisation point to learn

@@ -9,7 +9,7 @@ import torch
 
 from tests import helpers as H
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, H.needs_variants]
 
 
 def _level(shape, batch, npb, seed, clustered=True, c=64):

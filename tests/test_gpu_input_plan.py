@@ -223,6 +223,7 @@ def test_prefetcher_hands_out_arena_backed_batches_and_the_detector_trains_on_th
         assert torch.equal(g0, g1)
 
 
+@H.needs_variants
 @pytest.mark.parametrize("c", [32, 64])
 @pytest.mark.parametrize("canonical", [True, False])
 def test_line_kernel_is_bit_identical_to_the_per_offset_kernel(c, canonical):
@@ -271,6 +272,7 @@ def test_line_kernel_is_bit_identical_to_the_per_offset_kernel(c, canonical):
     np.testing.assert_allclose(folded.cpu().numpy(), s_ref[:2 * c].cpu().numpy(), rtol=1e-12)
 
 
+@H.needs_variants
 def test_sparse_conv_routes_submanifold_layers_to_the_line_kernel(monkeypatch):
     """The autograd operator: 64 -> 64 SubM layer forward (with statistics) and backward take toda_spconv_gather_gemm_subm, results
     identical to the route with TODA_GG_LINE off."""
@@ -298,6 +300,7 @@ def test_sparse_conv_routes_submanifold_layers_to_the_line_kernel(monkeypatch):
         assert torch.equal(a, b)
 
 
+@H.needs_variants
 def test_wide_kernel_with_half_slices_is_bit_identical(monkeypatch):
     """128 -> 128 (VoxelResBackBone8x stride-8 level, reference spconv_backbone.py:191-240): gather_gemm_wide_kernel (two 32 KiB half
     slices by LDS-DMA, double buffered) against gather_gemm_lds_kernel<8, 8, 1, .., 512> (one 64 KiB slice through registers): forward

@@ -311,9 +311,10 @@ def test_compacting_narrow_gather_gemm_matches_the_output_stationary_kernel(cg, 
     bias = dev(rng.standard_normal(cp).astype(np.float32))
     x = dev(feat)
     assert ops.gather_gemm_compact_supported(cg, cp, 27) and not ops.gather_gemm_compact_supported(cg, cp, 3) and not ops.gather_gemm_compact_supported(64, 16, 27)
-    ref = ops.gather_gemm(x, ops.pack_weight(w, False, False), rb.nbr_fwd, cp, bias)
     got = ops.gather_gemm_compact(x, w, rb.nbr_fwd, cp, bias)
-    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    if cg <= 16 or cg % 4 == 0:       # (the output-stationary kernel takes more than 16 gathered channels only in multiples of 4)
+        ref = ops.gather_gemm(x, ops.pack_weight(w, False, False), rb.nbr_fwd, cp, bias)
+        assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     assert torch.equal(ops.gather_gemm_compact(x, w, rb.nbr_fwd, cp, bias), got)
     # ... and the oracle itself (the kernel's ring loads are hand-counted inline asm: every instantiation <1|2, vec|dword> is pinned here)
     y0 = O.spconv_fwd(feat, w.cpu().numpy(), rb.nbr_fwd.cpu().numpy(), bias.cpu().numpy())
@@ -343,6 +344,7 @@ def test_compacting_narrow_gather_gemm_matches_the_output_stationary_kernel(cg, 
     assert torch.equal(got, bias.expand_as(got))
 
 
+@H.needs_variants
 @pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
 def test_dout_stationary_wgrad_matches_oracle(cin, cout):
     """toda_spconv_wgrad_tiled (wgrad_tile_kernel; opt-in, TODA_WG_TILE=1; K = 27, 32 / 64 channels: the output-gradient tile staged in
@@ -793,6 +795,7 @@ def test_full_size_waymo_cloud_properties():
     assert rb2.n_out == oi.shape[0]
 
 
+@H.needs_variants
 def test_mask_sorted_row_order_is_a_blockwise_permutation_and_changes_no_bit():
     """toda_rulebook_row_order: inside each block of 2048 canonical rows the rows are listed by ascending neighbour mask
     (ties in canonical order); gather-GEMM visiting rows in that order returns bit-identical output."""

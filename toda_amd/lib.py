@@ -18,6 +18,7 @@ _vp, _i, _sz, _dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_double
 SIGNATURES = {
     "toda_last_error": (C.c_char_p, []),
     "toda_abi_version": (_i, []),
+    "toda_variants_built": (_i, []),
     "toda_device_fault": (_i, []),
     "toda_voxelize_workspace_bytes": (_sz, [_i, _i]),
     "toda_voxelize_hard": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -147,6 +148,11 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def variants_built():
+    """True when libtoda_hip.so carries the opt-in kernel families (make -C toda_amd/csrc VARIANTS=1)."""
+    return bool(load().toda_variants_built())
 
 
 def last_error():

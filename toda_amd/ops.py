@@ -611,6 +611,21 @@ def gather_gemm(feat, wp, nbr, c_produce, bias=None, order=None):
 LINE = _os.environ.get("TODA_GG_LINE", "0") == "1"
 
 
+def _require_variants():
+    """The opt-in kernel families live in a library built with `make -C toda_amd/csrc VARIANTS=1`; asking for one of them through an
+    environment knob on the default library is an error, not a silent no-op."""
+    knobs = [k for k in ("TODA_GG_LINE", "TODA_HALO", "TODA_WG_TILE", "TODA_ROW_ORDER", "TODA_GG_WS", "TODA_GG_STAGE", "TODA_GG_WRES", "TODA_GG_LDS_PF",
+                         "TODA_GG_BLK512", "TODA_GG_RT") if _os.environ.get(k, "0") not in ("0", "")]
+    if _os.environ.get("TODA_GG_LDS88", "3") not in ("3", ""):
+        knobs.append("TODA_GG_LDS88")
+    if knobs and not L.variants_built():
+        raise RuntimeError(f"{', '.join(knobs)} select opt-in kernels that this libtoda_hip.so does not contain: "
+                           "rebuild with `make -C toda_amd/csrc VARIANTS=1`")
+
+
+_require_variants()
+
+
 def _line_route(c_gather, c_produce, rb, nbr):
     return (LINE and rb.kind == "subm" and rb.k_vol == 27 and c_gather == c_produce and c_gather in (32, 64) and nbr.shape[1] >= 64
             and all(int(d) == 1 for d in rb.geom.get("dilation", (1, 1, 1))))

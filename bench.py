@@ -445,8 +445,8 @@ def run_gpu(args, rank, world, device):
 
 # (gathered channels, produced channels, K) of a dominant launch shape -> (PMC summary under profiles/, kernel instantiation,
 # threads per output row of that instantiation, slack of the grid in threads)
-PMC_FILES = {(64, 64, 27): ("r03_pmc_gather_gemm_64x64.json", "<4, 4, 2", 2, 1024),        # C3: 64 lanes per 32-row tile
-             (128, 128, 27): ("r03_pmc_gather_gemm_128x128.json", "<8, 8, 1", 4, 2048)}   # C5: 512 threads per 128 rows
+PMC_FILES = {(64, 64, 27): ("r04_pmc_gather_gemm_64x64.json", "<4, 4, 2", 2, 1024),        # C3: 64 lanes per 32-row tile
+             (128, 128, 27): ("r04_pmc_gather_gemm_128x128.json", "<8, 8, 1", 4, 2048)}   # C5: 512 threads per 128 rows
 
 
 def _sha256(path):

@@ -139,12 +139,14 @@ int toda_gridindex_from_conv(const int32_t* idx_in, int n_in, const int32_t* n_i
                              int out_cap, void* stream);
 /* The same from the INPUT level's grid index instead of its coordinate list: output stationary (one thread per
  * 32-cell output word ORs the input rows that reach it), no atomics, no clearing of gi_out, two launches; the input
- * row count never enters, so the levels of a backbone chain without a host round trip. */
+ * row count never enters, so the levels of a backbone chain without a host round trip.  in_rows_marked != 0: gi_in was
+ * built by toda_gridindex_from_coords_unordered, which also keeps one byte per lattice row (b, z, y) - input rows without
+ * a site are then skipped after one byte load (the voxel level: most of its 123 k rows). */
 int toda_gridindex_from_bitmap(const void* gi_in, int batch, const int32_t* shape_in_host,
                                const int32_t* ksize_host, const int32_t* stride_host,
                                const int32_t* pad_host, const int32_t* shape_out_host,
                                void* gi_out, int32_t* idx_out, int32_t* n_out_dev,
-                               int out_cap, void* stream);
+                               int out_cap, int in_rows_marked, void* stream);
 
 /* Rulebook of spconv.SubMConv3d (spconv_backbone.py:12,78): out sites = in
  * sites.  nbr[k*n + o] = input row at o + (k - centre) * dilation or -1.

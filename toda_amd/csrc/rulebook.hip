@@ -19,7 +19,8 @@ struct GridDims {
 
 struct GiLayout {
     long long cells;   // number of 32-bit words
-    size_t o_cells, o_part, o_total, bytes;
+    long long rows;    // B * D * H lattice rows (x runs)
+    size_t o_cells, o_part, o_total, o_rows, bytes;
 };
 
 static GiLayout gi_layout(int batch, const int32_t* shape) {
@@ -33,6 +34,11 @@ static GiLayout gi_layout(int batch, const int32_t* shape) {
     o += align_up((size_t)(cdiv(l.cells, RB_BLOCK) + 1) * sizeof(int32_t), 256);      // 256-word tiles (>= the scan's 2048-word ones)
     l.o_total = o;
     o += 256;
+    // one byte per lattice row (b, z, y): "this row holds a site".  Kept by the O(sites) builder of the voxel level (mark / clear);
+    // toda_gridindex_from_bitmap skips the input rows whose byte is zero (most of them at the voxel level: 123 k rows, 46 MB of words)
+    l.rows = (long long)batch * shape[0] * shape[1];
+    l.o_rows = o;
+    o += align_up((size_t)l.rows, 256);
     l.bytes = o;
     return l;
 }
@@ -157,7 +163,8 @@ gi_decode_kernel(const uint2* __restrict__ cells, long long n_cells, GridDims g,
 // so neither a memset nor a scan ever sweeps the lattice.  cell.y = first rank of the word, exactly what gi_rank reads.
 __global__ void __launch_bounds__(RB_BLOCK)
 gi_mark_first_kernel(const int4* __restrict__ idx, int n, const int32_t* __restrict__ n_dev, GridDims g,
-                     uint2* __restrict__ cells, int* __restrict__ first, int32_t* __restrict__ counter) {
+                     uint2* __restrict__ cells, unsigned char* __restrict__ rowmask, int* __restrict__ first,
+                     int32_t* __restrict__ counter) {
     n = eff_n(n, n_dev);
     const int i = blockIdx.x * RB_BLOCK + threadIdx.x;
     if (i == 0) *counter = 0;
@@ -168,6 +175,7 @@ gi_mark_first_kernel(const int4* __restrict__ idx, int n, const int32_t* __restr
         const long long lin = lin_index(c.x, c.y, c.z, c.w, g);
         const unsigned bit = 1u << (lin & 31);
         mine = (atomicOr(&cells[lin >> 5].x, bit) & bit) ? 0 : 1;      // exactly one of several rows with the same coordinate
+        rowmask[((long long)c.x * g.D + c.y) * g.H + c.z] = 1;          // plain store: every writer stores the same value
     }
     first[i] = mine;
 }
@@ -215,6 +223,7 @@ struct ClearLevel {
     const int4* idx;
     const int32_t* n_dev;
     uint2* cells;
+    unsigned char* rowmask;
     GridDims g;
     int n;
 };
@@ -232,6 +241,7 @@ __global__ void __launch_bounds__(RB_BLOCK) gi_clear_kernel(ClearArgs a) {
     const int4 c = l.idx[i];
     if (!in_grid(c, l.g)) return;
     l.cells[lin_index(c.x, c.y, c.z, c.w, l.g) >> 5] = make_uint2(0u, 0u);
+    l.rowmask[((long long)c.x * l.g.D + c.y) * l.g.H + c.z] = 0;
 }
 
 // ---- round 4: output set of a strided convolution from the input BITMAP, no atomics ---------------------------------------
@@ -256,8 +266,8 @@ __device__ __forceinline__ unsigned bits32_at(const uint2* __restrict__ cells, l
 constexpr int CONV_WIN = 4;      // 32-bit windows per input row segment: (count - 1) * sx + KX <= 128 bits
 
 __global__ void __launch_bounds__(RB_BLOCK)
-gi_conv_bits_kernel(const uint2* __restrict__ cells_in, GridDims gin, ConvGeom cg, uint2* __restrict__ cells_out,
-                    long long n_cells_out, int32_t* __restrict__ partials) {
+gi_conv_bits_kernel(const uint2* __restrict__ cells_in, const unsigned char* __restrict__ rowmask_in, GridDims gin, ConvGeom cg,
+                    uint2* __restrict__ cells_out, long long n_cells_out, int32_t* __restrict__ partials) {
     const long long w = (long long)blockIdx.x * RB_BLOCK + threadIdx.x;
     const GridDims go = cg.out;
     const long long total_bits = (long long)go.B * go.D * go.H * go.W;
@@ -296,7 +306,9 @@ gi_conv_bits_kernel(const uint2* __restrict__ cells_in, GridDims gin, ConvGeom c
                 for (int ky = 0; ky < cg.ks[1]; ++ky) {
                     const int yi = yo * cg.st[1] - cg.pd[1] + ky;
                     if ((unsigned)yi >= (unsigned)gin.H) continue;
-                    const long long row = (((long long)b * gin.D + zi) * gin.H + yi) * gin.W;
+                    const long long rix = ((long long)b * gin.D + zi) * gin.H + yi;
+                    if (rowmask_in && !rowmask_in[rix]) continue;       // an input row without a site (one byte instead of up to 8 words)
+                    const long long row = rix * gin.W;
 #pragma unroll
                     for (int q = 0; q < CONV_WIN; ++q)
                         if (q < nwin) win[q] |= bits32_at(cells_in, row + xi0 + 32 * q, row, row + gin.W);
@@ -658,12 +670,16 @@ extern "C" int toda_gridindex_from_coords_unordered(const int32_t* idx, int n, c
     char* b = (char*)gi;
     uint2* cells = (uint2*)(b + l.o_cells);
     int32_t* counter = (int32_t*)(b + l.o_total);
-    if (!gi_clean) TODA_HIP(hipMemsetAsync(cells, 0, (size_t)l.cells * sizeof(uint2), s));
+    unsigned char* rowmask = (unsigned char*)(b + l.o_rows);
+    if (!gi_clean) {
+        TODA_HIP(hipMemsetAsync(cells, 0, (size_t)l.cells * sizeof(uint2), s));
+        TODA_HIP(hipMemsetAsync(rowmask, 0, (size_t)l.rows, s));
+    }
     if (n == 0) return TODA_OK;
     const GridDims g{batch, shape_host[0], shape_host[1], shape_host[2]};
     const dim3 grid(cdiv(n, RB_BLOCK)), block(RB_BLOCK);
     // rowof doubles as the "this row set its bit first" flags between mark and alloc (rowof[rank] = row is written last)
-    hipLaunchKernelGGL(gi_mark_first_kernel, grid, block, 0, s, (const int4*)idx, n, n_dev, g, cells, rowof, counter);
+    hipLaunchKernelGGL(gi_mark_first_kernel, grid, block, 0, s, (const int4*)idx, n, n_dev, g, cells, rowmask, rowof, counter);
     hipLaunchKernelGGL(gi_alloc_kernel, dim3(cdiv(n, GA_BLOCK)), dim3(GA_BLOCK), 0, s, (const int4*)idx, n, n_dev, g, cells, (const int*)rowof,
                        counter);
     hipLaunchKernelGGL(gi_rowof_kernel, grid, block, 0, s, (const int4*)idx, n, n_dev, g, cells, rowof);
@@ -682,6 +698,7 @@ extern "C" int toda_gridindex_clear(const int32_t* idx, int n, const int32_t* n_
     a.lv[0].idx = (const int4*)idx;
     a.lv[0].n_dev = n_dev;
     a.lv[0].cells = (uint2*)((char*)gi + l.o_cells);
+    a.lv[0].rowmask = (unsigned char*)gi + l.o_rows;
     a.lv[0].g = GridDims{batch, shape_host[0], shape_host[1], shape_host[2]};
     a.lv[0].n = n;
     hipLaunchKernelGGL(gi_clear_kernel, dim3(cdiv(n, RB_BLOCK), 1), dim3(RB_BLOCK), 0, (hipStream_t)stream, a);
@@ -735,7 +752,7 @@ extern "C" int toda_gridindex_from_conv(const int32_t* idx_in, int n_in, const i
 extern "C" int toda_gridindex_from_bitmap(const void* gi_in, int batch, const int32_t* shape_in_host,
                                           const int32_t* ksize_host, const int32_t* stride_host, const int32_t* pad_host,
                                           const int32_t* shape_out_host, void* gi_out, int32_t* idx_out, int32_t* n_out_dev,
-                                          int out_cap, void* stream) {
+                                          int out_cap, int in_rows_marked, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int rc = check_geom("gridindex_from_bitmap", batch, shape_out_host);
     if (rc) return rc;
@@ -755,7 +772,8 @@ extern "C" int toda_gridindex_from_bitmap(const void* gi_in, int batch, const in
     int32_t* total = (int32_t*)(b + lo.o_total);
     const GridDims gin{batch, shape_in_host[0], shape_in_host[1], shape_in_host[2]};
     const int nb = cdiv(lo.cells, RB_BLOCK);
-    hipLaunchKernelGGL(gi_conv_bits_kernel, dim3(nb), dim3(RB_BLOCK), 0, s, cells_in, gin, cg, cells, lo.cells, part);
+    const unsigned char* rowmask_in = in_rows_marked ? (const unsigned char*)gi_in + li.o_rows : nullptr;
+    hipLaunchKernelGGL(gi_conv_bits_kernel, dim3(nb), dim3(RB_BLOCK), 0, s, cells_in, rowmask_in, gin, cg, cells, lo.cells, part);
     hipLaunchKernelGGL(gi_scan_decode_kernel, dim3(nb), dim3(RB_BLOCK), 0, s, cells, lo.cells, (const int32_t*)part, cg.out,
                        (int4*)idx_out, out_cap, total, n_out_dev);
     TODA_LAUNCH_CHECK();

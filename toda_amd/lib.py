@@ -33,7 +33,7 @@ SIGNATURES = {
     "toda_voxelize_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "toda_gridindex_from_coords_unordered": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "toda_gridindex_clear": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
-    "toda_gridindex_from_bitmap": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "toda_gridindex_from_bitmap": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "toda_spconv_packed_weight_floats": (_sz, [_i, _i, _i]),
     "toda_spconv_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "toda_spconv_pack_weights": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -425,7 +425,7 @@ def _plan_enqueue(level0, batch, shape, steps, counts, c0, gi0=None):
         hs = [L.host_i32(v) for v in (cur["shape"], ks, sd, pd, out_shape)]
         rc = lib.toda_gridindex_from_bitmap(L.ptr(cur["gi"].buf), int(batch), L.hptr(hs[0]), L.hptr(hs[1]), L.hptr(hs[2]), L.hptr(hs[3]),
                                             L.hptr(hs[4]), L.ptr(gi_out.buf), L.ptr(idx_out), counts.data_ptr() + 4 * (c0 + li - 1),
-                                            cap, L.stream())
+                                            cap, 1 if li == 1 else 0, L.stream())      # the voxel level's index carries row marks
         L.check(rc, "toda_gridindex_from_bitmap")
         levels.append({"idx": idx_out, "n_upper": cap, "shape": out_shape, "gi": gi_out, "cap": cap, "step": st})
     if slot is not None:

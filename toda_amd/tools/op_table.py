@@ -154,7 +154,7 @@ class OpTable:
     @classmethod
     def _c_toda_gridindex_from_bitmap(cls, a):
         batch = a[1]
-        di, do = cls._host_i32(a[2], 3), cls._host_i32(a[6], 3)
+        di, do = cls._host_i32(a[2], 3), cls._host_i32(a[6], 3)      # (a[11]: the input rows are marked)
         ci, co = batch * di[0] * di[1] * di[2] / 32.0, batch * do[0] * do[1] * do[2] / 32.0
         return (batch, *do), ("fixed", 8.0 * ci + 8.0 * co, 0.0, "one pass over the input bitmap's and the output bitmap's 8-byte words (output rows not counted)")
 

@@ -285,7 +285,38 @@ def run_gpu(args, rank, world, device):
 
         prefetch = InputPrefetcher(batch_stream(), net, device)
 
+    # experiments (not a workload): TODA_BENCH_REUSE_BATCH=1 prepares ONE batch and trains on it every step (no input pipeline at all);
+    # TODA_BENCH_THROTTLE=k holds the host at most k steps ahead of the GPU (host-side wait for the end of step t - k)
+    reuse = None
+    throttle = int(os.environ.get("TODA_BENCH_THROTTLE", "0"))
+    step_done = []
+    if os.environ.get("TODA_BENCH_REUSE_BATCH") == "1" and not pair and not mixed and not fwd_only:
+        from toda_amd.pcdet.models import prepare_batch_on_gpu
+        if prefetch is not None:
+            prefetch.close()
+            prefetch = None
+        with torch.no_grad():
+            reuse = prepare_batch_on_gpu(dict(batches[0]), net, dataset.voxel_cfg)
+        torch.cuda.synchronize()
+
     def step(it):
+        if throttle:
+            if len(step_done) >= throttle:
+                step_done[-throttle].synchronize()
+        if reuse is not None:
+            scheduler.step(it)
+            optimizer.zero_grad()
+            ret, tb, _ = model(dict(reuse))
+            loss = ret["loss"].mean()
+            loss.backward()
+            clip_and_step(optimizer, params, clip)
+            net.update_global_step()
+            if throttle:
+                ev = torch.cuda.Event()
+                ev.record()
+                step_done.append(ev)
+                del step_done[:-8]
+            return loss
         if fwd_only:  # BASELINE config 2: inference through the sparse backbone only
             with torch.no_grad():
                 if prefetch is not None:
@@ -393,6 +424,11 @@ def run_gpu(args, rank, world, device):
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if prefetch is not None and getattr(prefetch, "arena", None) is not None and rank == 0 and os.environ.get("TODA_BENCH_STEP_MS"):
+        print(f"[arena] slots {len(prefetch.arena.slots)}, waits for a free slot {prefetch.arena.waits}, buffers allocated {prefetch.arena.grown}", file=sys.stderr)
+    if prefetch is not None and getattr(prefetch, "_trace", None) and rank == 0:
+        tr = prefetch._trace[-args.steps:]
+        print("[prefetch] preparation wall ms (of which waiting for the counts): " + " ".join(f"{a * 1e3:.1f}({b * 1e3:.1f})" for a, b in tr), file=sys.stderr)
     if phases is not None and rank == 0:
         print("[host phases, ms per step] " + ", ".join(f"{k} {v / args.steps * 1e3:.2f}" for k, v in phases.items()), file=sys.stderr)
     final_loss = float(loss.item())

@@ -26,6 +26,12 @@ for w in c2 c5 c5mix c5cl; do
 done
 timeout -k 10 400 python bench.py --workload c5 --steps 20 --warmup 8 --no-cpu-baseline --layers --layers-out $O/r04_layers_c5.json > /dev/null 2> $O/r04_layers_c5.err
 timeout -k 10 400 python bench.py --steps 300 --warmup 40 --no-cpu-baseline > $O/r04_soak_c3.json 2> $O/r04_soak_c3.err
+# what the overlapped input pipeline costs / buys: no prefetch at all (voxelise + plan on the training stream, its host sync included),
+# two and five arena slots instead of three
+TODA_PREFETCH=0 timeout -k 10 400 python bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/r04_bench_c3_noprefetch.json 2> $O/r04_bench_c3_noprefetch.err
+TODA_PREFETCH_SLOTS=2 timeout -k 10 400 python bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/r04_bench_c3_slots2.json 2> $O/r04_bench_c3_slots2.err
+TODA_PREFETCH_SLOTS=5 timeout -k 10 400 python bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/r04_bench_c3_slots5.json 2> $O/r04_bench_c3_slots5.err
+TODA_PREFETCH_ARENA=0 timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/r04_bench_c3_noarena.json 2> $O/r04_bench_c3_noarena.err
 unset TODA_BENCH_STEP_MS
 fi
 if [ "$PART" = "counters" ] || [ "$PART" = "all" ]; then

@@ -53,6 +53,7 @@ class ArenaSlot:
         self.free_event = None      # training-stream event behind the last consumer of this slot
         self.grown = 0              # chunks / persistent buffers allocated so far (steady state: stops changing)
         self.plans = 0              # plans built into this slot since reset() (a stage-2 pair holds two)
+        self.in_use = False         # handed to a consumer and not yet released
 
     def reset(self):
         """Start of a new use.  The clean-up kernels of the previous use (un-marking the voxel level's bitmap from the coordinate
@@ -101,28 +102,87 @@ class ArenaSlot:
 
 
 class IndexArena:
-    """Round-robin slots for the batches an input pipeline has in flight (being prepared, prepared, being consumed)."""
+    """Slots for the batches an input pipeline has in flight (being prepared, prepared, being consumed).
 
-    def __init__(self, device, slots=3):
-        self.slots = [ArenaSlot(device) for _ in range(int(slots))]
+    A slot is re-used when the event behind its last consumer has COMPLETED.  The check is made on the host (`Event.query`, by the
+    pipeline's worker thread): with every slot in flight the worker sleeps until the oldest one is released and only then enqueues
+    the next batch's index kernels, so the pipeline prepares one batch per GPU step, stays `slots - 2` steps ahead, and neither
+    stream ever waits for the other on the GPU (`host_wait=False`: `stream.wait_event` instead).  `slots < max_slots`: grow instead of
+    waiting.  After the first batch the other slots are laid out like the first (`prewarm`), so nothing is allocated once the first
+    preparation is over."""
+
+    def __init__(self, device, slots=4, max_slots=None, host_wait=True):
+        self.device = torch.device(device)
+        self.host_wait = bool(host_wait)
+        max_slots = slots if max_slots is None else max_slots
+        self.slots = [ArenaSlot(device) for _ in range(max(2, int(slots)))]
+        self.max_slots = max(int(max_slots), len(self.slots))
         self.turn = 0
+        self.waits = 0              # acquisitions that had to wait on the stream (max_slots reached)
+        self._warm = False
 
     def acquire(self, stream):
-        """Next slot; `stream` (the side stream the slot is about to be written on) waits for its last consumer."""
-        slot = self.slots[self.turn % len(self.slots)]
-        self.turn += 1
-        if slot.free_event is not None:
-            stream.wait_event(slot.free_event)
-        slot.reset()
-        return slot
+        """A slot whose last consumer has finished (host-side check), else a new one; `stream` is the side stream it will be written on."""
+        n = len(self.slots)
+        pick = None
+        for k in range(n):
+            slot = self.slots[(self.turn + k) % n]
+            if not slot.in_use and (slot.free_event is None or slot.free_event.query()):
+                pick = slot
+                self.turn = (self.turn + k + 1) % n
+                break
+        if pick is None and n < self.max_slots:
+            pick = ArenaSlot(self.device)
+            self.slots.append(pick)
+            if self._warm:
+                self._clone_layout(self.slots[0], pick)
+        if pick is None:
+            # every slot is in flight and the arena is at its bound: wait for the OLDEST release - on the host (poll + sleep; this is the
+            # input pipeline's worker thread), so that the index kernels are enqueued only when they can run: the pipeline then prepares one
+            # batch per GPU step and stays `max_slots - 2` steps ahead, with no queue-to-queue dependency on the GPU
+            import time as _t
+            cands = [sl for sl in self.slots if not sl.in_use and sl.free_event is not None] or [sl for sl in self.slots if not sl.in_use]
+            pick = cands[self.turn % len(cands)]
+            self.turn = (self.turn + 1) % n
+            if pick.free_event is not None:
+                if self.host_wait:
+                    while not pick.free_event.query():
+                        _t.sleep(5e-5)
+                else:
+                    stream.wait_event(pick.free_event)
+            self.waits += 1
+        pick.in_use = True          # until release(): a slot that is being prepared or consumed has no event to be judged by
+        pick.reset()
+        return pick
 
-    @staticmethod
-    def release(slot, stream):
+    def release(self, slot, stream):
         """Everything that reads `slot` has been enqueued on `stream`."""
         ev = slot.free_event
         if ev is None:
             ev = slot.free_event = torch.cuda.Event()
         ev.record(stream)
+        slot.in_use = False
+
+    def prewarm(self):
+        """Lay every other slot out like the first one (chunk sizes, persistent buffers): called once, behind the first preparation."""
+        if self._warm or not self.slots[0].chunks:
+            return
+        self._warm = True
+        for slot in self.slots[1:]:
+            if not slot.chunks:
+                self._clone_layout(self.slots[0], slot)
+
+    @staticmethod
+    def _clone_layout(src, dst):
+        for ch in src.chunks:
+            dst.chunks.append(torch.empty_like(ch))
+            dst.grown += 1
+        for name, (meta, buf) in src.persist.items():
+            # contents included: the voxeliser's hash table is in its clean state (every call leaves it so); a bitmap that carries marks
+            # is not in dst.clean, so its first build clears it
+            dst.persist[name] = (meta, buf.clone())
+            dst.grown += 1
+        dst.state.update({k: v for k, v in src.state.items()})
 
     @property
     def grown(self):

@@ -28,6 +28,7 @@ import os as _os_early
 import time as _time
 
 _COUNT_PINNED = {}
+_LAST_WAIT_S = 0.0
 
 
 def read_counts(counts_dev, while_waiting=None):
@@ -52,8 +53,11 @@ def read_counts(counts_dev, while_waiting=None):
     if side:
         # hipEventSynchronize spins even on a "blocking" event here (the thread's CPU time did not move): poll and sleep instead.
         # The wait sits under a whole backward pass, 50 us of granularity cost nothing.
+        global _LAST_WAIT_S
+        t_w = _time.perf_counter()
         while not ev.query():
             _time.sleep(5e-5)
+        _LAST_WAIT_S = _time.perf_counter() - t_w
     else:
         ev.synchronize()
     vals = host.tolist()

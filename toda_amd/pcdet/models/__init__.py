@@ -108,13 +108,24 @@ class InputPrefetcher:
         # older than this point.
         self.side.wait_stream(torch.cuda.current_stream(device))
         self.pending = None
-        # Device memory of the prepared batches: rotating arena slots (toda_amd.arena) instead of the caching allocator - what the
-        # side stream produces is consumed on the caller's stream a step later, the worst case for a stream-aware allocator (round 3:
-        # hipMalloc calls inside steady-state steps).  TODA_PREFETCH_ARENA=0 goes back to the allocator.
+        # Device memory of the prepared batches: arena slots (toda_amd.arena) instead of the caching allocator - what the side stream
+        # produces is consumed on the caller's stream a step later, the worst case for a stream-aware allocator (round 3: hipMalloc
+        # calls inside steady-state steps).  A slot is re-used when its last consumer has finished (host-side event query by the worker;
+        # neither stream waits for the other on the GPU).  TODA_PREFETCH_ARENA=0 goes back to the allocator.
         from ... import arena as _arena
         self._arena_mod = _arena
-        self.arena = _arena.IndexArena(device, int(os.environ.get("TODA_PREFETCH_SLOTS", "3"))) if os.environ.get("TODA_PREFETCH_ARENA", "1") == "1" else None
+        self.arena = None
+        if os.environ.get("TODA_PREFETCH_ARENA", "1") == "1":
+            n_slots = int(os.environ.get("TODA_PREFETCH_SLOTS", "4"))
+            self.arena = _arena.IndexArena(device, n_slots, int(os.environ.get("TODA_PREFETCH_MAX_SLOTS", n_slots)),
+                                           host_wait=os.environ.get("TODA_PREFETCH_STREAM_WAIT", "0") != "1")
         self._in_use = None          # slot of the batch the caller is consuming
+        # (Round 4 measured WHERE in the step the index kernels run - start of the forward, behind the sparse forward, at the start of the
+        # dense or sparse backward - and whether the side stream waits for the training stream on the GPU or the worker waits on the host:
+        # 16.87-16.99 ms per step everywhere.  A batch's ~0.5 ms of index kernels costs ~0.4 ms wherever it lands: the training stream
+        # leaves no idle capacity to hide it in - without any input pipeline the step is 16.4 ms.  DESIGN.md section 5.)
+        self._host_wait = os.environ.get("TODA_PREFETCH_HOST_WAIT", "1") == "1" and os.environ.get("TODA_PREFETCH_THREAD", "1") == "1"
+        self._trace = [] if os.environ.get("TODA_PREFETCH_TRACE") else None      # (seconds per preparation, of which waiting for the counts)
         # The preparation runs on a worker thread (TODA_PREFETCH_THREAD=0: on the caller's), so its two host syncs and its ~150
         # launches overlap the caller's own enqueueing instead of following it: the forward-only workload is host-bound otherwise
         # (69 launches of the backbone + 155 of the next batch's index plan per 3.2 ms of GPU work: 907 -> 1144 samples/s); the
@@ -128,6 +139,16 @@ class InputPrefetcher:
             self.kick()
 
     def _prepare(self):
+        import time as _t
+        t0 = _t.perf_counter()
+        try:
+            return self._prepare_inner()
+        finally:
+            if self._trace is not None:
+                from ... import ops as _ops
+                self._trace.append((_t.perf_counter() - t0, getattr(_ops, "_LAST_WAIT_S", 0.0)))
+
+    def _prepare_inner(self):
         if self.pool is not None:
             torch.cuda.set_device(self.device)       # the worker thread's own current device
         with torch.no_grad(), torch.cuda.stream(self.side):
@@ -141,8 +162,17 @@ class InputPrefetcher:
                     batch = tuple(prepare_batch_on_gpu(b, self.net, self.voxel_cfg) for b in batch)
                 else:
                     batch = prepare_batch_on_gpu(batch, self.net, self.voxel_cfg)
+            if self.arena is not None:
+                self.arena.prewarm()         # once: the other slots get the first one's layout (no device allocation after the warm-up steps)
             ev = torch.cuda.Event()
             ev.record(self.side)
+            if self._host_wait:
+                # hand the batch over only when its preparation has FINISHED on the GPU (poll + sleep: this is the worker thread, and the
+                # tables' kernels take a few hundred microseconds): next() then needs no stream-side wait, and the training stream's queue
+                # carries no cross-queue dependency at all
+                import time as _t
+                while not ev.query():
+                    _t.sleep(5e-5)
         return batch, ev, slot
 
     def kick(self):
@@ -163,7 +193,8 @@ class InputPrefetcher:
             # everything that reads the PREVIOUS batch (forward, backward, optimizer) has been enqueued on this stream by now
             self.arena.release(self._in_use, main)
         self._in_use = slot
-        main.wait_event(ev)
+        if not ev.query():
+            main.wait_event(ev)
         _record_stream(batch, main)
         return batch
 

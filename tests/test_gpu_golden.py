@@ -71,7 +71,9 @@ def test_bev_backbone_on_gpu_matches_reference():
     reference module's vectors (reference base_bev_backbone.py:81-112)."""
     from tests.test_golden_reference import check_bev_backbone
 
-    check_bev_backbone("cuda", tol=10.0)
+    # (no x10 any more - VERDICT r3 item 7: measured passing at the CPU tolerances themselves; the factor 2 is head-room for the torch /
+    # MIOpen convolutions this 8 / 16-channel fixture takes, whose algorithm choice - hence fp32 summation order - may differ by box)
+    check_bev_backbone("cuda", tol=2.0)
 
 
 def test_c1_pointpillar_chain_on_gpu_matches_reference():
@@ -80,7 +82,7 @@ def test_c1_pointpillar_chain_on_gpu_matches_reference():
     anchor_head_single.py:41-75, anchor_head_template.py:101-223, axis_aligned_target_assigner.py:36-210)."""
     from tests.test_golden_reference import check_c1_pointpillar_chain
 
-    check_c1_pointpillar_chain("cuda", tol=10.0)
+    check_c1_pointpillar_chain("cuda", tol=2.0)      # as above: passes at 1.0; the dense part of this chain runs on torch / MIOpen
 
 
 def test_anchor_head_losses_on_gpu_match_reference():

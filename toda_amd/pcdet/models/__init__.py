@@ -116,7 +116,7 @@ class InputPrefetcher:
         self._arena_mod = _arena
         self.arena = None
         if os.environ.get("TODA_PREFETCH_ARENA", "1") == "1":
-            n_slots = int(os.environ.get("TODA_PREFETCH_SLOTS", "4"))
+            n_slots = int(os.environ.get("TODA_PREFETCH_SLOTS", "2"))
             self.arena = _arena.IndexArena(device, n_slots, int(os.environ.get("TODA_PREFETCH_MAX_SLOTS", n_slots)),
                                            host_wait=os.environ.get("TODA_PREFETCH_STREAM_WAIT", "0") != "1")
         self._in_use = None          # slot of the batch the caller is consuming

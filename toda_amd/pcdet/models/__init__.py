@@ -125,6 +125,20 @@ class InputPrefetcher:
         # 16.87-16.99 ms per step everywhere.  A batch's ~0.5 ms of index kernels costs ~0.4 ms wherever it lands: the training stream
         # leaves no idle capacity to hide it in - without any input pipeline the step is 16.4 ms.  DESIGN.md section 5.)
         self._host_wait = os.environ.get("TODA_PREFETCH_HOST_WAIT", "1") == "1" and os.environ.get("TODA_PREFETCH_THREAD", "1") == "1"
+        # Phase of the index kernels inside the consumer's step: with two slots a preparation starts when a step ends, i.e. it lands
+        # under the next step's sparse forward - on the C3 step right on the dominant 64 -> 64 gather-GEMMs (0.605 instead of 0.58 ms per
+        # launch).  The worker therefore also waits (on the host) until the training stream has passed the sparse backbone's forward of
+        # the step in flight: an event recorded by a forward hook on backbone_3d.  The index kernels then run beside the dense neck.
+        self._fwd_done = None
+        self._phase_hook = None
+        bb = getattr(net, "backbone_3d", None)
+        if os.environ.get("TODA_PREFETCH_PHASE", "1") == "1" and self.arena is not None and self._host_wait and bb is not None:
+            def _mark(_m, _a, _out):
+                if torch.is_grad_enabled():      # training steps only (the forward-only loops have no slack to wait in)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    self._fwd_done = ev
+            self._phase_hook = bb.register_forward_hook(_mark)
         self._trace = [] if os.environ.get("TODA_PREFETCH_TRACE") else None      # (seconds per preparation, of which waiting for the counts)
         # The preparation runs on a worker thread (TODA_PREFETCH_THREAD=0: on the caller's), so its two host syncs and its ~150
         # launches overlap the caller's own enqueueing instead of following it: the forward-only workload is host-bound otherwise
@@ -156,7 +170,12 @@ class InputPrefetcher:
                 batch = next(self.it)        # inside the side-stream context: a source that mixes / collates on the device runs there too
             except StopIteration:
                 return None
-            slot = self.arena.acquire(self.side) if self.arena is not None else None      # the side stream waits for the slot's last consumer
+            slot = self.arena.acquire(self.side) if self.arena is not None else None      # (waits on the host for a free slot)
+            gate = self._fwd_done
+            if gate is not None and slot is not None:
+                import time as _t
+                while not gate.query():
+                    _t.sleep(5e-5)
             with self._arena_mod.use_slot(slot):
                 if isinstance(batch, (tuple, list)):      # the (adversarial, original) pair of the stage-2 consistency step
                     batch = tuple(prepare_batch_on_gpu(b, self.net, self.voxel_cfg) for b in batch)
@@ -202,6 +221,9 @@ class InputPrefetcher:
         """Stop the worker: a pending preparation is waited for and dropped (its side-stream work and pinned buffers would otherwise
         stay alive until interpreter exit - one prefetcher per epoch and per evaluation).  Idempotent."""
         pend, self.pending = self.pending, None
+        if self._phase_hook is not None:
+            self._phase_hook.remove()
+            self._phase_hook = None
         if self.pool is not None:
             if pend is not None:
                 try:

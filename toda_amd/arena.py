@@ -11,8 +11,9 @@ come out of DataLoader workers as host arrays (pcdet/datasets/processor/data_pro
 Here a prepared batch owns a SLOT: a few large chunks carved by bump allocation (exact sizes, known after the plan's one
 host round trip) plus named persistent buffers whose contents carry an invariant from one use to the next (the voxel
 level's bitmap is all zero, the voxeliser's hash table is empty).  Slots rotate; the only synchronisation is one event per
-slot: recorded on the training stream when the step that consumed the slot has been enqueued, waited for by the side stream
-before the slot is written again.  No allocator traffic in steady state, no record_stream."""
+slot: recorded on the training stream when the step that consumed the slot has been enqueued, queried on the host by the
+pipeline's worker thread (or, host_wait=False, waited for by the side stream) before the slot is written again.  No
+allocator traffic in steady state, no record_stream."""
 import threading
 
 import torch

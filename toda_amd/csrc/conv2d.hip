@@ -29,6 +29,10 @@
 
 #include "common.h"
 
+#ifndef TODA_VARIANTS
+#define TODA_VARIANTS 0
+#endif
+
 namespace toda {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -254,22 +258,81 @@ __device__ __forceinline__ void wn_bt2(const f32x2 (&d)[6], f32x2 (&v)[6]) {
     v[5] = wn_fma2(1.5f, b, wn_fma2(-2.0f, d[3], d[1] + d[5]));
 }
 
+// fp32 MFMAs and fp32 vector instructions run on the SAME lanes of a SIMD (matrix fp32 peak = packed vector fp32 peak; the ablation
+// of either kernel shows their times ADD): the transforms are not hidden behind the matrix work, every vector instruction counts.  So
+// the transforms are written on register PAIRS (v_pk_*_f32: two lanes' worth per issue slot): the column passes on two columns at a
+// time, the row passes inside one 6-vector with broadcast / negated halves (op_sel, neg_lo / neg_hi).
+__device__ __forceinline__ f32x2 w2_lo(f32x2 a) { return __builtin_shufflevector(a, a, 0, 0); }
+__device__ __forceinline__ f32x2 w2_hi(f32x2 a) { return __builtin_shufflevector(a, a, 1, 1); }
+__device__ __forceinline__ f32x2 w2_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// a pair of fp32 constants as the 64-bit scalar operand of a packed instruction
+#define W2_K(a_, b_) ((unsigned long long)__builtin_bit_cast(unsigned, (float)(a_)) | ((unsigned long long)__builtin_bit_cast(unsigned, (float)(b_)) << 32))
+#define W2_KK(a_) W2_K(a_, a_)
+// The packed instructions themselves: left alone the compiler splits a packed operation with a constant or a half-broadcast operand into
+// two single ones (an inline constant is free there), which is the wrong trade when every vector issue slot is taken from the MFMAs.
+__device__ __forceinline__ f32x2 w2_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 w2_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 w2_mul(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 w2_fmak(unsigned long long k, f32x2 a, f32x2 c) {       // k * a + c
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(k), "v"(a), "v"(c));
+    return d;
+}
+// B^T on two independent columns at once (wn_bt2 in packed instructions)
+__device__ __forceinline__ void w2_bt2(const f32x2 (&d)[6], f32x2 (&v)[6]) {
+    const f32x2 a = w2_sub(d[3], d[1]), b = w2_sub(d[4], d[2]);
+    v[0] = w2_fmak(W2_KK(1.5f), a, w2_fmak(W2_KK(-2.0f), d[2], w2_add(d[0], d[4])));
+    v[1] = w2_fmak(W2_KK(-2.5f), d[2], w2_fmak(W2_KK(0.5f), d[3], w2_add(d[1], d[4])));
+    v[2] = w2_fmak(W2_KK(2.5f), d[3], w2_fmak(W2_KK(0.5f), d[2], w2_sub(d[4], d[1])));
+    v[3] = w2_fmak(W2_KK(2.0f), a, b);
+    v[4] = w2_fmak(W2_KK(-0.5f), a, b);
+    v[5] = w2_fmak(W2_KK(1.5f), b, w2_fmak(W2_KK(-2.0f), d[3], w2_add(d[1], d[5])));
+}
+
+// Row pass of B^T d B on ONE row of the column-passed patch, p = (d1, d2), q = (d3, d4), e = (d0, d5):
+//   (a, b) = q - p;  (v3, v4) = (2, -.5) a + b;  (v1, v2) = (d4 + d1, d4 - d1) + (.5, 2.5) d3 + (-2.5, .5) d2;
+//   (v0, v5) = 1.5 (a, b) + e + (d4, d1) - 2 (d2, d3)          (the last two terms cross the pairs: four single instructions)
+// 6 packed + 4 single instructions instead of 16 single ones.
+__device__ __forceinline__ void wn_bt_row(f32x2 p, f32x2 q, f32x2 e, float (&v)[6]) {
+    f32x2 ab, v34, x, z, v12, w;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(ab) : "v"(q), "v"(p));
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(v34) : "s"(W2_K(2.0f, -0.5f)), "v"(ab));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(x) : "v"(q), "v"(p));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(z) : "v"(q), "s"(W2_K(0.5f, 2.5f)), "v"(x));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(v12) : "v"(p), "s"(W2_K(-2.5f, 0.5f)), "v"(z));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(w) : "s"(W2_K(1.5f, 1.5f)), "v"(ab), "v"(e));
+    v[0] = __builtin_fmaf(-2.0f, p[1], w[0] + q[1]);
+    v[1] = v12[0];
+    v[2] = v12[1];
+    v[3] = v34[0];
+    v[4] = v34[1];
+    v[5] = __builtin_fmaf(-2.0f, q[0], w[1] + p[0]);
+}
+
 // patch -> B^T d B, written to the A image slot of the thread's (group, tile row m, channel c)
 __device__ __forceinline__ void wn_input_transform_store(const Patch& d, float* __restrict__ dst) {
     f32x2 tp[6], tq[6], te[6];      // column pass: t[i][1..2], t[i][3..4], t[i][0 | 5]
-    wn_bt2(d.p, tp);
-    wn_bt2(d.q, tq);
-    wn_bt2(d.e, te);
+    w2_bt2(d.p, tp);
+    w2_bt2(d.q, tq);
+    w2_bt2(d.e, te);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        float v0, v1, v2, v3, v4, v5;
-        wn_bt(te[i][0], tp[i][0], tp[i][1], tq[i][0], tq[i][1], te[i][1], v0, v1, v2, v3, v4, v5);
-        dst[(i * 6 + 0) * WN_IMG] = v0;
-        dst[(i * 6 + 1) * WN_IMG] = v1;
-        dst[(i * 6 + 2) * WN_IMG] = v2;
-        dst[(i * 6 + 3) * WN_IMG] = v3;
-        dst[(i * 6 + 4) * WN_IMG] = v4;
-        dst[(i * 6 + 5) * WN_IMG] = v5;
+        float v[6];
+        wn_bt_row(tp[i], tq[i], te[i], v);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * WN_IMG] = v[j];
     }
 }
 
@@ -535,6 +598,7 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
                     } else {
                         WN_WAIT(f, 0);
                     }
+                    if (ablate & 8) continue;
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][0], fb[f][0], acc[f], 0, 0, 0);
                     acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][0], fb[f + 1][0], acc[f + 1], 0, 0, 0);
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][1], fb[f][1], acc[f], 0, 0, 0);
@@ -789,22 +853,42 @@ __device__ __forceinline__ void wn_load_dy(__amdgpu_buffer_rsrc_t rsrc, const Ti
         d.c[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (t.exists && y0 + i < g.H) ? (unsigned)(base + i * g.W) * 4u : WN_OOB, 0, 0));
 }
 
-// dY tile (4 x 4) -> A dY A^T
+// dY tile (4 x 4) -> A dY A^T, on register pairs: the column pass on the column pairs (0, 1) and (2, 3), each row of the row pass in
+// five packed instructions  (P = (y0, y1), Q = (y2, y3): (e, o) = P + Q; (m1, m2) = e -+ o; (m3, m4) = y0 + (.5, -2) y1 + (.25, 4) y2 +
+// (.125, -8) y3; m0 = y0, m5 = y3)
+__device__ __forceinline__ void wn_a_cols(const f32x2 (&y)[4], f32x2 (&m)[6]) {
+    const f32x2 e = w2_add(y[0], y[2]), o = w2_add(y[1], y[3]);
+    m[0] = y[0];
+    m[1] = w2_sub(e, o);
+    m[2] = w2_add(e, o);
+    m[3] = w2_fmak(W2_KK(0.125f), y[3], w2_fmak(W2_KK(0.25f), y[2], w2_fmak(W2_KK(0.5f), y[1], y[0])));
+    m[4] = w2_fmak(W2_KK(-8.0f), y[3], w2_fmak(W2_KK(4.0f), y[2], w2_fmak(W2_KK(-2.0f), y[1], y[0])));
+    m[5] = y[3];
+}
 __device__ __forceinline__ void wn_dy_transform_store(const DyRaw& d, float* __restrict__ dst) {
-    float m[6][4];        // column pass: A applied down the 4 rows of every column
+    f32x2 a[4], b[4], ma[6], mb[6];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        float y[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = (x >= 2 && d.tail) ? 0.0f : d.c[i][x];
-        wn_a(y[0], y[1], y[2], y[3], m[0][x], m[1][x], m[2][x], m[3][x], m[4][x], m[5][x]);
+    for (int i = 0; i < 4; ++i) {
+        a[i] = f32x2{d.c[i][0], d.c[i][1]};
+        b[i] = f32x2{d.tail ? 0.0f : d.c[i][2], d.tail ? 0.0f : d.c[i][3]};
     }
+    wn_a_cols(a, ma);
+    wn_a_cols(b, mb);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        float v[6];
-        wn_a(m[i][0], m[i][1], m[i][2], m[i][3], v[0], v[1], v[2], v[3], v[4], v[5]);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) dst[(i * 6 + j) * WN_IMG] = v[j];
+        const f32x2 P = ma[i], Q = mb[i];
+        const f32x2 eo = w2_add(P, Q);
+        f32x2 m12, u;
+        asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(m12) : "v"(eo));
+        asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(u) : "v"(P), "s"(W2_K(0.5f, -2.0f)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(u) : "v"(Q), "s"(W2_K(0.25f, 4.0f)));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(u) : "v"(Q), "s"(W2_K(0.125f, -8.0f)));
+        dst[(i * 6 + 0) * WN_IMG] = P[0];
+        dst[(i * 6 + 1) * WN_IMG] = m12[0];
+        dst[(i * 6 + 2) * WN_IMG] = m12[1];
+        dst[(i * 6 + 3) * WN_IMG] = u[0];
+        dst[(i * 6 + 4) * WN_IMG] = u[1];
+        dst[(i * 6 + 5) * WN_IMG] = Q[1];
     }
 }
 
@@ -814,7 +898,7 @@ struct WgradGeom {
 };
 
 __global__ void __launch_bounds__(WS_BLOCK, 2)
-wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const WgradGeom wg, float* __restrict__ slabs) {
+wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const WgradGeom wg, float* __restrict__ slabs, const int ablate) {
     __shared__ float lds[4 * WN_FREQ * WN_IMG];   // V0 | V1 | dM0 | dM1
     constexpr int IMG = WN_FREQ * WN_IMG;
     const WinoGeom& g = wg.g;
@@ -866,6 +950,7 @@ wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
                     } else {
                         WN_WAIT(f, 0);
                     }
+                    if (ablate & 8) continue;
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][0], fb[f][0], acc[f], 0, 0, 0);
                     acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f + 1][0], fb[f + 1][0], acc[f + 1], 0, 0, 0);
                     acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[f][1], fb[f][1], acc[f], 0, 0, 0);
@@ -899,7 +984,7 @@ wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
         };
         auto fetch = [&](WStage& st, int q_fetch) {
             const bool live = q_fetch < total;
-            const __amdgpu_buffer_rsrc_t xr = wn_rsrc(x, live ? x_bytes : 0u), yr = wn_rsrc(dy, live ? y_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t xr = wn_rsrc(x, live && !(ablate & 1) ? x_bytes : 0u), yr = wn_rsrc(dy, live && !(ablate & 2) ? y_bytes : 0u);
             const int cib = unit / wg.n_co_blocks, cob = unit - cib * wg.n_co_blocks;
             wn_load_x(xr, tp, cib * 32 + slot, g, st.x);
             wn_load_dy(yr, tp, cob * 32 + slot, g, st.y);
@@ -914,6 +999,16 @@ wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
             }
         };
         auto produce = [&](const WStage& st, int buf) {
+            if (ablate & 4) {           // the stores without the transform arithmetic
+                float* const d0 = lds + buf * IMG + img_off;
+                float* const d1 = lds + (2 + buf) * IMG + img_off;
+#pragma unroll
+                for (int f = 0; f < WN_FREQ; ++f) {
+                    d0[f * WN_IMG] = st.x.c[f % 6][f & 3];
+                    d1[f * WN_IMG] = st.y.c[f & 3][f % 4];
+                }
+                return;
+            }
             wn_x_transform_store(st.x, lds + buf * IMG + img_off);
             wn_dy_transform_store(st.y, lds + (2 + buf) * IMG + img_off);
         };
@@ -940,19 +1035,20 @@ wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, con
 
 // stage 1 of the fold: red[unit][f][co][ci] = sum of the unit's segment slabs in workgroup order (one thread per element:
 // coalesced, and enough threads even when a 64-channel layer has 4 units cut into 64 segments each)
+template <int SLAB>
 __global__ void __launch_bounds__(WN_BLOCK)
-wino_wgrad_reduce_kernel(const float* __restrict__ slabs, const WgradGeom wg, int G, float* __restrict__ red) {
-    // WG_SLAB_FLOATS is a multiple of the block size: a block lies inside one unit, whose segment list (which workgroups of the
+wino_wgrad_reduce_kernel(const float* __restrict__ slabs, const int n_units, const int steps_per_unit, int G, float* __restrict__ red) {
+    // SLAB is a multiple of the block size: a block lies inside one unit, whose segment list (which workgroups of the
     // stream-K split touched it) thread 0 works out once - the 64-bit divisions of ws_range_lo per thread and per segment cost more
     // than the fold itself; the loads of eight segments are then in flight together, the adds stay in workgroup order
-    static_assert(WG_SLAB_FLOATS % WN_BLOCK == 0, "a fold block must not straddle two units");
+    static_assert(SLAB % WN_BLOCK == 0, "a fold block must not straddle two units");
     __shared__ int seg[WS_MAX_GRID];
     __shared__ int n_seg;
     const long long e = (long long)blockIdx.x * WN_BLOCK + threadIdx.x;
-    const int unit = (int)(((long long)blockIdx.x * WN_BLOCK) / WG_SLAB_FLOATS);
+    const int unit = (int)(((long long)blockIdx.x * WN_BLOCK) / SLAB);
     if (threadIdx.x == 0) {
-        const long long S = (long long)wg.n_units * wg.steps_per_unit;
-        const long long u_lo = (long long)unit * wg.steps_per_unit, u_hi = u_lo + wg.steps_per_unit;
+        const long long S = (long long)n_units * steps_per_unit;
+        const long long u_lo = (long long)unit * steps_per_unit, u_hi = u_lo + steps_per_unit;
         int w0 = (int)(u_lo * G / S);
         while (w0 > 0 && ws_range_lo(w0, G, S) > u_lo) --w0;
         while (w0 + 1 < G && ws_range_lo(w0 + 1, G, S) <= u_lo) ++w0;
@@ -966,20 +1062,20 @@ wino_wgrad_reduce_kernel(const float* __restrict__ slabs, const WgradGeom wg, in
         n_seg = n;
     }
     __syncthreads();
-    if (unit >= wg.n_units) return;
-    const int off = (int)(e - (long long)unit * WG_SLAB_FLOATS);
-    const float* p = slabs + (size_t)unit * WG_SLAB_FLOATS + off;
+    if (unit >= n_units) return;
+    const int off = (int)(e - (long long)unit * SLAB);
+    const float* p = slabs + (size_t)unit * SLAB + off;
     const int n = n_seg;
     float acc = 0.0f;
     int i = 0;
     for (; i + 8 <= n; i += 8) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = p[(size_t)seg[i + j] * WG_SLAB_FLOATS];
+        for (int j = 0; j < 8; ++j) v[j] = p[(size_t)seg[i + j] * SLAB];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += v[j];
     }
-    for (; i < n; ++i) acc += p[(size_t)seg[i] * WG_SLAB_FLOATS];
+    for (; i < n; ++i) acc += p[(size_t)seg[i] * SLAB];
     red[e] = acc;
 }
 
@@ -1016,6 +1112,10 @@ wino_wgrad_finish_kernel(const float* __restrict__ red, const WgradGeom wg, floa
             out[a * 3 + b] = (float)acc;
         }
 }
+
+#if TODA_VARIANTS
+#include "conv2d_variants.cuh"
+#endif
 
 static int wino_geom(const char* who, int batch, int cin, int cout, int H, int W, WinoGeom* g) {
     TODA_CHECK_ARG(batch >= 1 && H >= 1 && W >= 2 && W % 2 == 0, "%s: needs batch >= 1, H >= 1 and an even W (got %d x %d x %d)", who, batch, H, W);
@@ -1128,10 +1228,25 @@ static int wgrad_geom(const char* who, int batch, int cin, int cout, int H, int 
     return TODA_OK;
 }
 
+#if TODA_VARIANTS
+static bool wgrad_reg_form(int batch, int cin, int cout, int H, int W) {
+    static const int pick = getenv("TODA_WINO_WGRAD") ? atoi(getenv("TODA_WINO_WGRAD")) : 1;       // 1: the staged kernel, 2: the register form (opt-in)
+    const long long bytes = 4LL * batch * (cin > cout ? cin : cout) * H * W;
+    return pick == 2 && cin % W2_CI == 0 && cout % W2_CO == 0 && bytes < (1LL << 31) && W >= 16;    // W >= 16: at least four tiles per row
+}
+#endif
+
 extern "C" size_t toda_conv3x3_wgrad_workspace_bytes(int batch, int cin, int cout, int H, int W) {
+    // one slab per stream-K segment (index w + unit) + the per-unit sums
+#if TODA_VARIANTS
+    if (wgrad_reg_form(batch, cin, cout, H, W)) {
+        const size_t units = (size_t)(cin / W2_CI) * (cout / W2_CO);
+        return (WS_MAX_GRID + 2 * units) * W2_SLAB_FLOATS * sizeof(float);
+    }
+#endif
     (void)batch, (void)H, (void)W;
     const size_t units = (size_t)(cin / 32) * (cout / 32);
-    return (WS_MAX_GRID + 2 * units) * WG_SLAB_FLOATS * sizeof(float);   // one slab per stream-K segment (index w + unit) + the per-unit sums
+    return (WS_MAX_GRID + 2 * units) * WG_SLAB_FLOATS * sizeof(float);
 }
 
 extern "C" int toda_conv3x3_wgrad(const float* x, const float* dy, int batch, int cin, int cout, int H, int W, float* dw, void* ws,
@@ -1154,13 +1269,36 @@ extern "C" int toda_conv3x3_wgrad(const float* x, const float* dy, int batch, in
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (n_cu > WS_MAX_GRID) n_cu = WS_MAX_GRID;
     }
+#if TODA_VARIANTS
+    if (wgrad_reg_form(batch, cin, cout, H, W)) {
+        Wg2Geom w2;
+        w2.g = wg.g;
+        w2.n_cib = cin / W2_CI, w2.n_cob = cout / W2_CO;
+        w2.n_units = w2.n_cib * w2.n_cob;
+        w2.steps_per_unit = cdiv(wg.g.n_tiles, 4);
+        const long long steps2 = (long long)w2.n_units * w2.steps_per_unit;
+        const int grid2 = steps2 < n_cu ? (int)steps2 : n_cu;
+        static const int ablate2 = getenv("TODA_WINO_WG_ABLATE") ? atoi(getenv("TODA_WINO_WG_ABLATE")) : 0;   // measurement only: wrong numbers
+        hipLaunchKernelGGL(wino_wgrad_reg_kernel, dim3(grid2), dim3(W2_BLOCK), 0, (hipStream_t)stream, x, dy, w2, (float*)ws, ablate2);
+        TODA_LAUNCH_CHECK();
+        float* red2 = (float*)ws + (size_t)(WS_MAX_GRID + w2.n_units) * W2_SLAB_FLOATS;
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<W2_SLAB_FLOATS>, dim3(cdiv((long long)w2.n_units * W2_SLAB_FLOATS, WN_BLOCK)), dim3(WN_BLOCK),
+                           0, (hipStream_t)stream, (const float*)ws, w2.n_units, w2.steps_per_unit, grid2, red2);
+        TODA_LAUNCH_CHECK();
+        hipLaunchKernelGGL(wino_wgrad_reg_finish_kernel, dim3(cdiv((long long)cin * cout, WN_BLOCK)), dim3(WN_BLOCK), 0, (hipStream_t)stream,
+                           (const float*)red2, w2, dw);
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
+#endif
     const long long steps = (long long)wg.n_units * wg.steps_per_unit;
     const int grid = steps < n_cu ? (int)steps : n_cu;
-    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, dy, wg, (float*)ws);
+    static const int ablate = getenv("TODA_WINO_WG_ABLATE") ? atoi(getenv("TODA_WINO_WG_ABLATE")) : 0;   // measurement only: wrong numbers
+    hipLaunchKernelGGL(wino_wgrad_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, dy, wg, (float*)ws, ablate);
     TODA_LAUNCH_CHECK();
     float* red = (float*)ws + (size_t)(WS_MAX_GRID + wg.n_units) * WG_SLAB_FLOATS;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv((long long)wg.n_units * WG_SLAB_FLOATS, WN_BLOCK)), dim3(WN_BLOCK), 0,
-                       (hipStream_t)stream, (const float*)ws, wg, grid, red);
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel<WG_SLAB_FLOATS>, dim3(cdiv((long long)wg.n_units * WG_SLAB_FLOATS, WN_BLOCK)), dim3(WN_BLOCK), 0,
+                       (hipStream_t)stream, (const float*)ws, wg.n_units, wg.steps_per_unit, grid, red);
     TODA_LAUNCH_CHECK();
     hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3(cdiv((long long)cin * cout, WN_BLOCK)), dim3(WN_BLOCK), 0, (hipStream_t)stream,
                        (const float*)red, wg, dw);

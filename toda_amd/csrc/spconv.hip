@@ -695,6 +695,8 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
     // full_tag: the round holds 16 pairs (every round but a chunk's last): no per-step test around the MFMAs.  With the test the
     // compiler sinks the loads of steps 1-3 into the conditional blocks, next to their use: load -> wait -> 16 MFMAs four times per
     // round instead of eight loads in flight and 64 MFMAs behind them.
+    const unsigned lane_a = (unsigned)(MT * ii + m0) * 4u, lane_b = (unsigned)(NT * ii + n0) * 4u;
+    const unsigned row_a = (unsigned)cin * 4u, row_b = (unsigned)cout * 4u;
     auto round16 = [&](int d, int limit, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         float a[4][MTB], b[4][NTB];
@@ -703,8 +705,8 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
             const int p = d + 4 * t + g;
             const bool ok = FULL || p < limit;
             const int pc = ok ? p : d;  // any valid queue slot
-            const unsigned ia = ((unsigned)qi[pc] * (unsigned)cin + (unsigned)(MT * ii + m0)) * 4u;
-            const unsigned ib = ((unsigned)qo[pc] * (unsigned)cout + (unsigned)(NT * ii + n0)) * 4u;
+            const unsigned ia = (unsigned)qi[pc] + lane_a;       // the queue holds BYTE offsets of rows (multiplied once, when a pair is queued:
+            const unsigned ib = (unsigned)qo[pc] + lane_b;       // a 32-bit multiply is a quarter-rate instruction on the lanes the MFMAs use)
             // EXACT (channel counts = 16 x tiles: every layer but conv_input): the load form of each side is chosen at
             // compile time (16-byte loads when the block holds >= 4 tiles of that side).  As a run-time branch the two load forms share destination registers and hipcc puts an
             // s_waitcnt vmcnt(3) in front of every 16-byte load: four loads in flight per round instead of eight.
@@ -767,8 +769,8 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
         if (vote == 0) continue;
         if (i >= 0) {
             const int pos = qn + __popcll(vote & ((1ull << lane) - 1));
-            qi[pos] = i;
-            qo[pos] = o;
+            qi[pos] = (int)((unsigned)i * row_a);
+            qo[pos] = (int)((unsigned)o * row_b);
         }
         qn += __popcll(vote);
         __builtin_amdgcn_wave_barrier();

@@ -10,7 +10,7 @@
 // 4 registers: the AGPR file and a little more), a workgroup of four waves 32 x 64 - the waves of a pair read the same patches
 // (second reader: L1) -, one wave per SIMD.  Per step of four tiles a lane issues 12 + 8 loads (a 6 x 6 patch as 16 + 8 bytes
 // per row from x0 - 1, two 4 x 4 tiles of dY), ~400 vector instructions of transform and 72 MFMAs.
-// What the staged kernel above paid (ablation, profiles/r04_wino_wgrad_ablation.txt): with loads, transforms and MFMAs all
+// What the staged kernel above paid (ablation, profiles/r04_wino_wgrad_experiments.txt): with loads, transforms and MFMAs all
 // removed it still took 58 % of its time - 72 ds_write_b32 per producer lane and 72 ds_read_b64 per consumer lane and chunk.
 // Stream-K over (unit = (32-ci block, 64-co block), step); segments dump their accumulators as they stand (1 KiB per store
 // instruction), wino_wgrad_reduce_kernel<W2_SLAB_FLOATS> folds them in workgroup order, wino_wgrad_reg_finish_kernel applies

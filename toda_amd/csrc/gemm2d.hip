@@ -33,10 +33,14 @@ constexpr int PG_BLOCK = 256;
 // consecutive CONTRACTION indices of one row (init() fixes the row, load() walks the contraction).  Index arithmetic is the cost
 // of these kernels, not bytes: no division by a run-time value inside the loop.  Out-of-range elements read as 0.
 
+struct NoCur {};      // (operands without a pixel cursor, see RowCur)
+
 // dense matrix with strides: element (r, c) = p[r * sr + c * sc]
 template <bool COLSHAPE>
 struct MatOp {
     static constexpr bool COL = COLSHAPE;
+    static constexpr bool CURSOR = false;
+    typedef NoCur Cur;
     const float* p;
     int rows, cols;
     long long sr, sc;
@@ -75,6 +79,8 @@ struct MatOp {
 // Pixels of an NCHW map as operand ROWS, channels as contraction: element (n = b * hw + pix, k) = x[(b * C + k) * hw + pix].
 struct PixPlain {
     static constexpr bool COL = true;
+    static constexpr bool CURSOR = false;
+    typedef NoCur Cur;
     const float* x;
     int B, C, hw;
     struct State {
@@ -109,15 +115,87 @@ struct PixCursor {
     int b, pix;
 };
 
+// ---- contraction over PIXELS (the weight gradients) ------------------------------------------------------------------------
+// The contraction index n = (b, y, x) of a stage starts at a WAVE-UNIFORM position and a thread's eight values sit a fixed 0 .. 24
+// places behind it.  fp32 MFMAs and vector instructions share the lanes of a SIMD (the time of either adds to the other: measured
+// on conv2d.hip's kernels), and a 32-bit multiply is quarter rate, a division a dozen instructions with four
+// of those - the round-3 form of these accessors spent 7 vector instructions per MFMA (a fifth of them quarter-rate) on two
+// divisions per call and 64-bit address products per element.  FAST form: the stage's position (b, y, x) is a cursor in scalar
+// registers that is stepped, not divided; the (at most three) grid rows a stage can touch have their offsets and flags worked out
+// there too; a thread only picks between them (compare + select) and adds, in 32 bits.  It needs grid rows of at least one stage
+// (32 pixels) and maps below 2^31 elements (the host picks; the plain form stays for everything else).
+struct RowCur {
+    int b, y, x;           // position of the stage's first contraction index over [B][rows][width]
+    int off[3];            // element offset of grid row j = 0, 1, 2 counted from (b, y): b_j * image + y_j * row
+    int flags;             // bit j: b_j < B;  bit 4 + j: y_j == 0
+};
+__device__ __forceinline__ void rowcur_rows(RowCur& c, int B, int rows, int image, int row) {
+    int b = c.b, y = c.y;
+    c.flags = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        c.off[j] = b * image + y * row;
+        c.flags |= ((b < B ? 1 : 0) | (y == 0 ? 16 : 0)) << j;
+        if (++y == rows) y = 0, ++b;
+    }
+}
+__device__ __forceinline__ void rowcur_set(RowCur& c, int n, int B, int rows, int width, int image, int row) {
+    c.b = n / (rows * width);
+    const int rem = n - c.b * rows * width;
+    c.y = rem / width;
+    c.x = rem - c.y * width;
+    rowcur_rows(c, B, rows, image, row);
+}
+__device__ __forceinline__ void rowcur_step(RowCur& c, int step, int B, int rows, int width, int image, int row) {
+    c.x += step;
+    if (c.x >= width) {           // width >= step: one carry at most
+        c.x -= width;
+        if (++c.y == rows) c.y = 0, ++c.b;
+    }
+    rowcur_rows(c, B, rows, image, row);
+}
+// a thread's eight places behind the cursor: xs = column of the first one, jw = how many places its grid row still has (the rest of
+// the eight lie in the next one), w = 1 when the first one is already past the cursor's row
+struct RowPick {
+    int xs, jw, w;
+};
+__device__ __forceinline__ RowPick rowcur_pick(const RowCur& c, int tn, int width) {
+    RowPick p;
+    p.xs = c.x + tn;
+    p.w = p.xs >= width ? 1 : 0;
+    p.xs -= p.w ? width : 0;
+    p.jw = width - p.xs;
+    return p;
+}
+
 // Channels of an NCHW map as operand rows, pixels as contraction (weight gradients): element (ch, n) = x[(b * C + ch) * hw + pix].
+template <bool FAST>
 struct ChanPlain {
     static constexpr bool COL = false;
+    static constexpr bool CURSOR = FAST;
     const float* x;
     int B, C, hw;
     struct State {
         int ch;
     };
+    typedef RowCur Cur;
+    static bool fast_ok(int hw) { return (hw & 3) == 0 && hw >= PG_K; }          // an image = one grid row of hw pixels
+    __device__ __forceinline__ void cur_set(Cur& c, int n) const { rowcur_set(c, n, B, 1, hw, C * hw, 0); }
+    __device__ __forceinline__ void cur_step(Cur& c) const { rowcur_step(c, PG_K, B, 1, hw, C * hw, 0); }
     __device__ __forceinline__ void init(State& s, int ch) const { s.ch = ch; }
+    __device__ __forceinline__ void load(const State& s, const Cur& c, int tn, float (&v)[8]) const {
+        const bool ok = s.ch < C;
+        const int rowbase = s.ch * hw;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {          // two aligned groups of four pixels, each inside one image
+            const RowPick p = rowcur_pick(c, tn + 4 * h, hw);
+            const bool in = ok && ((c.flags >> p.w) & 1);
+            pg4 t = pg4{0.f, 0.f, 0.f, 0.f};
+            if (in) t = *reinterpret_cast<const pg4*>(x + ((p.w ? c.off[1] : c.off[0]) + rowbase + p.xs));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[4 * h + i] = t[i];
+        }
+    }
     __device__ __forceinline__ void load(const State& s, int n, float (&v)[8]) const {
         const bool ok = s.ch < C;
         const int b0 = n / hw, p0 = n - b0 * hw;          // (one division per stage and thread; the 8 pixels follow by carry)
@@ -151,6 +229,8 @@ struct ConvS2Geom {
 };
 struct PixConvS2 {          // rows = output pixels, contraction = (ci, ky, kx)
     static constexpr bool COL = true;
+    static constexpr bool CURSOR = false;
+    typedef NoCur Cur;
     ConvS2Geom g;
     struct State {
         long long off[8];      // offset of x[b][0][2 oy - 1][2 ox - 1]; < 0 marks an invalid pixel through `ok`
@@ -185,8 +265,10 @@ struct PixConvS2 {          // rows = output pixels, contraction = (ci, ky, kx)
         for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? g.x[s.off[i] + d] : 0.0f;
     }
 };
+template <bool FAST>
 struct TapConvS2 {          // rows = (ci, ky, kx), contraction = output pixels (weight gradient)
     static constexpr bool COL = false;
+    static constexpr bool CURSOR = FAST;
     ConvS2Geom g;
     int rows;
     struct State {
@@ -194,11 +276,31 @@ struct TapConvS2 {          // rows = (ci, ky, kx), contraction = output pixels 
         int ky, kx;
         bool ok;
     };
+    typedef RowCur Cur;
+    // grid row = output row oy (Wo pixels), element offset of (b, oy, 0) = b * C H W + oy * 2 W
+    static bool fast_ok(int Wo) { return Wo >= PG_K; }
+    __device__ __forceinline__ void cur_set(Cur& c, int n) const { rowcur_set(c, n, g.B, g.Ho, g.Wo, g.C * g.H * g.W, 2 * g.W); }
+    __device__ __forceinline__ void cur_step(Cur& c) const { rowcur_step(c, PG_K, g.B, g.Ho, g.Wo, g.C * g.H * g.W, 2 * g.W); }
     __device__ __forceinline__ void init(State& s, int k) const {
         const int ci = k / 9, t = k - ci * 9;
         s.ky = t / 3, s.kx = t - s.ky * 3;
         s.ok = k < rows;
         s.d = ((long long)ci * g.H + s.ky - 1) * g.W + s.kx - 1;
+    }
+    __device__ __forceinline__ void load(const State& s, const Cur& c, int tn, float (&v)[8]) const {
+        const RowPick p = rowcur_pick(c, tn, g.Wo);
+        const int fa = c.flags >> p.w, fb = fa >> 1;                  // flags of the thread's first row and of the one after it
+        const bool row_a = s.ok && (fa & 1) && !(s.ky == 0 && (fa & 16)), row_b = s.ok && (fb & 1) && !(s.ky == 0 && (fb & 16));
+        const unsigned low = p.jw >= 8 ? 0xFFu : (1u << p.jw) - 1u;
+        unsigned m = (row_a ? low : 0u) | (row_b ? (0xFFu & ~low) : 0u);
+        if (s.kx == 0) {              // the left tap of the first pixel of a row is padding
+            if (p.xs == 0) m &= ~1u;
+            if (p.jw < 8) m &= ~(1u << p.jw);
+        }
+        const int d = (int)s.d;
+        const int ea = (p.w ? c.off[1] : c.off[0]) + 2 * p.xs + d, eb = (p.w ? c.off[2] : c.off[1]) + d - 2 * p.jw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? g.x[(i < p.jw ? ea : eb) + 2 * i] : 0.0f;
     }
     __device__ __forceinline__ void load(const State& s, int n, float (&v)[8]) const {
         const int howo = g.Ho * g.Wo;
@@ -224,6 +326,8 @@ struct UnshuffleGeom {
 };
 struct PixUnshuffle {       // rows = low-resolution pixels, contraction = (co, i, j)
     static constexpr bool COL = true;
+    static constexpr bool CURSOR = false;
+    typedef NoCur Cur;
     UnshuffleGeom g;
     struct State {
         long long off[8];
@@ -253,18 +357,35 @@ struct PixUnshuffle {       // rows = low-resolution pixels, contraction = (co, 
         for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? g.dy[s.off[i] + d] : 0.0f;
     }
 };
+template <bool FAST>
 struct ChanUnshuffle {      // rows = (co, i, j), contraction = low-resolution pixels (weight gradient)
     static constexpr bool COL = false;
+    static constexpr bool CURSOR = FAST;
     UnshuffleGeom g;
     int rows;
     struct State {
         long long d;
         bool ok;
     };
+    typedef RowCur Cur;
+    // grid row = low-resolution row y (w pixels), element offset of (b, y, 0) = b * C * 4 h w + y * 4 w
+    static bool fast_ok(int w) { return w >= PG_K; }
+    __device__ __forceinline__ void cur_set(Cur& c, int n) const { rowcur_set(c, n, g.B, g.h, g.w, g.C * 4 * g.h * g.w, 4 * g.w); }
+    __device__ __forceinline__ void cur_step(Cur& c) const { rowcur_step(c, PG_K, g.B, g.h, g.w, g.C * 4 * g.h * g.w, 4 * g.w); }
     __device__ __forceinline__ void init(State& s, int k) const {
         const int co = k >> 2, i2 = (k >> 1) & 1, j2 = k & 1;
         s.ok = k < rows;
         s.d = ((long long)co * (2 * g.h) + i2) * (2 * g.w) + j2;
+    }
+    __device__ __forceinline__ void load(const State& s, const Cur& c, int tn, float (&v)[8]) const {
+        const RowPick p = rowcur_pick(c, tn, g.w);
+        const int fa = c.flags >> p.w, fb = fa >> 1;
+        const unsigned low = p.jw >= 8 ? 0xFFu : (1u << p.jw) - 1u;
+        const unsigned m = ((s.ok && (fa & 1)) ? low : 0u) | ((s.ok && (fb & 1)) ? (0xFFu & ~low) : 0u);
+        const int d = (int)s.d;
+        const int ea = (p.w ? c.off[1] : c.off[0]) + 2 * p.xs + d, eb = (p.w ? c.off[2] : c.off[1]) + d - 2 * p.jw;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ((m >> i) & 1u) ? g.dy[(i < p.jw ? ea : eb) + 2 * i] : 0.0f;
     }
     __device__ __forceinline__ void load(const State& s, int n, float (&v)[8]) const {
         const int hw = g.h * g.w;
@@ -294,6 +415,8 @@ struct S2Class {
 };
 struct PixS2Dgrad {         // rows = input pixels of the class (b, y', x'), contraction = (co, tap of the class)
     static constexpr bool COL = true;
+    static constexpr bool CURSOR = false;
+    typedef NoCur Cur;
     const float* dy;        // [B][Cout][Ho][Wo]
     int B, Cout, H, W, Ho, Wo;
     S2Class c;
@@ -335,6 +458,8 @@ struct PixS2Dgrad {         // rows = input pixels of the class (b, y', x'), con
 };
 struct WS2Dgrad {           // rows = ci, contraction = (co, tap of the class): w[co][ci][ky][kx]
     static constexpr bool COL = false;
+    static constexpr bool CURSOR = false;
+    typedef NoCur Cur;
     const float* w;
     int Cin, Cout;
     S2Class c;
@@ -458,13 +583,21 @@ __device__ __forceinline__ void pg_tile(const Op1& o1, const Op2& o2, const Stor
         else if (h == 0) o2.init(q2[0], r2_0 + t / ROW_DIV);
     }
     float v1[PER][8], v2[PER][8];
+    // operands whose contraction runs over pixels (FAST form): the stage's position as a wave-uniform cursor, stepped before every fetch
+    typename Op1::Cur k1;
+    typename Op2::Cur k2;
+    if constexpr (Op1::CURSOR) o1.cur_set(k1, c_begin);
+    if constexpr (Op2::CURSOR) o2.cur_set(k2, c_begin);
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int h = 0; h < PER; ++h) {
-            if (Op1::COL) o1.load(q1[h], c0 + (t >> 3), v1[h]);
-            else o1.load(q1[0], c0 + (t % ROW_DIV) * (8 * PER) + 8 * h, v1[h]);
-            if (Op2::COL) o2.load(q2[h], c0 + (t >> 3), v2[h]);
-            else o2.load(q2[0], c0 + (t % ROW_DIV) * (8 * PER) + 8 * h, v2[h]);
+            const int tn = (t % ROW_DIV) * (8 * PER) + 8 * h;
+            if constexpr (Op1::COL) o1.load(q1[h], c0 + (t >> 3), v1[h]);
+            else if constexpr (Op1::CURSOR) o1.load(q1[0], k1, tn, v1[h]);
+            else o1.load(q1[0], c0 + tn, v1[h]);
+            if constexpr (Op2::COL) o2.load(q2[h], c0 + (t >> 3), v2[h]);
+            else if constexpr (Op2::CURSOR) o2.load(q2[0], k2, tn, v2[h]);
+            else o2.load(q2[0], c0 + tn, v2[h]);
         }
     };
     auto stash_one = [&](float* img, bool col, const float (&v)[PER][8]) {
@@ -489,7 +622,11 @@ __device__ __forceinline__ void pg_tile(const Op1& o1, const Op2& o2, const Stor
     int buf = 0;
     for (int c0 = c_begin; c0 < c_end; c0 += PG_K) {
         const bool more = c0 + PG_K < c_end;
-        if (more) fetch(c0 + PG_K);
+        if (more) {
+            if constexpr (Op1::CURSOR) o1.cur_step(k1);
+            if constexpr (Op2::CURSOR) o2.cur_step(k2);
+            fetch(c0 + PG_K);
+        }
 #pragma unroll
         for (int kk = 0; kk < PG_K; kk += 16) {           // groups of 16 contraction values = 4 MFMA steps
             pg4 fa[WT], fb[WT];
@@ -681,10 +818,17 @@ extern "C" int toda_conv3x3s2_wgrad(const float* x, const float* dy, int batch, 
         return TODA_EWORKSPACE;
     }
     int per = cdiv(cdiv(N, splits), PG_K) * PG_K;
-    ChanPlain o1{dy, batch, cout, Ho * Wo};                       // rows co, contraction pixels
-    TapConvS2 o2{ConvS2Geom{x, batch, cin, H, W, Ho, Wo}, K};   // rows (ci, ky, kx)
     StoreSlab st{(float*)ws, cout, K};
-    PG_LAUNCH(ChanPlain, TapConvS2, StoreSlab, cout, K, splits, o1, o2, st, N, per);
+    const bool small_map = (long long)batch * (cin > cout ? cin : cout) * H * W < (1LL << 31);      // 32-bit element offsets in the FAST accessors
+    if (small_map && ChanPlain<true>::fast_ok(Ho * Wo) && TapConvS2<true>::fast_ok(Wo)) {
+        ChanPlain<true> o1{dy, batch, cout, Ho * Wo};                       // rows co, contraction pixels
+        TapConvS2<true> o2{ConvS2Geom{x, batch, cin, H, W, Ho, Wo}, K};   // rows (ci, ky, kx)
+        PG_LAUNCH(ChanPlain<true>, TapConvS2<true>, StoreSlab, cout, K, splits, o1, o2, st, N, per);
+    } else {
+        ChanPlain<false> o1{dy, batch, cout, Ho * Wo};
+        TapConvS2<false> o2{ConvS2Geom{x, batch, cin, H, W, Ho, Wo}, K};
+        PG_LAUNCH(ChanPlain<false>, TapConvS2<false>, StoreSlab, cout, K, splits, o1, o2, st, N, per);
+    }
     const long long elems = (long long)cout * K;
     hipLaunchKernelGGL(pg_slab_reduce_kernel, dim3(cdiv(elems, PG_BLOCK)), dim3(PG_BLOCK), 0, (hipStream_t)stream, (const float*)ws, splits, elems, dw);
     TODA_LAUNCH_CHECK();
@@ -749,14 +893,23 @@ extern "C" int toda_deconv_wgrad(const float* x, const float* dy, int batch, int
         return TODA_EWORKSPACE;
     }
     int per = cdiv(cdiv(N, splits), PG_K) * PG_K;
-    ChanPlain o1{x, batch, cin, H * W};                           // rows ci, contraction pixels
     StoreSlab st{(float*)ws, cin, K};
-    if (s == 1) {
-        ChanPlain o2{dy, batch, cout, H * W};
-        PG_LAUNCH(ChanPlain, ChanPlain, StoreSlab, cin, K, splits, o1, o2, st, N, per);
+    const bool small_map = (long long)batch * (cin > cout ? cin : cout) * H * s * W * s < (1LL << 31);      // 32-bit element offsets in the FAST accessors
+    const bool fast = small_map && ChanPlain<true>::fast_ok(H * W) && (s == 1 || ChanUnshuffle<true>::fast_ok(W));
+    if (s == 1 && fast) {
+        ChanPlain<true> o1{x, batch, cin, H * W}, o2{dy, batch, cout, H * W};                           // rows ci / co, contraction pixels
+        PG_LAUNCH(ChanPlain<true>, ChanPlain<true>, StoreSlab, cin, K, splits, o1, o2, st, N, per);
+    } else if (s == 1) {
+        ChanPlain<false> o1{x, batch, cin, H * W}, o2{dy, batch, cout, H * W};
+        PG_LAUNCH(ChanPlain<false>, ChanPlain<false>, StoreSlab, cin, K, splits, o1, o2, st, N, per);
+    } else if (fast) {
+        ChanPlain<true> o1{x, batch, cin, H * W};
+        ChanUnshuffle<true> o2{UnshuffleGeom{dy, batch, cout, H, W}, K};
+        PG_LAUNCH(ChanPlain<true>, ChanUnshuffle<true>, StoreSlab, cin, K, splits, o1, o2, st, N, per);
     } else {
-        ChanUnshuffle o2{UnshuffleGeom{dy, batch, cout, H, W}, K};
-        PG_LAUNCH(ChanPlain, ChanUnshuffle, StoreSlab, cin, K, splits, o1, o2, st, N, per);
+        ChanPlain<false> o1{x, batch, cin, H * W};
+        ChanUnshuffle<false> o2{UnshuffleGeom{dy, batch, cout, H, W}, K};
+        PG_LAUNCH(ChanPlain<false>, ChanUnshuffle<false>, StoreSlab, cin, K, splits, o1, o2, st, N, per);
     }
     const long long elems = (long long)cin * K;
     hipLaunchKernelGGL(pg_slab_reduce_kernel, dim3(cdiv(elems, PG_BLOCK)), dim3(PG_BLOCK), 0, (hipStream_t)stream, (const float*)ws, splits, elems, dw);

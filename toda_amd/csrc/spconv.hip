@@ -647,7 +647,10 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
              const int* __restrict__ nbr, int n_out, int K, int rows_per_chunk, int MT, int NT, int nsub_n,
              float* __restrict__ slab, int xcd_chunks) {
     constexpr int QCAP = 64 + 16;
+    // a side of 16 or 32 channels (one or two tiles = the whole side: the launch gives blocks of fewer than four tiles only then) is staged
+    constexpr bool STAGE_A = EXACT && !COOP && MTB < 4, STAGE_B = EXACT && !COOP && NTB < 4;
     __shared__ float red[MTB * NTB * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float stage[(STAGE_A || STAGE_B) ? SC_BLOCK / 64 : 1][(STAGE_A || STAGE_B) ? 1024 : 4];      // per wave: 16 rows of both operands
     __shared__ int q_in[SC_BLOCK / 64][QCAP], q_out[SC_BLOCK / 64][QCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ii = lane & 15, g = lane >> 4;
@@ -700,6 +703,77 @@ wgrad_kernel(const float* __restrict__ in, int n_in, int cin, const float* __res
     auto round16 = [&](int d, int limit, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         float a[4][MTB], b[4][NTB];
+        if constexpr (STAGE_A || STAGE_B) {
+            // Sides of 16 or 32 channels: a lane's one or two channels of a pair are 4 or 8 bytes, and the address unit takes a
+            // wave-instruction's 64 addresses at the same pace whatever their width (16 cycles): eight 8-byte loads per 16 MFMAs kept it
+            // busy all the time (16 waves per CU; 32 -> 32 at 682 k rows: 0.273 ms).  Such a side comes in as WHOLE ROWS, 16 bytes per
+            // lane (the 16 rows of a round in one or two loads instead of four), and takes the turn into the MFMA layout through a
+            // wave-private LDS tile (contiguous writes, 256- or 512-byte reads: no conflicts): 0.241 ms.
+            float* const st = stage[wv];
+            constexpr int LA = 4 * MTB, LB = 4 * NTB;          // lanes per row (16 bytes each)
+            constexpr int IA = STAGE_A ? LA / 4 : 0, IB = STAGE_B ? LB / 4 : 0;      // loads per round: 64 lanes cover 64 / L rows
+            f32x4 ra[STAGE_A ? IA : 1], rb[STAGE_B ? IB : 1];
+            if constexpr (STAGE_A) {
+#pragma unroll
+                for (int j = 0; j < IA; ++j) {
+                    const int p = d + lane / LA + (64 / LA) * j;
+                    const bool ok = FULL || p < limit;
+                    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? (unsigned)qi[ok ? p : d] + (unsigned)(lane % LA) * 16u : OOB, 0, 0));
+                }
+            }
+            if constexpr (STAGE_B) {
+#pragma unroll
+                for (int j = 0; j < IB; ++j) {
+                    const int p = d + lane / LB + (64 / LB) * j;
+                    const bool ok = FULL || p < limit;
+                    rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? (unsigned)qo[ok ? p : d] + (unsigned)(lane % LB) * 16u : OOB, 0, 0));
+                }
+            }
+            // the side that is not staged: 16-byte loads straight into the MFMA layout, as below
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int p = d + 4 * t + g;
+                const bool ok = FULL || p < limit;
+                const int pc = ok ? p : d;
+                if constexpr (!STAGE_A) {
+#pragma unroll
+                    for (int m4 = 0; m4 < MTB; m4 += 4) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? (unsigned)qi[pc] + lane_a + 4u * m4 : OOB, 0, 0));
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) a[t][m4 + m] = v[m];
+                    }
+                }
+                if constexpr (!STAGE_B) {
+#pragma unroll
+                    for (int n4 = 0; n4 < NTB; n4 += 4) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? (unsigned)qo[pc] + lane_b + 4u * n4 : OOB, 0, 0));
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) b[t][n4 + n] = v[n];
+                    }
+                }
+            }
+            if constexpr (STAGE_A) {
+#pragma unroll
+                for (int j = 0; j < IA; ++j) *reinterpret_cast<f32x4*>(st + (lane / LA + (64 / LA) * j) * (16 * MTB) + (lane % LA) * 4) = ra[j];
+            }
+            if constexpr (STAGE_B) {
+#pragma unroll
+                for (int j = 0; j < IB; ++j) *reinterpret_cast<f32x4*>(st + 512 + (lane / LB + (64 / LB) * j) * (16 * NTB) + (lane % LB) * 4) = rb[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (STAGE_A) {
+#pragma unroll
+                    for (int m = 0; m < MTB; ++m) a[t][m] = st[(4 * t + g) * (16 * MTB) + MTB * ii + m];
+                }
+                if constexpr (STAGE_B) {
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n) b[t][n] = st[512 + (4 * t + g) * (16 * NTB) + NTB * ii + n];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int p = d + 4 * t + g;

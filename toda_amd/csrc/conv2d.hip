@@ -541,17 +541,22 @@ wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, con
     // instead of re-fetching it 16 chunks later, when the XCD's 4 MiB have long been replaced (PMC: 204 MB fetched per
     // launch against 36 MB of input).  The sequence a gang splits by stream-K is then (tile block, chunk); the partner of a
     // cut unit is the same member of the next gang.  Otherwise (gsz = 1) the sequence is (tile block, channel block, chunk).
-    const int gsz = gang ? g.n_cout_blocks : 1;
+    // Round 4: a gang may hold FEWER members than there are channel blocks (gang = its size, a divisor of the count).  The sequence is
+    // then (channel-block group, tile block, chunk): an eighth of it - one XCD - stays inside one group, whose transformed filters
+    // (members x 36 x Cin x 32 floats, sized by the host to fit the XCD's L2 beside the streaming patches) are then read from HBM once per
+    // XCD instead of once per TILE BLOCK (PMC r04: 350 MB per launch, of which the 9.4 MB of filters of a 256 -> 256 layer 36 times over).
+    const int gsz = gang ? gang : 1;
     const int G = gridDim.x / gsz;                  // ranges of the step sequence
     const int rng = w / gsz, member = w - rng * gsz;
-    const long long S = (long long)(gang ? g.n_tile_blocks : n_units) * g.n_chunks;
+    const int n_groups = gang ? g.n_cout_blocks / gsz : 1;
+    const long long S = (long long)(gang ? n_groups * g.n_tile_blocks : n_units) * g.n_chunks;
     const long long lo = ws_range_lo(rng, G, S), hi = ws_range_lo(rng + 1, G, S);
     // (64-bit division runs on the vector ALU: hand the wave-uniform results back to scalar registers, or every use as a
     // scalar operand - the loads' soffset - becomes a waterfall loop)
     const int total = __builtin_amdgcn_readfirstlane((int)(hi - lo));   // chunks this workgroup multiplies = barriers every wave passes
     if (total == 0) return;
-    auto tb_of = [&](int useq) { return gang ? useq : useq / g.n_cout_blocks; };
-    auto cb_of = [&](int useq) { return gang ? member : useq % g.n_cout_blocks; };
+    auto tb_of = [&](int useq) { return gang ? useq % g.n_tile_blocks : useq / g.n_cout_blocks; };
+    auto cb_of = [&](int useq) { return gang ? (useq / g.n_tile_blocks) * gsz + member : useq % g.n_cout_blocks; };
 
     if (wave < 4) {
         // ------------------------------------------------------------------ consumers
@@ -1192,10 +1197,18 @@ extern "C" int toda_conv3x3_fwd(const float* x, const float* u, const float* bia
         }
         // one 144-KiB workgroup per CU; never more workgroups than chunk steps
         // gang mode: n_cout_blocks workgroups per range of the (tile block, chunk) sequence (see the kernel)
+        // gang size: the largest power-of-two divisor of the channel-block count whose filters (size x 36 x Cin x 32 floats) fit
+        // TODA_WINO_GANG_KB (2560 KiB of the XCD's 4 MiB L2); TODA_WINO_GANG = 0: no gangs, 1: this rule, -1: round 3's gang of all blocks
         static const int env_gang = getenv("TODA_WINO_GANG") ? atoi(getenv("TODA_WINO_GANG")) : 1;
+        static const int gang_kb = getenv("TODA_WINO_GANG_KB") ? atoi(getenv("TODA_WINO_GANG_KB")) : 2560;
         const int ncb = g.n_cout_blocks;
-        const int gang = env_gang && ncb > 1 && ncb <= 32 && (32 % ncb) == 0 && (n_cu % ncb) == 0 &&
-                         (long long)g.n_tile_blocks * g.n_chunks >= n_cu / ncb;
+        int gang = 0;
+        if (env_gang && ncb > 1 && ncb <= 32 && (32 % ncb) == 0 && (n_cu % ncb) == 0) {
+            gang = ncb;
+            const long long slice = (long long)WN_FREQ * cin * WN_COUT * 4;
+            while (env_gang > 0 && gang > 1 && gang * slice > (long long)gang_kb * 1024) gang >>= 1;
+            if ((long long)(ncb / gang) * g.n_tile_blocks * g.n_chunks < n_cu / gang) gang = 0;
+        }
         const long long steps = (long long)n_units * g.n_chunks;
         const int grid = gang ? n_cu : (steps < n_cu ? (int)steps : n_cu);
         int* flags = (int*)ws;                                  // 4 words per workgroup: zero on entry, zero again on exit

@@ -1542,6 +1542,10 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     const int Q = tiles_pow2(c_gather), NT = tiles_pow2(c_produce);
     hipStream_t s = (hipStream_t)stream;
     const bool vec_ok = (c_gather & 3) == 0;
+    {   // measurement only (wrong numbers): TODA_GG_ABLATE=1 gives the gathers an empty table (same instruction stream, no row traffic)
+        static const int ablate = getenv("TODA_GG_ABLATE") ? atoi(getenv("TODA_GG_ABLATE")) : 0;
+        if (ablate & 1) n_in = 0;
+    }
     // weight staging: the LDS-shared slice when it measured faster (Q >= 2 and NT >= Q); TODA_GG_LDS = 0 never, 2 always
     static const int env_lds_raw = getenv("TODA_GG_LDS") ? atoi(getenv("TODA_GG_LDS")) : 1;
     const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);

@@ -20,6 +20,21 @@ import torch
 
 _TLS = threading.local()
 CHUNK_BYTES = 512 << 20
+# How a pipeline's worker thread waits for an event on the host.  Blocking events + Event.synchronize(): the thread sleeps inside the
+# runtime with the interpreter lock RELEASED.  The round-4 first form polled Event.query() every 50 us - 20,000 lock hand-overs a second
+# taken from the thread that enqueues the step; harmless at 16 ms per step, but the forward-only loop (3.3 ms per step, 2.6 ms of them
+# host work) fell into alternating 3.3 / 4.3 ms steps on some boxes (profiles/r04_bench_c2_step_ms.txt).  TODA_PREFETCH_POLL=1: poll.
+import os as _os
+BLOCKING_EVENTS = _os.environ.get("TODA_PREFETCH_POLL", "0") != "1"
+
+
+def _host_wait(ev):
+    if BLOCKING_EVENTS:
+        ev.synchronize()
+        return
+    import time as _t
+    while not ev.query():
+        _t.sleep(5e-5)
 
 
 def current_slot():
@@ -147,8 +162,7 @@ class IndexArena:
             self.turn = (self.turn + 1) % n
             if pick.free_event is not None:
                 if self.host_wait:
-                    while not pick.free_event.query():
-                        _t.sleep(5e-5)
+                    _host_wait(pick.free_event)
                 else:
                     stream.wait_event(pick.free_event)
             self.waits += 1
@@ -160,7 +174,7 @@ class IndexArena:
         """Everything that reads `slot` has been enqueued on `stream`."""
         ev = slot.free_event
         if ev is None:
-            ev = slot.free_event = torch.cuda.Event()
+            ev = slot.free_event = torch.cuda.Event(blocking=BLOCKING_EVENTS)
         ev.record(stream)
         slot.in_use = False
 

@@ -135,7 +135,7 @@ class InputPrefetcher:
         if os.environ.get("TODA_PREFETCH_PHASE", "1") == "1" and self.arena is not None and self._host_wait and bb is not None:
             def _mark(_m, _a, _out):
                 if torch.is_grad_enabled():      # training steps only (the forward-only loops have no slack to wait in)
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(blocking=self._arena_mod.BLOCKING_EVENTS)
                     ev.record()
                     self._fwd_done = ev
             self._phase_hook = bb.register_forward_hook(_mark)
@@ -173,9 +173,7 @@ class InputPrefetcher:
             slot = self.arena.acquire(self.side) if self.arena is not None else None      # (waits on the host for a free slot)
             gate = self._fwd_done
             if gate is not None and slot is not None:
-                import time as _t
-                while not gate.query():
-                    _t.sleep(5e-5)
+                self._arena_mod._host_wait(gate)
             with self._arena_mod.use_slot(slot):
                 if isinstance(batch, (tuple, list)):      # the (adversarial, original) pair of the stage-2 consistency step
                     batch = tuple(prepare_batch_on_gpu(b, self.net, self.voxel_cfg) for b in batch)
@@ -183,15 +181,13 @@ class InputPrefetcher:
                     batch = prepare_batch_on_gpu(batch, self.net, self.voxel_cfg)
             if self.arena is not None:
                 self.arena.prewarm()         # once: the other slots get the first one's layout (no device allocation after the warm-up steps)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(blocking=self._arena_mod.BLOCKING_EVENTS)
             ev.record(self.side)
             if self._host_wait:
-                # hand the batch over only when its preparation has FINISHED on the GPU (poll + sleep: this is the worker thread, and the
-                # tables' kernels take a few hundred microseconds): next() then needs no stream-side wait, and the training stream's queue
-                # carries no cross-queue dependency at all
-                import time as _t
-                while not ev.query():
-                    _t.sleep(5e-5)
+                # hand the batch over only when its preparation has FINISHED on the GPU (this is the worker thread; it sleeps in the runtime
+                # with the interpreter lock released): next() then needs no stream-side wait, and the training stream's queue carries no
+                # cross-queue dependency at all
+                self._arena_mod._host_wait(ev)
         return batch, ev, slot
 
     def kick(self):

@@ -24,7 +24,8 @@ def timeit(fn, n=20):
     return ev[0].elapsed_time(ev[1]) / n
 # (key, table, cin(gathered), cout(produced), transpose, flip)
 cases = [('subm1', 'fwd', 5, 16, False, False), ('subm1', 'fwd', 16, 16, False, False), ('subm1', 'bwd', 16, 16, True, True),
-         ('spconv2', 'fwd', 16, 32, False, False), ('spconv2', 'bwd', 32, 16, True, False)]
+         ('spconv2', 'fwd', 16, 32, False, False), ('spconv2', 'bwd', 32, 16, True, False),
+         ('subm2', 'fwd', 32, 32, False, False), ('subm2', 'bwd', 32, 32, True, True)]
 for key, tab, cg, cp, tr, fl in cases:
     rb = plan[key]['rb']
     nbr = rb.nbr_fwd if tab == 'fwd' else rb.nbr_bwd

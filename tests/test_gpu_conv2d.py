@@ -351,3 +351,34 @@ def test_register_form_wgrad_matches_fp64_and_repeats_bit_for_bit():
     assert p.returncode == 0, p.stderr[-2000:]
     worst = float(p.stdout.strip().split("WORST")[-1])
     assert worst < 1e-5, worst
+
+
+_GANG_CHILD = r"""
+import sys, torch
+import torch.nn.functional as F
+sys.path.insert(0, sys.argv[1])
+from toda_amd import ops
+torch.manual_seed(3)
+worst = 0.0
+for (B, ci, co, H, W) in [(2, 256, 256, 94, 94), (1, 128, 128, 47, 46), (2, 512, 64, 20, 20), (1, 64, 320, 9, 30), (3, 256, 128, 10, 94)]:
+    x = torch.randn(B, ci, H, W, device="cuda"); w = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
+    y = ops.conv3x3(x, w)
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), padding=1)
+    worst = max(worst, float((y.double().cpu() - ref).abs().max() / ref.abs().max()))
+print("WORST", worst)
+"""
+
+
+@pytest.mark.parametrize("gang,kb", [("-1", "2560"), ("1", "600"), ("1", "1280"), ("1", "5120"), ("0", "2560")])
+def test_winograd_forward_is_the_same_for_every_gang_size(gang, kb):
+    """The stream-K sequence of wino_fwd_ws_kernel is (channel-block group, tile block, chunk) with gangs sized by an L2 budget (round 4): all
+    block counts per gang - every block (round 3's form), 1, 2, 4, none - give the convolution (the switch is read once: child process)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TODA_WINO_GANG=gang, TODA_WINO_GANG_KB=kb)
+    p = subprocess.run([sys.executable, "-c", _GANG_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert float(p.stdout.strip().split("WORST")[-1]) < 2e-5

@@ -2,9 +2,11 @@
 
 What it restates (reference file:line):
   cutmix            pcdet/datasets/processor/inter_domain_point_cutmix.py:10-90
-  polarmix          pcdet/datasets/processor/inter_domain_point_polarmix.py:44-99 (swap), :153-191 (rotate_copy),
-                    :193-245 (polarmix), :247-300 (sector / Omega draws)
+  polarmix          pcdet/datasets/processor/inter_domain_point_polarmix.py:44-99 (swap, with and without use_pitch),
+                    :101-151 (swap_with_range), :153-191 (rotate_copy), :193-245 (polarmix), :247-300 (sector / Omega draws)
   lasermix (cyc)    pcdet/datasets/processor/inter_domain_point_lasermix.py:88-173
+  lasermix (sph)    pcdet/datasets/processor/inter_domain_point_lasermix.py:22-85, entry point :176-192
+  pseudo mixes      pcdet/datasets/processor/inter_domain_point_pseudomix.py:19-47 (pseudobbox), :49-68 (pseudobackground)
   mixup / mixup_cd  pcdet/datasets/processor/intra_domain_point_mixup.py:15-72
   primitives        pcdet/utils/box_utils.py:28-89, pcdet/utils/common_utils.py:34-63,
                     pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:121-168 (oracle_points_in_boxes),
@@ -120,7 +122,19 @@ def _sector(yaw, lo, hi):
     return (yaw > _w(lo)) & (yaw < _w(hi))
 
 
-def polar_swap(pt1, pt2, lo, hi, box1, box2, inc_method="center"):
+def pitch32(z, dis, sign=-1.0):
+    """sign * arctan2(z, dis) as the correctly rounded fp32 value (see the module note on numpy's fp32 arctan2)."""
+    v = np.arctan2(np.asarray(z, np.float64), np.asarray(dis, np.float64)).astype(F32)
+    return -v if sign < 0 else v
+
+
+def _range32(x, y):
+    """np.sqrt(x ** 2 + y ** 2) of fp32 columns: every step rounded to fp32."""
+    x, y = np.asarray(x, F32), np.asarray(y, F32)
+    return np.sqrt(x * x + y * y)
+
+
+def polar_swap(pt1, pt2, lo, hi, box1, box2, inc_method="center", use_pitch=False):
     if inc_method == "center":
         take1 = _sector(yaw32(box1[:, 0], box1[:, 1]), lo, hi)
         take2 = _sector(yaw32(box2[:, 0], box2[:, 1]), lo, hi)
@@ -135,9 +149,35 @@ def polar_swap(pt1, pt2, lo, hi, box1, box2, inc_method="center"):
     else:
         raise NotImplementedError(inc_method)
     boxes = np.concatenate([box1[~take1], box2[take2]], 0)
-    in1 = _sector(yaw32(pt1[:, 0], pt1[:, 1]), lo, hi)
-    in2 = _sector(yaw32(pt2[:, 0], pt2[:, 1]), lo, hi)
-    return np.concatenate([pt1[~in1], pt2[in2]], 0), boxes
+    yaw1, yaw2 = yaw32(pt1[:, 0], pt1[:, 1]), yaw32(pt2[:, 0], pt2[:, 1])
+    in1, in2 = _sector(yaw1, lo, hi), _sector(yaw2, lo, hi)
+    if not use_pitch:
+        return np.concatenate([pt1[~in1], pt2[in2]], 0), boxes
+    # use_pitch (:81-93): cloud 2 also gives the points OUTSIDE the sector whose elevation lies outside cloud 1's
+    # elevation span (both judged beyond 1 m of range); they come before the sector's points
+    dis1, dis2 = _range32(pt1[:, 0], pt1[:, 1]), _range32(pt2[:, 0], pt2[:, 1])
+    far1, far2 = dis1 > F32(1), dis2 > F32(1)
+    pitch1, pitch2 = pitch32(pt1[:, 2], dis1), pitch32(pt2[:, 2], dis2)
+    p_min, p_max = pitch1[far1].min(), pitch1[far1].max()
+    beyond = ((yaw2 < _w(lo)) | (yaw2 > _w(hi))) & ((pitch2 < p_min) | (pitch2 > p_max)) & far2
+    return np.concatenate([pt1[~in1], pt2[beyond], pt2[in2]], 0), boxes
+
+
+def polar_swap_with_range(pt1, pt2, lo, hi, box1, box2, pc_range, rng=np.random):
+    """swap_with_range (:101-151): the sector is cut at a random range - the near part (threshold beyond 40 % of the
+    x range) or the far part is exchanged; boxes follow by centre."""
+    r_max = F32(np.asarray(pc_range, F32)[3])
+    dis_th = F32(rng.random()) * r_max                 # python float * np.float32 -> fp32
+    near = F32(dis_th / r_max) > F32(0.4)
+
+    def chosen(x, y):
+        inside = _sector(yaw32(x, y), lo, hi)
+        d = _range32(x, y)
+        return inside & ((d < dis_th) if near else (d > dis_th))
+
+    in1, in2 = chosen(pt1[:, 0], pt1[:, 1]), chosen(pt2[:, 0], pt2[:, 1])
+    b1, b2 = chosen(box1[:, 0], box1[:, 1]), chosen(box2[:, 0], box2[:, 1])
+    return np.concatenate([pt1[~in1], pt2[in2]], 0), np.concatenate([box1[~b1], box2[b2]], 0)
 
 
 def rotate_paste_candidates(pts, boxes, omegas, existing):
@@ -199,13 +239,21 @@ def polarmix_sectors(degree, train_percent, update_methods, rng):
     return sectors
 
 
-def polarmix(source, target, rot_copy_num, degree, train_percent, update_methods, inc_method="center", rng=np.random):
+def polarmix(source, target, rot_copy_num, degree, train_percent, update_methods, inc_method="center", rng=np.random,
+             polar_dis="FULL", use_pitch=False, pc_range=None):
+    """polar_dis = "RAND": the reference's own call of swap_with_range carries a keyword that function does not take
+    (:215-220, a TypeError as shipped); this is that call without the stray keyword."""
     sectors = polarmix_sectors(degree, train_percent, update_methods, rng)
     omegas = [0, rng.random() * np.pi * 2 / 3, (rng.random() + 1) * np.pi * 2 / 3][:rot_copy_num]
     pts, boxes = source["points"], source["gt_boxes"]
     rng.random()                                    # the reference's `if np.random.random() < 1.0` (swap branch)
     for lo, hi in sectors:
-        pts, boxes = polar_swap(pts, target["points"], lo, hi, boxes, target["gt_boxes"], inc_method)
+        if polar_dis == "FULL":
+            pts, boxes = polar_swap(pts, target["points"], lo, hi, boxes, target["gt_boxes"], inc_method, use_pitch)
+        elif polar_dis == "RAND":
+            pts, boxes = polar_swap_with_range(pts, target["points"], lo, hi, boxes, target["gt_boxes"], pc_range, rng)
+        else:
+            raise NotImplementedError(polar_dis)
     rng.random()                                    # ... and the rotate-paste branch
     new_pts, new_boxes = rotate_paste_candidates(target["points"], target["gt_boxes"], omegas, boxes)
     pts = drop_points_in_boxes(pts, new_boxes[:, :7])
@@ -261,6 +309,53 @@ def lasermix_cyc(source, target, num_areas, num_angles, pc_range, inc_method="ce
                 raise NotImplementedError(inc_method)
             pick += 1
     return {"points": np.concatenate(out_pts, 0), "gt_boxes": np.concatenate(out_box, 0)}
+
+
+def lasermix_sph(source, target, pitch_angles, num_areas, order=0, rng=np.random):
+    """laser_mix_transform_sph (:22-85): elevation bands (degrees, top to bottom) alternate between the two scenes, band i
+    from `source` when i % 2 == order.  Elevation = arctan2(z - 1.8, range) in radians, clipped against the DEGREE bounds
+    +- 1e-5 (as the reference does: only the upper bound ever acts), band edges compared in fp64 (numpy promotes an fp32
+    array against np.float64 scalars).  The entry point passes inc_method where `order` is expected (:186-192): a string
+    never equals i % 2, so every band comes from the target - restated as is."""
+    lo, hi = F32(pitch_angles[0] + 1e-5), F32(pitch_angles[1] - 1e-5)
+
+    def elevation(x, y, z):
+        return np.clip(pitch32(F32(-1.8) + np.asarray(z, F32), _range32(x, y), sign=+1.0), lo, hi)
+
+    sp, sb, tp, tb = source["points"], source["gt_boxes"], target["points"], target["gt_boxes"]
+    ev = {"sp": elevation(sp[:, 0], sp[:, 1], sp[:, 2]), "sb": elevation(sb[:, 0], sb[:, 1], sb[:, 2]),
+          "tp": elevation(tp[:, 0], tp[:, 1], tp[:, 2]), "tb": elevation(tb[:, 0], tb[:, 1], tb[:, 2])}
+    n_bands = rng.choice(num_areas, size=1)[0]
+    edges = np.linspace(pitch_angles[1], pitch_angles[0], n_bands + 1)
+    out_pts, out_box = [], []
+    for i in range(n_bands):
+        a, b = edges[i + 1] / 180 * np.pi, edges[i] / 180 * np.pi
+        if i % 2 == order:
+            out_pts.append(sp[(ev["sp"] > a) & (ev["sp"] <= b)])
+            out_box.append(sb[(ev["sb"] > a) & (ev["sb"] <= b)])
+        else:
+            out_pts.append(tp[(ev["tp"] > a) & (ev["tp"] <= b)])
+            out_box.append(tb[(ev["tb"] > a) & (ev["tb"] <= b)])
+    return {"points": np.concatenate(out_pts, 0), "gt_boxes": np.concatenate(out_box, 0)}
+
+
+# --------------------------------------------------------------------------------- pseudo mixes
+def pseudobbox(source, target):
+    """inter_domain_point_pseudobbox (inter_domain_point_pseudomix.py:19-47): the target's boxes that touch no source box in
+    BEV are pasted, with their points, into the source scene (whose points inside those boxes go)."""
+    sp, sb, tp, tb = source["points"], source["gt_boxes"], target["points"], target["gt_boxes"]
+    free = bev_overlap(sb, tb).sum(0) == 0
+    paste = tb[free]
+    pts = np.concatenate([sp[~points_in_any_box(sp, paste, 0)], tp[points_in_any_box(tp, paste, 0)]], 0)
+    return {"points": pts, "gt_boxes": np.concatenate([sb, paste], 0)}
+
+
+def pseudobackground(source, target):
+    """inter_domain_point_pseudobackground (:49-68): the source's objects (points inside its boxes) on the target's
+    background (points outside the target's boxes); boxes = the source's."""
+    sp, sb, tp, tb = source["points"], source["gt_boxes"], target["points"], target["gt_boxes"]
+    pts = np.concatenate([sp[points_in_any_box(sp, sb, 0)], tp[~points_in_any_box(tp, tb, 0)]], 0)
+    return {"points": pts, "gt_boxes": sb}
 
 
 # --------------------------------------------------------------------------------------- MixUp

@@ -2,7 +2,9 @@
 """Capture golden vectors from the REFERENCE's own data-path Python (build container only).
 
     python tests/golden/capture_mix.py
-writes tests/golden/mix_*.npz (CutMix / PolarMix / LaserMix / MixUp), aug_world.npz (global flip / rotation / scaling),
+    python tests/golden/capture_mix.py --only-round4      (the fixtures added in round 4, the others untouched)
+writes tests/golden/mix_*.npz (CutMix / PolarMix incl. use_pitch and swap_with_range / LaserMix cylindrical and spherical /
+pseudo-box and pseudo-background mixes / MixUp), aug_world.npz (global flip / rotation / scaling),
 gt_sampling.npz (DataBaseSampler), collate_batch.npz, data_processor.npz (range mask + shuffle), decode_bbox.npz
 (decode_bbox_from_heatmap), consistency.npz (reverse_transform / get_consistency_loss), small_utils.npz
 (PointFeatureEncoder, box / angle helpers).
@@ -53,7 +55,7 @@ def setup():
     CR._load("pcdet.datasets.augmentor.augmentor_utils", "pcdet/datasets/augmentor/augmentor_utils.py")
     M = {"augmentor_utils": sys.modules["pcdet.datasets.augmentor.augmentor_utils"]}
     for name in ("inter_domain_point_cutmix", "inter_domain_point_polarmix", "inter_domain_point_lasermix",
-                 "intra_domain_point_mixup"):
+                 "intra_domain_point_mixup", "inter_domain_point_pseudomix"):
         M[name] = CR._load(f"pcdet.datasets.processor.{name}", f"pcdet/datasets/processor/{name}.py")
     return M
 
@@ -246,8 +248,49 @@ def cap_small_utils():
     print("small_utils", out["points"].shape)
 
 
+def cap_round4(M):
+    """The mixes round 4 added: pseudo-box / pseudo-background (inter_domain_point_pseudomix.py:19-68), PolarMix's swap with
+    use_pitch (through the entry point) and swap_with_range (called directly: the entry point's own call of it raises a
+    TypeError, inter_domain_point_polarmix.py:215-220), spherical LaserMix (through the entry point, which hands inc_method
+    to `order`, and directly with order 0 / 1)."""
+    pm, lm, ps = M["inter_domain_point_polarmix"], M["inter_domain_point_lasermix"], M["inter_domain_point_pseudomix"]
+    src, tgt = scene("waymo_toda", 71, 6000, 14), scene("nuscenes_toda", 72, 5000, 12)
+    # three target boxes that sit on source boxes (they must not be pasted) next to the target's own
+    clash = src["gt_boxes"][[1, 4, 9]].copy()
+    clash[:, 0:2] += np.float32(0.4)
+    tgt_b = dict(tgt, gt_boxes=np.concatenate([tgt["gt_boxes"][:5], clash, tgt["gt_boxes"][5:]], 0))
+    save("pseudobbox", src, tgt_b, ps.inter_domain_point_pseudobbox(copy(src), copy(tgt_b)))
+    save("pseudobackground", src, tgt, ps.inter_domain_point_pseudobackground(copy(src), copy(tgt)))
+
+    src, tgt = scene("waymo_toda", 21, 6000, 14), scene("nuscenes_toda", 22, 4000, 12)
+    for name, seed, p in [("polarmix_pitch_center", 204, dict(rc=1, degree=1.570796, pct=0.3, methods=["FIX", "FIX"], inc="center")),
+                          ("polarmix_pitch_corner_del", 205, dict(rc=2, degree=[0.8, 1.9], pct=0.6, methods=["RAND", "ASC", "DESC"], inc="corner_del"))]:
+        np.random.seed(seed)
+        out = pm.inter_domain_point_polarmix(copy(src), copy(tgt), p["rc"], p["degree"], p["pct"], p["methods"], PC_RANGE, "FULL", p["inc"], True)
+        deg = np.atleast_1d(np.asarray(p["degree"], np.float64))
+        save(name, src, tgt, out, seed=seed, rc=p["rc"], degree=deg, degree_is_float=isinstance(p["degree"], float),
+             pct=p["pct"], methods=np.array(p["methods"]), inc=p["inc"])
+    for name, seed, lo, hi in [("polar_range_near", 206, -0.7, 1.1), ("polar_range_far", 218, 1.9, 3.0)]:
+        np.random.seed(seed)
+        pts, boxes = pm.swap_with_range(src["points"].copy(), tgt["points"].copy(), lo, hi, src["gt_boxes"].copy(), tgt["gt_boxes"].copy(), PC_RANGE)
+        save(name, src, tgt, {"points": pts, "gt_boxes": boxes}, seed=seed, lo=lo, hi=hi)
+
+    src, tgt = scene("waymo_toda", 31, 6000, 14), scene("nuscenes_toda", 32, 5000, 12)
+    np.random.seed(303)
+    out = lm.inter_domain_point_lasermix(copy(src), copy(tgt), [-20, 0], [3, 4, 5, 6], None, PC_RANGE, "center")
+    save("lasermix_sph_entry", src, tgt, out, seed=303, pitch=np.array([-20, 0]), num_areas=np.array([3, 4, 5, 6]))
+    for name, seed, order, pitch, areas in [("lasermix_sph_order0", 304, 0, [-25, 3], [4, 5, 6]), ("lasermix_sph_order1", 305, 1, [-20, 0], [5])]:
+        np.random.seed(seed)
+        out = lm.laser_mix_transform_sph(copy(src), copy(tgt), pitch, areas, order)
+        save(name, src, tgt, out, seed=seed, pitch=np.array(pitch), num_areas=np.array(areas), order=order)
+
+
 def main():
     M = setup()
+    if "--only-round4" in sys.argv:
+        cap_round4(M)
+        return
+    cap_round4(M)
     # CutMix needs > 10 000 target points inside the crop (inter_domain_point_cutmix.py:57)
     src, tgt = scene("waymo_toda", 11, 14000, 12), scene("nuscenes_toda", 12, 26000, 10)
     np.random.seed(101)

@@ -21,14 +21,25 @@ def load(name):
 
 
 def run_case(name, engine):
-    """engine: module-like with cutmix / polarmix / lasermix_cyc / mixup taking numpy dicts."""
+    """engine: module-like with cutmix / polarmix / polar_swap_with_range / lasermix_cyc / lasermix_sph / pseudobbox /
+    pseudobackground / mixup taking numpy dicts."""
     z, src, tgt = load(name)
+    if name.startswith("pseudo"):
+        return z, getattr(engine, name)(src, tgt)
     rng = np.random.RandomState(int(z["seed"]))
+    if name.startswith("polar_range"):
+        pts, boxes = engine.polar_swap_with_range(src["points"], tgt["points"], float(z["lo"]), float(z["hi"]), src["gt_boxes"],
+                                                  tgt["gt_boxes"], PC_RANGE, rng=rng)
+        return z, {"points": pts, "gt_boxes": boxes}
+    if name.startswith("lasermix_sph"):
+        order = int(z["order"]) if "order" in z.files else "center"        # the entry point hands inc_method to `order`
+        return z, engine.lasermix_sph(src, tgt, [int(v) for v in z["pitch"]], [int(v) for v in z["num_areas"]], order, rng=rng)
     if name == "cutmix":
         out = engine.cutmix(src, tgt, PC_RANGE, rng=rng)
     elif name.startswith("polarmix"):
         deg = float(z["degree"][0]) if bool(z["degree_is_float"]) else [float(v) for v in z["degree"]]
-        out = engine.polarmix(src, tgt, int(z["rc"]), deg, float(z["pct"]), [str(m) for m in z["methods"]], str(z["inc"]), rng=rng)
+        out = engine.polarmix(src, tgt, int(z["rc"]), deg, float(z["pct"]), [str(m) for m in z["methods"]], str(z["inc"]), rng=rng,
+                              use_pitch=name.startswith("polarmix_pitch"))
     elif name.startswith("lasermix"):
         out = engine.lasermix_cyc(src, tgt, int(z["num_areas"]), int(z["num_angles"]), PC_RANGE, str(z["inc"]), rng=rng)
     else:
@@ -37,7 +48,10 @@ def run_case(name, engine):
 
 
 CASES = ["cutmix", "polarmix_center", "polarmix_corner", "polarmix_corner_del", "lasermix_center", "lasermix_corner_del",
-         "mixup", "mixup_cd"]
+         "mixup", "mixup_cd",
+         # round 4: use_pitch, swap_with_range, spherical LaserMix, the pseudo mixes
+         "polarmix_pitch_center", "polarmix_pitch_corner_del", "polar_range_near", "polar_range_far",
+         "lasermix_sph_entry", "lasermix_sph_order0", "lasermix_sph_order1", "pseudobbox", "pseudobackground"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -430,6 +430,9 @@ int toda_nms_rotated(const float* boxes_sorted, int n, float thresh, int64_t* ke
  *   - the crop test of CutMix (inter_domain_point_cutmix.py:44-54) and mask_points_by_range
  *     (pcdet/utils/common_utils.py:60-63)                                         -> toda_points_rect
  *   - the cylinder cells of LaserMix (inter_domain_point_lasermix.py:89-165)       -> toda_points_polar_cell
+ *   - the elevation bands of spherical LaserMix (inter_domain_point_lasermix.py:40-47,62-80) -> toda_points_pitch_band
+ *   - PolarMix's sector cut at a random range (swap_with_range, inter_domain_point_polarmix.py:101-123) and the
+ *     elevation test of swap(use_pitch=True) (:81-93)                  -> toda_points_polar_select, toda_points_pitch_range
  *   - boolean-mask indexing / np.delete / np.concatenate of point arrays           -> toda_rows_select_append
  *   - rotate_copy's point rotation (inter_domain_point_polarmix.py:160-188)        -> toda_points_rotate_z
  * points: [n, c] fp32 rows (x, y, z, ...).  n_dev (nullable): device int32, rows = min(n, *n_dev), so
@@ -452,6 +455,19 @@ int toda_points_rect(const float* points, int n, const int32_t* n_dev, int c, co
 int toda_points_polar_cell(const float* points, int n, const int32_t* n_dev, int c, float phase,
                            const double* yaw_edges_host, int n_yaw, const double* dis_edges_host, int n_dis,
                            float dis_lo, float dis_hi, int32_t* cell, void* stream);
+/* flags[j] = [yaw_mode 1: lo < yaw < hi | 2: yaw < lo or yaw > hi]  and  [dis_mode 0: - | 1: range < dis_th | 2: range > dis_th]
+ * and, with pitch_range_dev != NULL, [range > 1 and -atan2(z, range) outside [pitch_range_dev[0], pitch_range_dev[1]]];
+ * yaw = -atan2(y, x) and range = sqrt(x^2 + y^2) as fp32 values, thresholds compared in fp64 (round them to fp32 where numpy would). */
+int toda_points_polar_select(const float* points, int n, const int32_t* n_dev, int c, double lo, double hi, int yaw_mode,
+                             int dis_mode, double dis_th, const float* pitch_range_dev, int32_t* flags, void* stream);
+/* range_dev[0:2] = min, max of -atan2(z, range) over the rows with range > 1 (+inf, -inf when there is none); deterministic. */
+size_t toda_points_pitch_range_workspace_bytes(void);
+int toda_points_pitch_range(const float* points, int n, const int32_t* n_dev, int c, float* range_dev, void* ws,
+                            size_t ws_bytes, void* stream);
+/* band[j] = i for edges[i + 1] < e <= edges[i] (n_bands + 1 descending edges, radians, host array), e = clip(atan2(z_offset + z,
+ * range), clip_lo, clip_hi) in fp32; -1 when no band holds it */
+int toda_points_pitch_band(const float* points, int n, const int32_t* n_dev, int c, float z_offset, float clip_lo,
+                           float clip_hi, const double* edges_host, int n_bands, int32_t* band, void* stream);
 /* Stable compaction: rows with (keys[j] == match) != invert (all rows when keys == NULL) are appended, in
  * order, at dst[*cursor_dev ...]; *cursor_dev += count.  Rows beyond cap_rows are dropped (the cursor still
  * counts them, so the caller sees the overflow). */

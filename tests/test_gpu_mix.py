@@ -81,6 +81,50 @@ def test_sector_rect_and_cell_flags_match_numpy_restatement():
         np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
+def test_range_cut_elevation_test_and_elevation_bands_match_numpy_restatement():
+    """toda_points_polar_select / _pitch_range / _pitch_band against the oracle's fp32 expressions on 200k points."""
+    from toda_amd import ops
+    p = cloud(15, 200000)
+    p[:6, :3] = [[0, 0, 1], [1, 0, 0], [0.6, 0.8, -2], [0.6, 0.8000001, 2], [-30, 0.0, 1.8], [3, 4, -1.7]]   # range 0, exactly 1, just beyond 1
+    d = dev(p)
+    yaw, dis = OM.yaw32(p[:, 0], p[:, 1]), OM._range32(p[:, 0], p[:, 1])
+    pitch = OM.pitch32(p[:, 2], dis)
+    for lo, hi, th in [(-0.5, 1.2, 21.5), (2.0, np.pi, 40.25), (-np.pi, -2.5, 3.0)]:
+        lo32, hi32, th32 = np.float32(lo), np.float32(hi), np.float32(th)
+        inside = (yaw > lo32) & (yaw < hi32)
+        np.testing.assert_array_equal(ops.points_polar_select(d, lo32, hi32, dis_mode=1, dis_th=th32).cpu().numpy() != 0, inside & (dis < th32))
+        np.testing.assert_array_equal(ops.points_polar_select(d, lo32, hi32, dis_mode=2, dis_th=th32).cpu().numpy() != 0, inside & (dis > th32))
+        np.testing.assert_array_equal(ops.points_polar_select(d, lo32, hi32).cpu().numpy() != 0, inside)
+        np.testing.assert_array_equal(ops.points_polar_select(d, lo32, hi32, outside=True).cpu().numpy() != 0, (yaw < lo32) | (yaw > hi32))
+    # elevation span of another cloud (beyond 1 m), read on the device by the select kernel
+    q = cloud(16, 70001)
+    q[:, 2] *= 0.05
+    qd = OM._range32(q[:, 0], q[:, 1])
+    qp = OM.pitch32(q[:, 2], qd)[qd > 1]
+    span = ops.points_pitch_range(dev(q))
+    np.testing.assert_array_equal(span.cpu().numpy(), np.array([qp.min(), qp.max()], np.float32))
+    want = ((yaw < np.float32(-0.5)) | (yaw > np.float32(1.2))) & ((pitch < qp.min()) | (pitch > qp.max())) & (dis > 1)
+    got = ops.points_polar_select(d, np.float32(-0.5), np.float32(1.2), outside=True, pitch_range=span).cpu().numpy() != 0
+    assert want.sum() > 1000
+    np.testing.assert_array_equal(got, want)
+    # a device-side row count, and a cloud with nothing beyond 1 m
+    n_dev = torch.tensor([12345], dtype=torch.int32, device="cuda")
+    qp2 = OM.pitch32(q[:12345, 2], qd[:12345])[qd[:12345] > 1]
+    np.testing.assert_array_equal(ops.points_pitch_range(dev(q), n_dev).cpu().numpy(), np.array([qp2.min(), qp2.max()], np.float32))
+    near = ops.points_pitch_range(dev(np.zeros((10, 4), np.float32))).cpu().numpy()
+    assert near[0] == np.inf and near[1] == -np.inf
+    # spherical LaserMix bands (degrees in, radians compared in fp64; clip bounds in degrees as the reference has them)
+    for pa, nb in [([-20, 0], 5), ([-25, 3], 6), ([-10, 10], 1)]:
+        lo, hi = np.float32(pa[0] + 1e-5), np.float32(pa[1] - 1e-5)
+        edges = np.linspace(pa[1], pa[0], nb + 1) / 180 * np.pi
+        ev = np.clip(OM.pitch32(np.float32(-1.8) + p[:, 2], dis, sign=+1.0), lo, hi)
+        want = np.full(len(p), -1, np.int32)
+        for i in range(nb):
+            want[(ev > edges[i + 1]) & (ev <= edges[i])] = i
+        assert (want >= 0).sum() > 1000 and (want < 0).sum() > 1000
+        np.testing.assert_array_equal(ops.points_pitch_band(d, np.float32(-1.8), lo, hi, edges).cpu().numpy(), want)
+
+
 def test_select_append_is_a_stable_compaction_with_device_side_counts():
     from toda_amd import ops
     a, b = cloud(7, 70001, c=5), cloud(8, 33333, c=5)
@@ -133,7 +177,8 @@ def full_scene(kind, seed, n_boxes):
     return {"points": np.ascontiguousarray(pts[:, :4]), "gt_boxes": np.concatenate([bx, cls], 1).astype(np.float32)}
 
 
-@pytest.mark.parametrize("which", ["cutmix", "polarmix", "lasermix", "mixup_cd"])
+@pytest.mark.parametrize("which", ["cutmix", "polarmix", "lasermix", "mixup_cd", "polarmix_pitch", "polarmix_rand", "lasermix_sph",
+                                   "pseudobbox", "pseudobackground"])
 def test_device_mixers_match_oracle_at_full_c5_size(which):
     """180k-point Waymo-shape source x 35k-point nuScenes-shape target (config C5), same seed on both sides."""
     from toda_amd.pcdet.datasets.processor import point_mix
@@ -145,12 +190,23 @@ def test_device_mixers_match_oracle_at_full_c5_size(which):
         args = lambda e, r: e.polarmix(src, tgt, 2, [1.0, 2.0], 0.4, ["FIX", "RAND", "ASC_SIG"], "corner_del", rng=r)
     elif which == "lasermix":
         args = lambda e, r: e.lasermix_cyc(src, tgt, 3, 4, PC_RANGE, "corner_del", rng=r)
+    elif which == "polarmix_pitch":
+        args = lambda e, r: e.polarmix(src, tgt, 2, [1.0, 2.0], 0.4, ["FIX", "RAND", "ASC_SIG"], "corner_del", rng=r, use_pitch=True)
+    elif which == "polarmix_rand":
+        args = lambda e, r: e.polarmix(src, tgt, 1, [0.8, 1.6], 0.7, ["DESC", "RAND", "FIX"], "center", rng=r, polar_dis="RAND", pc_range=PC_RANGE)
+    elif which == "lasermix_sph":
+        args = lambda e, r: e.lasermix_sph(src, tgt, [-20, 0], [4, 5, 6], 1, rng=r)
+    elif which == "pseudobbox":
+        tgt = dict(tgt, gt_boxes=np.concatenate([tgt["gt_boxes"], src["gt_boxes"][:6] + np.float32([0.3, -0.2, 0, 0, 0, 0, 0.1, 0])], 0))
+        args = lambda e, r: e.pseudobbox(src, tgt)
+    elif which == "pseudobackground":
+        args = lambda e, r: e.pseudobackground(src, tgt)
     else:
         args = lambda e, r: e.mixup(src, tgt, 2.0, collision=True, rng=r)
     want = args(OM, np.random.RandomState(77))
     got = args(point_mix, np.random.RandomState(77))
     np.testing.assert_array_equal(got["gt_boxes"], want["gt_boxes"])
-    assert got["points"].shape == want["points"].shape and got["points"].shape[0] > 30000
+    assert got["points"].shape == want["points"].shape and got["points"].shape[0] > (25000 if which == "lasermix_sph" else 30000)
     np.testing.assert_array_equal(got["points"], want["points"])
 
 
@@ -169,8 +225,38 @@ def test_mixers_keep_cuda_tensors_on_the_device_and_wrappers_are_drop_in():
     np.random.seed(4)
     out = intra_domain_point_mixup(dict(src, frame_id="a"), dict(tgt), alpha=2)
     assert isinstance(out["points"], np.ndarray) and out["frame_id"] == "a"
+    # POLARMIX_DIS = RAND (the reference's call raises a TypeError; its swap_with_range is what runs here) and use_pitch
+    np.random.seed(5)
+    out = inter_domain_point_polarmix(src_d, tgt_d, 1, 1.5, 0.0, ["FIX"], PC_RANGE, "RAND", "center", False)
+    np.random.seed(5)
+    want = OM.polarmix(src, tgt, 1, 1.5, 0.0, ["FIX"], "center", polar_dis="RAND", pc_range=PC_RANGE)
+    np.testing.assert_array_equal(out["points"].cpu().numpy(), want["points"])
+    np.testing.assert_array_equal(out["gt_boxes"], want["gt_boxes"])
+    np.random.seed(6)
+    out = inter_domain_point_polarmix(src_d, tgt_d, 2, 1.5, 0.0, ["FIX", "FIX"], PC_RANGE, "FULL", "corner", True)
+    np.random.seed(6)
+    want = OM.polarmix(src, tgt, 2, 1.5, 0.0, ["FIX", "FIX"], "corner", use_pitch=True)
+    np.testing.assert_array_equal(out["points"].cpu().numpy(), want["points"])
     with pytest.raises(NotImplementedError):
-        inter_domain_point_polarmix(src_d, tgt_d, 1, 1.5, 0.0, ["FIX"], PC_RANGE, "RAND", "center", False)
+        inter_domain_point_polarmix(src_d, tgt_d, 1, 1.5, 0.0, ["FIX"], PC_RANGE, "HALF", "center", False)
+    # the pseudo mixes write into the target dict and return it, like the reference; spherical LaserMix through its entry point
+    from toda_amd.pcdet.datasets.processor.inter_domain_point_lasermix import inter_domain_point_lasermix
+    from toda_amd.pcdet.datasets.processor.inter_domain_point_pseudomix import inter_domain_point_pseudobackground, inter_domain_point_pseudobbox
+    t2 = dict(tgt_d)
+    out = inter_domain_point_pseudobbox(src_d, t2)
+    assert out is t2 and out["points"].is_cuda and out["frame_id"] == "b"
+    want = OM.pseudobbox(src, tgt)
+    np.testing.assert_array_equal(out["points"].cpu().numpy(), want["points"])
+    np.testing.assert_array_equal(out["gt_boxes"], want["gt_boxes"])
+    out = inter_domain_point_pseudobackground(src_d, dict(tgt_d))
+    np.testing.assert_array_equal(out["points"].cpu().numpy(), OM.pseudobackground(src, tgt)["points"])
+    np.random.seed(7)
+    out = inter_domain_point_lasermix(src_d, tgt_d, [-20, 0], [5], None, PC_RANGE, "center")
+    np.random.seed(7)
+    want = OM.lasermix_sph(src, tgt, [-20, 0], [5], "center")
+    assert out["points"].is_cuda and out["frame_id"] == "b"
+    np.testing.assert_array_equal(out["points"].cpu().numpy(), want["points"])
+    np.testing.assert_array_equal(out["gt_boxes"], want["gt_boxes"])
 
 
 def test_mix_dataset_item_matches_the_host_pipeline():
@@ -216,6 +302,53 @@ def test_mix_dataset_item_matches_the_host_pipeline():
     assert batch["points"].is_cuda and batch["points"].shape[1] == 5 and batch["points_per_sample"][0] == p.shape[0]
     voxelize_on_gpu(batch, ds.voxel_cfg)
     assert batch["voxel_coords"].shape[0] > 20000 and int(batch["voxel_coords"][:, 0].max()) == 1
+
+
+@pytest.mark.parametrize("mix_type", ["pseudobbox", "pseudobackground", "lasermix_sph"])
+def test_mix_dataset_serves_the_pseudo_mixes_and_spherical_lasermix(mix_type):
+    """MIX_TYPE pseudobbox / pseudobackground (tools/cfgs/stage1_pseudomix) and lasermix without LASERMIX_NUM_ANGLES
+    (tools/cfgs/stage1_lasermix/*_pp01.yaml) through SyntheticMixDataset, against the oracle mix on the same frames."""
+    import os
+    from toda_amd.pcdet.config import AttrDict, cfg_from_yaml_file
+    from toda_amd.pcdet.datasets import SyntheticMixDataset
+    from toda_amd.pcdet.datasets.synthetic import synth_cloud
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = AttrDict()
+    cfg_from_yaml_file(os.path.join(root, "toda_amd/tools/cfgs/models/toda_stage1_polarmix.yaml"), cfg)
+    cfg.DATA_CONFIG.POLARMIX_PROB = 1.0
+    if mix_type == "lasermix_sph":
+        cfg.DATA_CONFIG.MIX_TYPE = "lasermix"
+        cfg.DATA_CONFIG.pop("LASERMIX_NUM_ANGLES", None)
+        cfg.DATA_CONFIG.LASERMIX_NUM_AREAS = [5]
+        cfg.DATA_CONFIG.LASERMIX_PITCH_ANGLE = [-20, 0]
+    else:
+        cfg.DATA_CONFIG.MIX_TYPE = mix_type
+    ds = SyntheticMixDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    assert ds.mix_prob == 1.0 and (mix_type != "lasermix_sph" or ds.laser_num_angles is None)
+    index = 5
+    np.random.seed(123)
+    item = ds[index]
+    np.random.seed(123)
+    assert np.random.random(1) < 1.0
+    frames = []
+    for kind, idx in ((ds.source_kind, index % ds.num_source), (ds.target_kind, 100_000 + index % ds.num_target)):
+        pts, bx, _ = synth_cloud(kind, ds.seed + idx, class_count=1)
+        pts = pts[:, :4].copy()
+        pts[:, 3:4] = pts[:, 3:4] / max(pts[:, 3:4].max(), 1e-12)
+        frames.append({"points": pts, "gt_boxes": np.concatenate([bx, np.ones((len(bx), 1), np.float32)], 1)})
+    if mix_type == "lasermix_sph":
+        mixed = OM.lasermix_sph(frames[0], frames[1], [-20, 0], [5], ds.mix_inc_method)
+    else:
+        mixed = getattr(OM, mix_type)(frames[0], frames[1])
+    r = ds.point_cloud_range
+    p = mixed["points"]
+    p = p[(p[:, 0] >= r[0]) & (p[:, 0] <= r[3]) & (p[:, 1] >= r[1]) & (p[:, 1] <= r[4])]
+    keep_b = OM.boxes_with_corners_in_range(mixed["gt_boxes"], r, 1)
+    p = p[np.random.permutation(p.shape[0])]
+    np.testing.assert_array_equal(item["gt_boxes"], mixed["gt_boxes"][keep_b])
+    assert p.shape[0] > 10000 and item["points"].is_cuda
+    np.testing.assert_array_equal(item["points"].cpu().numpy(), p)
 
 
 def test_world_augmentations_on_the_device_match_reference():

@@ -135,6 +135,96 @@ points_polar_cell_kernel(const float* __restrict__ pts, int n, const int32_t* __
     cell[j] = (ci >= 0 && cj >= 0) ? ci * g.n_dis + cj : -1;
 }
 
+// ---- PolarMix with a range cut (swap_with_range) or an elevation test (swap, use_pitch) ---------------------------------
+// range = sqrt(x^2 + y^2) with every step rounded to fp32 (np.sqrt(x ** 2 + y ** 2) on fp32 columns; -ffp-contract=off)
+__device__ __forceinline__ float range_f32(float x, float y) { return sqrtf(x * x + y * y); }
+// sign * arctan2(z, range) as an fp32 value (same convention as yaw_f32: fp64 evaluation, rounded once)
+__device__ __forceinline__ float pitch_f32(float z, float range) { return (float)atan2((double)z, (double)range); }
+
+// flags[j] = yaw test & range test & elevation test
+//   yaw_mode 1: lo < yaw < hi, 2: yaw < lo | yaw > hi
+//   dis_mode 0: none, 1: range < dis_th, 2: range > dis_th      (swap_with_range, inter_domain_point_polarmix.py:101-123)
+//   pitch_range != NULL: range > 1 and -arctan2(z, range) outside [pitch_range[0], pitch_range[1]]   (swap, :81-93)
+__global__ void __launch_bounds__(PT_BLOCK)
+points_polar_select_kernel(const float* __restrict__ pts, int n, const int32_t* __restrict__ n_dev, int c, double lo, double hi,
+                           int yaw_mode, int dis_mode, double dis_th, const float* __restrict__ pitch_range,
+                           int32_t* __restrict__ flags) {
+    const int rows = eff_n(n, n_dev);
+    const int j = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (j >= rows) return;
+    const float x = pts[(size_t)j * c], y = pts[(size_t)j * c + 1];
+    const double yaw = (double)yaw_f32(x, y);
+    bool sel = yaw_mode == 1 ? ((yaw > lo) & (yaw < hi)) : ((yaw < lo) | (yaw > hi));
+    const float dis = range_f32(x, y);
+    if (dis_mode == 1) sel = sel && (double)dis < dis_th;
+    if (dis_mode == 2) sel = sel && (double)dis > dis_th;
+    if (pitch_range) {
+        const float p = -pitch_f32(pts[(size_t)j * c + 2], dis);
+        sel = sel && dis > 1.0f && (p < pitch_range[0] || p > pitch_range[1]);
+    }
+    flags[j] = sel ? 1 : 0;
+}
+
+// min / max of -arctan2(z, range) over the rows with range > 1 (pitch1[mask1].min() / .max(), :88): per-workgroup partials,
+// then one workgroup folds them - no atomics, nothing to initialise.  No such row: (+inf, -inf).
+__global__ void __launch_bounds__(PT_BLOCK)
+points_pitch_range_kernel(const float* __restrict__ pts, int n, const int32_t* __restrict__ n_dev, int c,
+                          const float* __restrict__ partial_in, int n_partial, float* __restrict__ out) {
+    __shared__ float smin[PT_BLOCK / 64], smax[PT_BLOCK / 64];
+    float lo = INFINITY, hi = -INFINITY;
+    if (partial_in) {                                       // second pass: fold the partials
+        for (int i = threadIdx.x; i < n_partial; i += PT_BLOCK) {
+            lo = fminf(lo, partial_in[2 * i]);
+            hi = fmaxf(hi, partial_in[2 * i + 1]);
+        }
+    } else {
+        const int rows = eff_n(n, n_dev);
+        for (int j = blockIdx.x * PT_BLOCK + threadIdx.x; j < rows; j += gridDim.x * PT_BLOCK) {
+            const float x = pts[(size_t)j * c], y = pts[(size_t)j * c + 1];
+            const float dis = range_f32(x, y);
+            if (dis > 1.0f) {
+                const float p = -pitch_f32(pts[(size_t)j * c + 2], dis);
+                lo = fminf(lo, p);
+                hi = fmaxf(hi, p);
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, d, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = lo, smax[threadIdx.x >> 6] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < PT_BLOCK / 64; ++w) lo = fminf(lo, smin[w]), hi = fmaxf(hi, smax[w]);
+        out[2 * blockIdx.x] = lo;
+        out[2 * blockIdx.x + 1] = hi;
+    }
+}
+
+struct PitchBands {
+    double edges[PT_MAX_EDGES];      // descending, radians
+    int n;
+    float z_offset, clip_lo, clip_hi;
+};
+
+// Spherical LaserMix (laser_mix_transform_sph, inter_domain_point_lasermix.py:40-47,62-80): elevation = arctan2(z_offset + z,
+// range) clipped to [clip_lo, clip_hi] in fp32, band i holds edges[i + 1] < elevation <= edges[i] (fp64 compare); -1: no band.
+__global__ void __launch_bounds__(PT_BLOCK)
+points_pitch_band_kernel(const float* __restrict__ pts, int n, const int32_t* __restrict__ n_dev, int c, PitchBands g,
+                         int32_t* __restrict__ band) {
+    const int rows = eff_n(n, n_dev);
+    const int j = blockIdx.x * PT_BLOCK + threadIdx.x;
+    if (j >= rows) return;
+    const float x = pts[(size_t)j * c], y = pts[(size_t)j * c + 1];
+    float p = pitch_f32(g.z_offset + pts[(size_t)j * c + 2], range_f32(x, y));
+    p = fminf(fmaxf(p, g.clip_lo), g.clip_hi);
+    int b = -1;
+    for (int i = 0; i < g.n; ++i)
+        if ((double)p > g.edges[i + 1] && (double)p <= g.edges[i]) b = i;
+    band[j] = b;
+}
+
 // ---- stable compaction appended at a device-side cursor ------------------------------------
 __global__ void __launch_bounds__(PT_BLOCK)
 select_mark_kernel(const int32_t* __restrict__ keys, int n, const int32_t* __restrict__ n_dev, int match, int invert,
@@ -261,6 +351,48 @@ extern "C" int toda_points_polar_cell(const float* points, int n, const int32_t*
     for (int i = 0; i <= n_dis; ++i) g.dis_edges[i] = dis_edges_host[i];
     g.n_yaw = n_yaw, g.n_dis = n_dis, g.phase = phase, g.dis_lo = dis_lo, g.dis_hi = dis_hi;
     hipLaunchKernelGGL(points_polar_cell_kernel, dim3(cdiv(n, PT_BLOCK)), dim3(PT_BLOCK), 0, s, points, n, n_dev, c, g, cell);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_points_polar_select(const float* points, int n, const int32_t* n_dev, int c, double lo, double hi, int yaw_mode,
+                                        int dis_mode, double dis_th, const float* pitch_range_dev, int32_t* flags, void* stream) {
+    PT_COMMON_CHECK("points_polar_select");
+    TODA_CHECK_ARG((yaw_mode == 1 || yaw_mode == 2) && dis_mode >= 0 && dis_mode <= 2, "points_polar_select: yaw_mode 1|2, dis_mode 0|1|2");
+    hipLaunchKernelGGL(points_polar_select_kernel, dim3(cdiv(n, PT_BLOCK)), dim3(PT_BLOCK), 0, s, points, n, n_dev, c, lo, hi, yaw_mode,
+                       dis_mode, dis_th, pitch_range_dev, flags);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+constexpr int PT_RANGE_BLOCKS = 256;
+
+extern "C" size_t toda_points_pitch_range_workspace_bytes(void) { return (size_t)PT_RANGE_BLOCKS * 2 * sizeof(float); }
+
+extern "C" int toda_points_pitch_range(const float* points, int n, const int32_t* n_dev, int c, float* range_dev, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    TODA_CHECK_ARG(n >= 0 && c >= 3, "points_pitch_range: need n >= 0 and at least 3 columns (x, y, z)");
+    hipStream_t s = (hipStream_t)stream;
+    if (ws_bytes < toda_points_pitch_range_workspace_bytes()) {
+        set_error("points_pitch_range: workspace %zu < required %zu", ws_bytes, toda_points_pitch_range_workspace_bytes());
+        return TODA_EWORKSPACE;
+    }
+    const int blocks = n > 0 ? (cdiv(n, PT_BLOCK) < PT_RANGE_BLOCKS ? cdiv(n, PT_BLOCK) : PT_RANGE_BLOCKS) : 1;
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL(points_pitch_range_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, points, n, n_dev, c, (const float*)nullptr, 0, partial);
+    hipLaunchKernelGGL(points_pitch_range_kernel, dim3(1), dim3(PT_BLOCK), 0, s, points, n, n_dev, c, (const float*)partial, blocks, range_dev);
+    TODA_LAUNCH_CHECK();
+    return TODA_OK;
+}
+
+extern "C" int toda_points_pitch_band(const float* points, int n, const int32_t* n_dev, int c, float z_offset, float clip_lo,
+                                      float clip_hi, const double* edges_host, int n_bands, int32_t* band, void* stream) {
+    PT_COMMON_CHECK("points_pitch_band");
+    TODA_CHECK_ARG(n_bands >= 1 && n_bands < PT_MAX_EDGES, "points_pitch_band: 1..32 bands");
+    PitchBands g;
+    for (int i = 0; i <= n_bands; ++i) g.edges[i] = edges_host[i];
+    g.n = n_bands, g.z_offset = z_offset, g.clip_lo = clip_lo, g.clip_hi = clip_hi;
+    hipLaunchKernelGGL(points_pitch_band_kernel, dim3(cdiv(n, PT_BLOCK)), dim3(PT_BLOCK), 0, s, points, n, n_dev, c, g, band);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
 }

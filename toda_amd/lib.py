@@ -98,6 +98,10 @@ SIGNATURES = {
     "toda_points_sector": (_i, [_vp, _i, _vp, _i, _dbl, _dbl, _vp, _vp]),
     "toda_points_rect": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "toda_points_polar_cell": (_i, [_vp, _i, _vp, _i, C.c_float, _vp, _i, _vp, _i, C.c_float, C.c_float, _vp, _vp]),
+    "toda_points_polar_select": (_i, [_vp, _i, _vp, _i, _dbl, _dbl, _i, _i, _dbl, _vp, _vp, _vp]),
+    "toda_points_pitch_range_workspace_bytes": (_sz, []),
+    "toda_points_pitch_range": (_i, [_vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "toda_points_pitch_band": (_i, [_vp, _i, _vp, _i, C.c_float, C.c_float, C.c_float, _vp, _i, _vp, _vp]),
     "toda_rows_select_workspace_bytes": (_sz, [_i]),
     "toda_rows_select_append": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "toda_points_rotate_z": (_i, [_vp, _i, _vp, _i, _dbl, _dbl, _vp, _vp]),

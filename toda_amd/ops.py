@@ -1801,6 +1801,43 @@ def points_polar_cell(points, phase, yaw_edges, dis_edges, dis_lo, dis_hi, n_dev
     return cell
 
 
+def points_polar_select(points, lo, hi, outside=False, dis_mode=0, dis_th=0.0, pitch_range=None, n_dev=None):
+    """flags of PolarMix's richer sector tests (C ABI: toda_points_polar_select): yaw inside (lo, hi) or - `outside` - beyond it,
+    optionally cut at a range (dis_mode 1: nearer than dis_th, 2: farther) and / or kept only where the elevation lies outside
+    `pitch_range` (device float[2] from points_pitch_range)."""
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    flags = torch.zeros((n,), dtype=torch.int32, device=points.device)
+    rc = lib.toda_points_polar_select(L.ptr(points), n, nd, c, float(lo), float(hi), 2 if outside else 1, int(dis_mode), float(dis_th),
+                                      L.ptr(pitch_range) if pitch_range is not None else None, L.ptr(flags), L.stream())
+    L.check(rc, "toda_points_polar_select")
+    return flags
+
+
+def points_pitch_range(points, n_dev=None):
+    """Device float[2]: min and max of -atan2(z, range) over the rows beyond 1 m of range (no host sync)."""
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    out = torch.empty((2,), dtype=torch.float32, device=points.device)
+    ws_bytes = lib.toda_points_pitch_range_workspace_bytes()
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device)
+    rc = lib.toda_points_pitch_range(L.ptr(points), n, nd, c, L.ptr(out), L.ptr(ws), ws_bytes, L.stream())
+    L.check(rc, "toda_points_pitch_range")
+    return out
+
+
+def points_pitch_band(points, z_offset, clip_lo, clip_hi, edges, n_dev=None):
+    """Elevation band of every row (spherical LaserMix): `edges` descending, radians; -1 outside every band."""
+    lib = L.load()
+    n, c, nd = _rows(points, n_dev)
+    band = torch.full((n,), -1, dtype=torch.int32, device=points.device)
+    ed = L.host_f64(edges)
+    rc = lib.toda_points_pitch_band(L.ptr(points), n, nd, c, float(z_offset), float(clip_lo), float(clip_hi), L.hptr(ed), len(edges) - 1,
+                                    L.ptr(band), L.stream())
+    L.check(rc, "toda_points_pitch_band")
+    return band
+
+
 def points_rotate_z(points, cosv, sinv, n_dev=None):
     lib = L.load()
     n, c, nd = _rows(points, n_dev)

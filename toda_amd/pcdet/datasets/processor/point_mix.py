@@ -1,9 +1,10 @@
 """TODA's mixing processors with the point work on the MI355X.
 
 The reference mixes two scenes with numpy and single-thread C++ inside DataLoader workers
-(pcdet/datasets/processor/inter_domain_point_{cutmix,polarmix,lasermix}.py, intra_domain_point_mixup.py).
+(pcdet/datasets/processor/inter_domain_point_{cutmix,polarmix,lasermix,pseudomix}.py, intra_domain_point_mixup.py).
 Here both raw clouds live in HBM; every per-point decision is a streaming HIP kernel
-(csrc/points.hip: azimuth sector, crop rectangle, LaserMix cell, point-in-box) and every
+(csrc/points.hip: azimuth sector with range cut / elevation test, crop rectangle, LaserMix cylinder cell and elevation band,
+point-in-box) and every
 `points[mask]` / `np.delete` / `np.concatenate` is a stable compaction appended at a device-side cursor
 (`ops.RowBuffer`), so a mixed scene is assembled without leaving the device and handed to the voxeliser.
 The box bookkeeping (a few dozen rows) stays on the host, written with the reference's fp32/fp64
@@ -116,8 +117,10 @@ def _in_sector(yaw, lo, hi):
     return (yaw > F32(lo)) & (yaw < F32(hi))
 
 
-def _swap_sector(cloud1, cloud2, lo, hi, box1, box2, inc_method):
-    """One sector of PolarMix's scene-level swap (inter_domain_point_polarmix.py:44-99)."""
+def _swap_sector(cloud1, cloud2, lo, hi, box1, box2, inc_method, use_pitch=False):
+    """One sector of PolarMix's scene-level swap (inter_domain_point_polarmix.py:44-99).  use_pitch (:81-93): cloud 2 also gives
+    its points OUTSIDE the sector whose elevation lies outside cloud 1's elevation span (both judged beyond 1 m of range);
+    they are placed before the sector's points.  The span is reduced on the device and read by the next kernel there."""
     if inc_method == "center":
         out1 = _in_sector(_yaw32(box1[:, 0], box1[:, 1]), lo, hi)
         in2 = _in_sector(_yaw32(box2[:, 0], box2[:, 1]), lo, hi)
@@ -136,8 +139,41 @@ def _swap_sector(cloud1, cloud2, lo, hi, box1, box2, inc_method):
     f1 = ops.points_sector(cloud1.data, F32(lo), F32(hi), cloud1.n_dev)
     f2 = ops.points_sector(cloud2.data, F32(lo), F32(hi), cloud2.n_dev)
     out = ops.RowBuffer(cloud1.cap + cloud2.cap, cloud1.data.shape[1], cloud1.data.device)
-    out.append(cloud1.data, f1, 1, invert=True, n_dev=cloud1.n_dev).append(cloud2.data, f2, 1, n_dev=cloud2.n_dev)
+    out.append(cloud1.data, f1, 1, invert=True, n_dev=cloud1.n_dev)
+    if use_pitch:
+        span = ops.points_pitch_range(cloud1.data, cloud1.n_dev)
+        beyond = ops.points_polar_select(cloud2.data, F32(lo), F32(hi), outside=True, pitch_range=span, n_dev=cloud2.n_dev)
+        out.append(cloud2.data, beyond, 1, n_dev=cloud2.n_dev)
+    out.append(cloud2.data, f2, 1, n_dev=cloud2.n_dev)
     return _as_cloud(out), boxes
+
+
+def _swap_sector_range(cloud1, cloud2, lo, hi, box1, box2, pc_range, rng):
+    """swap_with_range (inter_domain_point_polarmix.py:101-151): the sector is cut at a random range; the near part (threshold
+    beyond 40 % of the x range) or the far part changes hands, boxes follow by centre."""
+    r_max = F32(np.asarray(pc_range, F32)[3])
+    dis_th = F32(rng.random()) * r_max                                # python float * np.float32: fp32
+    mode = 1 if F32(dis_th / r_max) > F32(0.4) else 2
+
+    def chosen(x, y):
+        x, y = np.asarray(x, F32), np.asarray(y, F32)
+        d = np.sqrt(x * x + y * y)
+        return _in_sector(_yaw32(x, y), lo, hi) & ((d < dis_th) if mode == 1 else (d > dis_th))
+
+    b1, b2 = chosen(box1[:, 0], box1[:, 1]), chosen(box2[:, 0], box2[:, 1])
+    f1 = ops.points_polar_select(cloud1.data, F32(lo), F32(hi), dis_mode=mode, dis_th=dis_th, n_dev=cloud1.n_dev)
+    f2 = ops.points_polar_select(cloud2.data, F32(lo), F32(hi), dis_mode=mode, dis_th=dis_th, n_dev=cloud2.n_dev)
+    out = ops.RowBuffer(cloud1.cap + cloud2.cap, cloud1.data.shape[1], cloud1.data.device)
+    out.append(cloud1.data, f1, 1, invert=True, n_dev=cloud1.n_dev).append(cloud2.data, f2, 1, n_dev=cloud2.n_dev)
+    return _as_cloud(out), np.concatenate([box1[~b1], box2[b2]], 0)
+
+
+def polar_swap_with_range(pt1, pt2, lo, hi, box1, box2, pc_range, rng=np.random):
+    """swap_with_range as a function of its own (numpy in -> numpy out, CUDA tensors stay on the device)."""
+    p1, as_numpy = _upload(pt1)
+    p2, _ = _upload(pt2)
+    cloud, boxes = _swap_sector_range(_Cloud(p1), _Cloud(p2), lo, hi, box1, box2, pc_range, rng)
+    return _deliver(cloud.data[:int(cloud.n_dev.item())], as_numpy), boxes
 
 
 def polarmix_sectors(degree, train_percent, update_methods, rng):
@@ -203,8 +239,14 @@ def _rotate_paste(cloud2, boxes2, omegas, placed_boxes):
     return _as_cloud(pasted), np.concatenate(new_boxes, 0)
 
 
-def polarmix(source, target, rot_copy_num, degree, train_percent, update_methods, inc_method="center", rng=np.random):
-    """Reference inter_domain_point_polarmix.py:193-300 with POLARMIX_DIS = FULL."""
+def polarmix(source, target, rot_copy_num, degree, train_percent, update_methods, inc_method="center", rng=np.random,
+             polar_dis="FULL", use_pitch=False, pc_range=None):
+    """Reference inter_domain_point_polarmix.py:193-300.  POLARMIX_DIS = RAND: the reference's own call of swap_with_range
+    carries a keyword that function does not take (:215-220, a TypeError as shipped); this is that call without it."""
+    if polar_dis not in ("FULL", "RAND"):
+        raise NotImplementedError(polar_dis)
+    if polar_dis == "RAND" and pc_range is None:
+        raise ValueError("POLARMIX_DIS = RAND needs the point cloud range")
     sp, as_numpy = _upload(source["points"])
     tp, _ = _upload(target["points"])
     sectors = polarmix_sectors(degree, train_percent, update_methods, rng)
@@ -212,7 +254,10 @@ def polarmix(source, target, rot_copy_num, degree, train_percent, update_methods
     cloud, boxes, tcloud = _Cloud(sp), source["gt_boxes"], _Cloud(tp)
     rng.random()                              # the reference draws (and ignores) one number per stage: `random() < 1.0`
     for lo, hi in sectors:
-        cloud, boxes = _swap_sector(cloud, tcloud, lo, hi, boxes, target["gt_boxes"], inc_method)
+        if polar_dis == "FULL":
+            cloud, boxes = _swap_sector(cloud, tcloud, lo, hi, boxes, target["gt_boxes"], inc_method, use_pitch)
+        else:
+            cloud, boxes = _swap_sector_range(cloud, tcloud, lo, hi, boxes, target["gt_boxes"], pc_range, rng)
     rng.random()
     if len(omegas) == 0:
         raise ValueError("POLARMIX_RC_NUM must be >= 1 (the reference concatenates an empty list otherwise)")
@@ -278,6 +323,60 @@ def lasermix_cyc(source, target, num_areas, num_angles, pc_range, inc_method="ce
                 raise NotImplementedError(inc_method)
             turn += 1
     return {"points": _deliver(out.finish(), as_numpy), "gt_boxes": np.concatenate(out_boxes, 0)}
+
+
+def lasermix_sph(source, target, pitch_angles, num_areas, order=0, rng=np.random):
+    """Reference laser_mix_transform_sph (inter_domain_point_lasermix.py:22-85): elevation bands (degrees, top to bottom)
+    alternate between the scenes, band i from `source` when i % 2 == order.  Elevation = arctan2(z - 1.8, range) in radians,
+    clipped against the DEGREE bounds +- 1e-5 exactly as the reference does, band edges compared in fp64.  The entry point
+    hands inc_method to `order` (:186-192); a string never equals i % 2, so every band then comes from the target."""
+    sp, as_numpy = _upload(source["points"])
+    tp, _ = _upload(target["points"])
+    lo, hi = F32(pitch_angles[0] + 1e-5), F32(pitch_angles[1] - 1e-5)
+    n_bands = rng.choice(num_areas, size=1)[0]
+    edges = np.linspace(pitch_angles[1], pitch_angles[0], n_bands + 1) / 180 * np.pi
+
+    def box_elevation(b):
+        x, y = np.asarray(b[:, 0], F32), np.asarray(b[:, 1], F32)
+        rho = np.sqrt(x * x + y * y)
+        e = np.arctan2((F32(-1.8) + np.asarray(b[:, 2], F32)).astype(np.float64), rho.astype(np.float64)).astype(F32)
+        return np.clip(e, lo, hi)
+
+    scenes = [dict(pts=p, box=d["gt_boxes"], band=ops.points_pitch_band(p, F32(-1.8), lo, hi, edges), ev=box_elevation(d["gt_boxes"]))
+              for p, d in ((sp, source), (tp, target))]
+    out = ops.RowBuffer(sp.shape[0] + tp.shape[0], sp.shape[1], sp.device)
+    out_boxes = []
+    for i in range(n_bands):
+        s = scenes[0] if i % 2 == order else scenes[1]
+        out.append(s["pts"], s["band"], i)
+        out_boxes.append(s["box"][(s["ev"] > edges[i + 1]) & (s["ev"] <= edges[i])])
+    return {"points": _deliver(out.finish(), as_numpy), "gt_boxes": np.concatenate(out_boxes, 0)}
+
+
+# --------------------------------------------------------------------------------- pseudo mixes
+def pseudobbox(source, target):
+    """Reference inter_domain_point_pseudobbox (inter_domain_point_pseudomix.py:19-47): the target's boxes that touch no source
+    box in BEV are pasted, with the points inside them, into the source scene, whose own points inside those boxes go."""
+    sp, as_numpy = _upload(source["points"])
+    tp, _ = _upload(target["points"])
+    sb, tb = source["gt_boxes"], target["gt_boxes"]
+    paste = tb[_bev_overlap(sb, tb, sp.device).sum(0) == 0]
+    pb = _boxes_dev(paste, sp.device)
+    out = ops.RowBuffer(sp.shape[0] + tp.shape[0], sp.shape[1], sp.device)
+    out.append(sp, ops.points_in_boxes(sp, pb, 0), 1, invert=True).append(tp, ops.points_in_boxes(tp, pb, 0), 1)
+    return {"points": _deliver(out.finish(), as_numpy), "gt_boxes": np.concatenate([sb, paste], 0)}
+
+
+def pseudobackground(source, target):
+    """Reference inter_domain_point_pseudobackground (:49-68): the source's objects (points inside its boxes) on the target's
+    background (points outside the target's boxes); the boxes are the source's."""
+    sp, as_numpy = _upload(source["points"])
+    tp, _ = _upload(target["points"])
+    sb, tb = source["gt_boxes"], target["gt_boxes"]
+    out = ops.RowBuffer(sp.shape[0] + tp.shape[0], sp.shape[1], sp.device)
+    out.append(sp, ops.points_in_boxes(sp, _boxes_dev(sb, sp.device), 0), 1)
+    out.append(tp, ops.points_in_boxes(tp, _boxes_dev(tb, sp.device), 0), 1, invert=True)
+    return {"points": _deliver(out.finish(), as_numpy), "gt_boxes": sb}
 
 
 # --------------------------------------------------------------------------------------- MixUp

@@ -7,9 +7,11 @@ MI355X layout: both raw clouds are uploaded once and stay in HBM; feature encodi
 Use with num_workers = 0 (the training process owns the GPU).
 
 Config keys (as in the reference YAMLs, e.g. tools/cfgs/stage1_targetmix/*.yaml):
-  MIX_TYPE: polarmix | cutmix | cutpolarmix | lasermix        MIX_INC_METHOD: center | corner | corner_del
-  POLARMIX_PROB / CUTMIX_PROB / LASERMIX_PROB (probability of a mixed sample), POLARMIX_DEGREE,
-  POLARMIX_RC_NUM, POLARMIX_UPDATE_METHOD, POLARMIX_DIS (FULL), LASERMIX_NUM_AREAS, LASERMIX_NUM_ANGLES
+  MIX_TYPE: polarmix | cutmix | cutpolarmix | lasermix | pseudobbox | pseudobackground     MIX_INC_METHOD: center | corner | corner_del
+  POLARMIX_PROB (CUTMIX_PROB for cutmix; the LaserMix and pseudo-mix datasets of the reference read POLARMIX_PROB too,
+  waymo_nus_lasermix_dataset.py:153) = probability of a mixed sample, POLARMIX_DEGREE, POLARMIX_RC_NUM, POLARMIX_UPDATE_METHOD,
+  POLARMIX_DIS (FULL | RAND), POLARMIX_USE_PITCH, LASERMIX_NUM_AREAS, LASERMIX_NUM_ANGLES (absent: the spherical variant,
+  tools/cfgs/stage1_lasermix/*_pp01.yaml), LASERMIX_PITCH_ANGLE
   SYNTHETIC: {SOURCE_KIND, TARGET_KIND, NUM_SOURCE, NUM_TARGET, SEED}   (no real dataset on the box)
 """
 import numpy as np
@@ -20,6 +22,7 @@ from .dataset import DatasetTemplate
 from .processor.inter_domain_point_cutmix import inter_domain_point_cutmix
 from .processor.inter_domain_point_lasermix import inter_domain_point_lasermix
 from .processor.inter_domain_point_polarmix import inter_domain_point_polarmix
+from .processor.inter_domain_point_pseudomix import inter_domain_point_pseudobackground, inter_domain_point_pseudobbox
 from .synthetic import synth_cloud
 
 
@@ -33,17 +36,22 @@ class SyntheticMixDataset(DatasetTemplate):
         self.num_points = {self.source_kind: syn.get("NUM_POINTS_SOURCE", None), self.target_kind: syn.get("NUM_POINTS_TARGET", None)}
         self.on_device = bool(dataset_cfg.get("MIX_ON_DEVICE", True))
         self.mix_type = dataset_cfg.get("MIX_TYPE", "polarmix")
-        self.mix_prob = float(dataset_cfg.get({"polarmix": "POLARMIX_PROB", "cutmix": "CUTMIX_PROB", "cutpolarmix": "POLARMIX_PROB",
-                                               "lasermix": "LASERMIX_PROB"}[self.mix_type], 0.5))
+        if self.mix_type not in ("polarmix", "cutmix", "cutpolarmix", "lasermix", "pseudobbox", "pseudobackground"):
+            raise NotImplementedError(self.mix_type)
+        prob_key = "CUTMIX_PROB" if self.mix_type == "cutmix" else "POLARMIX_PROB"
+        if self.mix_type == "lasermix" and "LASERMIX_PROB" in dataset_cfg:       # this repo's earlier spelling
+            prob_key = "LASERMIX_PROB"
+        self.mix_prob = float(dataset_cfg.get(prob_key, 0.5))
         self.mix_inc_method = dataset_cfg.get("MIX_INC_METHOD", "center")
         self.polarmix_rot_copy_num = int(dataset_cfg.get("POLARMIX_RC_NUM", 1))
         self.polarmix_degree = dataset_cfg.get("POLARMIX_DEGREE", 1.570796)
         self.polarmix_update_method = list(dataset_cfg.get("POLARMIX_UPDATE_METHOD", ["FIX", "FIX", "FIX"]))
         self.polarmix_dis = dataset_cfg.get("POLARMIX_DIS", "FULL")
         self.polarmix_use_pitch = bool(dataset_cfg.get("POLARMIX_USE_PITCH", False))
-        self.laser_pitch_angle = dataset_cfg.get("LASERMIX_PITCH_ANGLE", None)
+        # defaults of waymo_nus_lasermix_dataset.py:34-36 (no LASERMIX_NUM_ANGLES: the spherical variant)
+        self.laser_pitch_angle = dataset_cfg.get("LASERMIX_PITCH_ANGLE", [-20, 0])
         self.laser_num_areas = dataset_cfg.get("LASERMIX_NUM_AREAS", 3)
-        self.laser_num_angles = dataset_cfg.get("LASERMIX_NUM_ANGLES", 2)
+        self.laser_num_angles = dataset_cfg.get("LASERMIX_NUM_ANGLES", None)
         self.cache_frames = bool(dataset_cfg.get("CACHE_FRAMES", False))   # keep generated frames resident (bench: inputs in HBM)
         self._cache = {}
         self.train_percent = 0.0          # the trainer moves it from 0 to 1 (reference train_utils: cur_it / total_it)
@@ -88,6 +96,10 @@ class SyntheticMixDataset(DatasetTemplate):
         if kind == "lasermix":
             return inter_domain_point_lasermix(source, target, self.laser_pitch_angle, self.laser_num_areas, self.laser_num_angles,
                                                self.point_cloud_range, self.mix_inc_method)
+        if kind == "pseudobbox":
+            return inter_domain_point_pseudobbox(source, target)
+        if kind == "pseudobackground":
+            return inter_domain_point_pseudobackground(source, target)
         raise NotImplementedError(kind)
 
     def __getitem__(self, index):

@@ -354,6 +354,15 @@ int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const 
 int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual /*nullable*/, const float* stats,
                          const float* gamma, int n, int c, int relu, double* sums, float* dx,
                          float* dres /*nullable*/, void* stream);
+/* ... and with the column sums of dx, dx_colsum[0:c] = sum over rows of dx: the bias gradient of the convolution that produced
+ * x (SparseBasicBlock's convolutions have a bias, spconv_backbone.py:37-40; autograd's `grad_output.sum(0)` pass over dx
+ * disappears).  Taken while dx is written; fixed-order fold (deterministic).  colsum_ws: toda_rows_bn_bwd_colsum_doubles(n, c)
+ * doubles; both pointers NULL: exactly toda_rows_bn_bwd_res. */
+size_t toda_rows_bn_bwd_colsum_doubles(int n, int c);
+int toda_rows_bn_bwd_res_colsum(const float* dy, const float* x, const float* residual /*nullable*/, const float* stats,
+                                const float* gamma, int n, int c, int relu, double* sums, float* dx,
+                                float* dres /*nullable*/, double* colsum_ws /*nullable*/, float* dx_colsum /*nullable*/,
+                                void* stream);
 
 /* Single-pass training-mode nn.BatchNorm2d (+ nn.ReLU) of the BEV neck and heads (base_bev_backbone.py:37-58,
  * center_head.py:20-28, 73-80; replaces torch's batch_norm + relu_ pair and their backward): the values of a channel sit in

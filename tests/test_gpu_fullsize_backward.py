@@ -64,6 +64,96 @@ def test_full_size_rows_bn_backward_matches_float64(n, c, residual):
     assert rel(mine.running_var.cpu().numpy(), ref.running_var.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("n,c,residual", [(389533, 64, True), (97511, 128, False), (1000, 16, False), (3, 4, True)])
+def test_rows_bn_backward_column_sums_of_dx_are_the_bias_gradient(n, c, residual):
+    """toda_rows_bn_bwd_res_colsum: dx and the parameter gradients are those of toda_rows_bn_bwd_res bit for bit, and dx_colsum is
+    the sum of dx over the rows.  With true batch statistics that sum is rounding noise (BatchNorm's input gradient sums to zero),
+    so the kernel is also called with a mean that is NOT the batch mean: then every channel has its own, large sum."""
+    from toda_amd import lib as L
+
+    lib = L.load()
+    rng = np.random.default_rng(n * 7 + c)
+    x = torch.from_numpy((rng.standard_normal((n, c)) * 1.3 + 0.1).astype(np.float32)).cuda()
+    g = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).cuda() + 0.5 * x      # correlated with x: a large d gamma
+    r = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).cuda() if residual else None
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).cuda()
+    beta = torch.from_numpy(rng.uniform(-0.5, 0.5, c).astype(np.float32)).cuda()
+    for shift_mean in (0.0, 0.25):
+        mean = x.double().mean(0) + shift_mean * torch.arange(1, c + 1, device="cuda", dtype=torch.float64) / c
+        invstd = 1.0 / torch.sqrt(x.double().var(0, unbiased=False) + 1e-3)
+        scale = gamma.double() * invstd
+        stats = torch.stack([mean, invstd, scale, beta.double() - mean * scale]).float().contiguous()
+        outs = []
+        for with_colsum in (False, True):
+            sums = torch.zeros((lib.toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device="cuda")
+            dx, dres = torch.empty_like(x), (torch.empty_like(x) if residual else None)
+            if with_colsum:
+                ws = torch.empty((lib.toda_rows_bn_bwd_colsum_doubles(n, c),), dtype=torch.float64, device="cuda")
+                cs = torch.full((c,), float("nan"), device="cuda")
+                rc = lib.toda_rows_bn_bwd_res_colsum(L.ptr(g), L.ptr(x), L.ptr(r), L.ptr(stats), L.ptr(gamma), n, c, 1, L.ptr(sums), L.ptr(dx),
+                                                     L.ptr(dres), L.ptr(ws), L.ptr(cs), L.stream())
+            else:
+                cs = None
+                rc = lib.toda_rows_bn_bwd_res(L.ptr(g), L.ptr(x), L.ptr(r), L.ptr(stats), L.ptr(gamma), n, c, 1, L.ptr(sums), L.ptr(dx), L.ptr(dres),
+                                              L.stream())
+            L.check(rc, "rows_bn_bwd")
+            outs.append((dx, dres, sums[:2 * c].clone(), cs))
+        (dx0, dres0, s0, _), (dx1, dres1, s1, cs) = outs
+        assert torch.equal(dx0, dx1) and torch.equal(s0, s1) and (not residual or torch.equal(dres0, dres1))
+        want = dx1.double().sum(0)
+        noise = dx1.double().abs().sum(0) * 2e-7 + 1e-30
+        assert bool(((cs.double() - want).abs() <= noise).all()), float(((cs.double() - want).abs() / noise).max())
+        if shift_mean and n > 100:
+            assert float(want.abs().min()) > 1e2 * float(noise.max())          # a discriminating case: channel sums far from zero and distinct
+    # a second call gives the same bits (fixed-order fold)
+    cs2 = torch.empty_like(cs)
+    rc = lib.toda_rows_bn_bwd_res_colsum(L.ptr(g), L.ptr(x), L.ptr(r), L.ptr(stats), L.ptr(gamma), n, c, 1, L.ptr(sums), L.ptr(dx), L.ptr(dres),
+                                         L.ptr(ws), L.ptr(cs2), L.stream())
+    L.check(rc, "rows_bn_bwd")
+    assert torch.equal(cs, cs2)
+
+
+def test_res_block_bias_gradients_come_from_the_bn_backward():
+    """SparseBasicBlock (convolutions WITH bias, reference spconv_backbone.py:37-40): the bias gradients are the column sums the
+    BatchNorm backward leaves behind - same values (to the rounding noise of a sum that is zero in exact arithmetic) as autograd's
+    own grad_output.sum(0), and no torch reduction over the rows is launched for them."""
+    import functools
+    from toda_amd import ops, spconv
+    from toda_amd.pcdet.models.backbones_3d.spconv_backbone import SparseBasicBlock
+
+    rng = np.random.default_rng(5)
+    shape = (16, 80, 80)
+    cells = rng.choice(shape[0] * shape[1] * shape[2], 30000, replace=False)
+    idx = np.stack([np.zeros_like(cells), cells // (shape[1] * shape[2]), cells // shape[2] % shape[1], cells % shape[2]], 1).astype(np.int32)
+    feats = rng.standard_normal((len(idx), 64)).astype(np.float32)
+    norm = functools.partial(torch.nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+    torch.manual_seed(0)
+    block = SparseBasicBlock(64, 64, norm_fn=norm, indice_key="res").cuda().train()
+    gy = torch.from_numpy(rng.standard_normal(feats.shape).astype(np.float32)).cuda()      # SubM: the output has the input's rows
+    grads = {}
+    orig = ops._take_colsum
+    for flag in (True, False):
+        ops.BN_BWD_COLSUM = flag
+        block.zero_grad(set_to_none=True)
+        taken = []
+        ops._take_colsum = lambda gout: taken.append(orig(gout)) or taken[-1]
+        try:
+            x = spconv.SparseConvTensor(torch.from_numpy(feats).cuda().requires_grad_(True), torch.from_numpy(idx).cuda(), shape, 1)
+            block(x).features.backward(gy)
+        finally:
+            ops._take_colsum = orig
+            ops.BN_BWD_COLSUM = True
+        grads[flag] = {k: p.grad.clone() for k, p in block.named_parameters()}, [t is not None for t in taken]
+    on, off = grads[True], grads[False]
+    assert on[1] == [True, True] and off[1] == [False, False]              # conv2's and conv1's backward, in that order
+    for k in on[0]:
+        if k.endswith("conv1.bias") or k.endswith("conv2.bias"):
+            scale = float(block.get_parameter(k.replace("bias", "weight")).grad.abs().max())
+            assert float((on[0][k] - off[0][k]).abs().max()) < 1e-4 * scale      # both are the noise of a zero sum
+        else:
+            assert torch.equal(on[0][k], off[0][k]), k
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 188, 188), (2, 256, 94, 94)])
 def test_full_size_bn2d_backward_matches_float64(shape):
     from toda_amd import ops

@@ -221,7 +221,8 @@ rows_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict_
 __global__ void __launch_bounds__(DN_BLOCK)
 rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__ x, const f32x4* __restrict__ res,
                          const float* __restrict__ stats, const float* __restrict__ gamma, double* __restrict__ sums,
-                         long long n4, int c, int n, int relu, f32x4* __restrict__ dx, f32x4* __restrict__ dres) {
+                         long long n4, int c, int n, int relu, f32x4* __restrict__ dx, f32x4* __restrict__ dres,
+                         double* __restrict__ colsum_part) {
     // the parameter gradients as float32 for the caller (sum dz = d beta, sum dz * xhat = d gamma): written over the per-block
     // scratch behind the 2c double results, which the fold has finished with
     if (blockIdx.x == 0 && threadIdx.x < 2 * c) reinterpret_cast<float*>(sums + 2 * c)[threadIdx.x] = (float)sums[threadIdx.x];
@@ -241,6 +242,7 @@ rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__
         m2[j] = (float)(sums[c + ch + j] * (double)inv_n);
     }
     const f32x4 k1 = ga * is, k2 = is * m2;  // xhat * m2 = (x - mu) * (is * m2)
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     for (long long t = t0; t < n4; t += stride) {
         const f32x4 g = dy[t], xv = x[t];
         const f32x4 rv = res ? res[t] : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -254,8 +256,40 @@ rows_bn_bwd_apply_kernel(const f32x4* __restrict__ dy, const f32x4* __restrict__
             out[j] = k1[j] * (dz - m1[j] - (xv[j] - mu[j]) * k2[j]);
         }
         dx[t] = out;
+        csum += out;
         if (dres) dres[t] = dzv;   // gradient of the shortcut branch
     }
+    // Column sums of dx = the bias gradient of the convolution that produced x (SparseBasicBlock's convolutions carry a bias,
+    // reference spconv_backbone.py:37-40; in exact arithmetic it is zero - BatchNorm's input gradient sums to zero per channel -
+    // and the reference's autograd returns the rounding noise of that sum; so does this): fp32 over a thread's rows, fp64 across
+    // the workgroup, per-workgroup partials [c][gridDim.x] folded in fixed order by colsum_fold_kernel.
+    if (colsum_part) {
+        __shared__ float cs[DN_BLOCK][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[threadIdx.x][j] = csum[j];
+        __syncthreads();
+        if (threadIdx.x < c) {
+            const int lanes = c >> 2, cl = threadIdx.x >> 2, j = threadIdx.x & 3;
+            double acc = 0.0;
+            for (int t = cl; t < DN_BLOCK; t += lanes) acc += (double)cs[t][j];   // DN_BLOCK % lanes == 0: thread t holds channels 4 (t % lanes) ..
+            colsum_part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = acc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(DN_BLOCK)
+colsum_fold_kernel(const double* __restrict__ part, int blocks, float* __restrict__ out) {
+    __shared__ double sh[DN_BLOCK];
+    const double* src = part + (size_t)blockIdx.x * blocks;
+    double acc = 0.0;
+    for (int g = threadIdx.x; g < blocks; g += DN_BLOCK) acc += src[g];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = DN_BLOCK / 2; w > 0; w >>= 1) {
+        if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)sh[0];
 }
 
 // one block: batch statistics -> (mean, invstd, scale, shift) + running-stat update, exactly
@@ -421,14 +455,21 @@ extern "C" int toda_rows_affine_act(const float* x, const float* scale, const fl
     return TODA_OK;
 }
 
-extern "C" int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual, const float* stats,
-                                    const float* gamma, int n, int c, int relu, double* sums, float* dx, float* dres,
-                                    void* stream) {
+extern "C" size_t toda_rows_bn_bwd_colsum_doubles(int n, int c) {
+    if (n <= 0 || c < 4) return 1;
+    return (size_t)c * ew_grid((long long)n * c / 4, c);
+}
+
+extern "C" int toda_rows_bn_bwd_res_colsum(const float* dy, const float* x, const float* residual, const float* stats,
+                                           const float* gamma, int n, int c, int relu, double* sums, float* dx, float* dres,
+                                           double* colsum_ws, float* dx_colsum, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    TODA_CHECK_ARG((colsum_ws == nullptr) == (dx_colsum == nullptr), "rows_bn_bwd: colsum workspace and result go together");
     TODA_CHECK_ARG(c >= 4 && c % 4 == 0 && c <= DN_BLOCK / 2 && DN_BLOCK % c == 0,
                    "rows_bn_bwd: channels must be a multiple of 4 dividing 256, <= 128 (got %d)", c);
     if (n <= 0) {
         TODA_HIP(hipMemsetAsync(sums, 0, 3 * c * sizeof(double), s));      // results + their float32 copy
+        if (dx_colsum) TODA_HIP(hipMemsetAsync(dx_colsum, 0, c * sizeof(float), s));
         return TODA_OK;
     }
     int blocks, rpb;
@@ -436,10 +477,18 @@ extern "C" int toda_rows_bn_bwd_res(const float* dy, const float* x, const float
     hipLaunchKernelGGL(rows_bn_bwd_reduce_kernel, dim3(blocks), dim3(DN_BLOCK), 0, s, dy, x, residual, stats, n, c, relu, rpb, sums);
     hipLaunchKernelGGL(fold_partials_kernel, dim3(2 * c), dim3(DN_BLOCK), 0, s, sums, blocks, 2 * c);
     const long long n4 = (long long)n * c / 4;
-    hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3(ew_grid(n4, c)), dim3(DN_BLOCK), 0, s, (const f32x4*)dy,
-                       (const f32x4*)x, (const f32x4*)residual, stats, gamma, sums, n4, c, n, relu, (f32x4*)dx, (f32x4*)dres);
+    const int grid = ew_grid(n4, c);
+    hipLaunchKernelGGL(rows_bn_bwd_apply_kernel, dim3(grid), dim3(DN_BLOCK), 0, s, (const f32x4*)dy,
+                       (const f32x4*)x, (const f32x4*)residual, stats, gamma, sums, n4, c, n, relu, (f32x4*)dx, (f32x4*)dres, colsum_ws);
+    if (dx_colsum) hipLaunchKernelGGL(colsum_fold_kernel, dim3(c), dim3(DN_BLOCK), 0, s, (const double*)colsum_ws, grid, dx_colsum);
     TODA_LAUNCH_CHECK();
     return TODA_OK;
+}
+
+extern "C" int toda_rows_bn_bwd_res(const float* dy, const float* x, const float* residual, const float* stats,
+                                    const float* gamma, int n, int c, int relu, double* sums, float* dx, float* dres,
+                                    void* stream) {
+    return toda_rows_bn_bwd_res_colsum(dy, x, residual, stats, gamma, n, c, relu, sums, dx, dres, nullptr, nullptr, stream);
 }
 
 extern "C" int toda_rows_bn_bwd(const float* dy, const float* x, const float* stats, const float* gamma, int n, int c,

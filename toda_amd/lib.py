@@ -72,6 +72,8 @@ SIGNATURES = {
     "toda_bn_finalize_partials": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "toda_rows_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_rows_bn_bwd_res": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "toda_rows_bn_bwd_colsum_doubles": (_sz, [_i, _i]),
+    "toda_rows_bn_bwd_res_colsum": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "toda_conv3x3s2_supported": (_i, [_i, _i, _i, _i, _i]),
     "toda_conv3x3s2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "toda_conv3x3s2_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -888,7 +888,9 @@ class _SparseConv(torch.autograd.Function):
         if need_w:
             gw = wgrad(features, gout, rb.nbr_fwd, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gout.sum(0)
+            gb = _take_colsum(gout)          # BatchNorm's backward has already summed its dx over the rows (toda_rows_bn_bwd_res_colsum)
+            if gb is None:
+                gb = gout.sum(0)
         if side is not None:
             torch.cuda.current_stream(gout.device).wait_stream(side)
             gw.record_stream(torch.cuda.current_stream(gout.device))
@@ -990,13 +992,30 @@ def rows_affine_act(x, scale, shift, residual=None, relu=True):
     return y
 
 
+# Column sums of a BatchNorm backward's dx, handed to the backward of the convolution that produced x (its bias gradient): keyed by
+# the gradient tensor, which autograd passes on untouched when the convolution's output has that one consumer.  The entry holds
+# the tensor itself, so its address cannot be re-used while the entry is alive; whatever is left over is dropped by the next forward.
+_DX_COLSUM = {}
+BN_BWD_COLSUM = _os.environ.get("TODA_BN_BWD_COLSUM", "1") == "1"
+
+
+def _take_colsum(gout):
+    ent = _DX_COLSUM.pop(gout.data_ptr(), None) if _DX_COLSUM else None
+    if ent is None or ent[0].shape != gout.shape or ent[0]._version != ent[2] or gout.stride() != ent[0].stride():
+        return None
+    return ent[1]
+
+
 class _BNRows(torch.autograd.Function):
     """nn.BatchNorm1d(+ReLU) over the rows of a sparse level in 3 passes forward / 5 backward
     (torch: 5 / 7): toda_rows_moments -> toda_bn_finalize -> toda_rows_affine_act, toda_rows_bn_bwd."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual=None, sums=None):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu, residual=None, sums=None, colsum=False):
         lib = L.load()
+        if _DX_COLSUM:
+            _DX_COLSUM.clear()
+        ctx.colsum = bool(colsum) and BN_BWD_COLSUM
         x = x.contiguous()
         residual = residual.contiguous() if residual is not None else None
         n, c = x.shape
@@ -1045,26 +1064,36 @@ class _BNRows(torch.autograd.Function):
             dz = gy * (pre > 0) if relu else gy
             gx = dz * stats[2]
             xhat = (x - stats[0]) * stats[1]
-            return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None, (dz if want_res else None), None
+            return gx, (dz * xhat).sum(0), dz.sum(0), None, None, None, None, None, None, (dz if want_res else None), None, None
         sums = torch.empty((L.load().toda_rows_reduce_doubles(n, c),), dtype=torch.float64, device=x.device)
         gx = torch.empty_like(x)
         gamma = weight if weight is not None else torch.ones(c, device=x.device)
         gres = torch.empty_like(x) if want_res else None
-        rc = L.load().toda_rows_bn_bwd_res(L.ptr(gy), L.ptr(x), L.ptr(residual), L.ptr(stats), L.ptr(gamma), n, c, int(relu),
-                                           L.ptr(sums), L.ptr(gx), L.ptr(gres), L.stream())
-        L.check(rc, "toda_rows_bn_bwd_res")
+        if ctx.colsum:
+            lib = L.load()
+            cs_ws = torch.empty((lib.toda_rows_bn_bwd_colsum_doubles(n, c),), dtype=torch.float64, device=x.device)
+            cs = torch.empty((c,), dtype=torch.float32, device=x.device)
+            rc = lib.toda_rows_bn_bwd_res_colsum(L.ptr(gy), L.ptr(x), L.ptr(residual), L.ptr(stats), L.ptr(gamma), n, c, int(relu),
+                                                 L.ptr(sums), L.ptr(gx), L.ptr(gres), L.ptr(cs_ws), L.ptr(cs), L.stream())
+            L.check(rc, "toda_rows_bn_bwd_res_colsum")
+            _DX_COLSUM[gx.data_ptr()] = (gx, cs, gx._version)
+        else:
+            rc = L.load().toda_rows_bn_bwd_res(L.ptr(gy), L.ptr(x), L.ptr(residual), L.ptr(stats), L.ptr(gamma), n, c, int(relu),
+                                               L.ptr(sums), L.ptr(gx), L.ptr(gres), L.stream())
+            L.check(rc, "toda_rows_bn_bwd_res")
         gs = sums[2 * c:3 * c].view(torch.float32)    # the kernel leaves (float)sums[0:2c] behind the double results
-        return gx, gs[c:], gs[:c], None, None, None, None, None, None, gres, None
+        return gx, gs[c:], gs[:c], None, None, None, None, None, None, gres, None, None
 
 
-def bn_rows(x, bn, relu, residual=None, sums=None):
+def bn_rows(x, bn, relu, residual=None, sums=None, colsum=False):
     """Apply an nn.BatchNorm1d module (its parameters, buffers and train/eval state) to rows [N, C], optionally
     fused with a shortcut addition (y = bn(x) + residual) and the ReLU that follows.  sums: the moments of x when the
-    convolution that produced x has already taken them (ops.sparse_conv(..., want_stats=True))."""
+    convolution that produced x has already taken them (ops.sparse_conv(..., want_stats=True)).  colsum: x comes straight out of a
+    convolution with a bias - the backward also sums dx over the rows and leaves the result for that convolution's backward."""
     training = bn.training or not bn.track_running_stats
     bump_bn_counter(bn)
     momentum = 0.0 if bn.momentum is None else bn.momentum
-    return _BNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu, residual, sums)
+    return _BNRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, momentum, bn.eps, relu, residual, sums, colsum)
 
 
 def bn_rows_supported(x, bn):

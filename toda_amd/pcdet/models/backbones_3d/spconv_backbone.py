@@ -50,9 +50,10 @@ class SparseBasicBlock(spconv.SparseModule):
         if ops.bn_rows_supported(y.features, self.bn1) and ops.bn_rows_supported(y.features, self.bn2):
             # BN + ReLU and BN + shortcut + ReLU as fused passes over the rows (the moments come out of the convolutions'
             # epilogues) instead of torch's BatchNorm1d + add + ReLU kernels; module tree and state_dict are unchanged
-            y = replace_feature(y, ops.bn_rows(y.features, self.bn1, True, sums=getattr(y, "bn_sums", None)))
+            y = replace_feature(y, ops.bn_rows(y.features, self.bn1, True, sums=getattr(y, "bn_sums", None), colsum=self.conv1.bias is not None))
             y = self.conv2(y, want_bn_stats=True) if self.bn2.training else self.conv2(y)
-            return replace_feature(y, ops.bn_rows(y.features, self.bn2, True, residual=shortcut.features, sums=getattr(y, "bn_sums", None)))
+            return replace_feature(y, ops.bn_rows(y.features, self.bn2, True, residual=shortcut.features, sums=getattr(y, "bn_sums", None),
+                                                  colsum=self.conv2.bias is not None))
         y = replace_feature(y, self.relu(self.bn1(y.features)))
         y = self.conv2(y)
         y = replace_feature(y, self.bn2(y.features))

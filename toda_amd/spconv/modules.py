@@ -61,7 +61,9 @@ class SparseSequential(SparseModule):
                     # BatchNorm1d (+ ReLU) over sparse rows: one fused HIP path instead of 2 modules
                     if isinstance(module, nn.BatchNorm1d) and ops.bn_rows_supported(x.features, module):
                         relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-                        x = x.replace_feature(ops.bn_rows(x.features, module, relu, sums=getattr(x, "bn_sums", None)))
+                        prev = mods[i - 1] if i > 0 else None
+                        x = x.replace_feature(ops.bn_rows(x.features, module, relu, sums=getattr(x, "bn_sums", None),
+                                                          colsum=getattr(prev, "bias", None) is not None and is_spconv_module(prev)))
                         i += 2 if relu else 1
                         continue
                     x = x.replace_feature(module(x.features))

@@ -210,6 +210,27 @@ def test_device_mixers_match_oracle_at_full_c5_size(which):
     np.testing.assert_array_equal(got["points"], want["points"])
 
 
+@pytest.mark.parametrize("empty", ["source", "target", "both"])
+def test_round4_mixers_handle_scenes_without_boxes(empty):
+    """No boxes on one or both sides (an unlabeled target frame before pseudo-labelling, a source frame whose objects were all
+    filtered): pseudo mixes, spherical LaserMix, PolarMix with use_pitch / RAND range - device against the oracle."""
+    from toda_amd.pcdet.datasets.processor import point_mix
+    src, tgt = full_scene("nuscenes_toda", 701, 8), full_scene("nuscenes_toda", 702, 9)
+    none = np.zeros((0, 8), np.float32)
+    if empty in ("source", "both"):
+        src = dict(src, gt_boxes=none)
+    if empty in ("target", "both"):
+        tgt = dict(tgt, gt_boxes=none)
+    calls = [lambda e, r: e.pseudobbox(src, tgt), lambda e, r: e.pseudobackground(src, tgt),
+             lambda e, r: e.lasermix_sph(src, tgt, [-20, 0], [5], 0, rng=r),
+             lambda e, r: e.polarmix(src, tgt, 1, 1.2, 0.5, ["FIX", "RAND"], "center", rng=r, polar_dis="RAND", pc_range=PC_RANGE),
+             lambda e, r: e.polarmix(src, tgt, 2, 1.2, 0.5, ["FIX"], "corner_del", rng=r, use_pitch=True)]
+    for k, call in enumerate(calls):
+        want, got = call(OM, np.random.RandomState(31 + k)), call(point_mix, np.random.RandomState(31 + k))
+        np.testing.assert_array_equal(got["gt_boxes"], want["gt_boxes"])
+        np.testing.assert_array_equal(got["points"], want["points"])
+
+
 def test_mixers_keep_cuda_tensors_on_the_device_and_wrappers_are_drop_in():
     from toda_amd.pcdet.datasets.processor.inter_domain_point_polarmix import inter_domain_point_polarmix
     from toda_amd.pcdet.datasets.processor.intra_domain_point_mixup import intra_domain_point_mixup

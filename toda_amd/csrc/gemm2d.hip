@@ -736,9 +736,11 @@ pg_slab_reduce_kernel(const float* __restrict__ slab, int splits, long long elem
 }
 
 static int pg_splits(long long n_pixels, int tiles) {
-    // weight gradients: the output is a few tiles, the parallelism comes from splitting the pixels - about 768 workgroups
-    // (256 CUs x 2 resident + tail), contraction chunks of at least 8 stages
-    int want = cdiv(768, tiles > 0 ? tiles : 1);
+    // weight gradients: the output is a few tiles, the parallelism comes from splitting the pixels - about 512 workgroups = the
+    // 256 CUs x 2 resident slots filled once (equal-length chunks: 768 workgroups were two rounds for one and a half rounds of work -
+    // stride-2 conv wgrad 182 -> 167 us, the deblocks' 82 / 156 -> 81 / 156; TODA_PG_WG_TARGET), contraction chunks of at least 8 stages
+    static const int target = getenv("TODA_PG_WG_TARGET") ? atoi(getenv("TODA_PG_WG_TARGET")) : 512;
+    int want = cdiv(target, tiles > 0 ? tiles : 1);
     long long max_by_len = n_pixels / (8 * PG_K);
     if (max_by_len < 1) max_by_len = 1;
     if (want > max_by_len) want = (int)max_by_len;

@@ -182,6 +182,17 @@ int toda_rulebook_conv(const int32_t* idx_in, int n_in, int batch,
  * additionally reverses the offset order (SubM dgrad reuses the forward
  * table through the point symmetry of the stencil). */
 size_t toda_spconv_packed_weight_floats(int k_vol, int c_gather, int c_produce);
+/* Matrix path of the gather-GEMMs (forward and data gradient of spconv SubMConv3d / SparseConv3d, reference
+ * pcdet/models/backbones_3d/spconv_backbone.py:77-125,191-240), process-wide: 0 = native - fp32 operands on
+ * v_mfma_f32_16x16x4_f32; 1 = split - every fp32 operand taken apart EXACTLY into three bf16 values (hi + mid + lo = x),
+ * six of the nine cross products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the three dropped ones are below
+ * 2^-24 of the product), 6/16 of the matrix cycles, for the channel pairs toda_spconv_split_supported names; every other
+ * pair runs native under either path.  Initial value: environment TODA_MM = native | split.  The packed operand of a
+ * supported pair is written in the format of the path current at PACK time (toda_spconv_packed_weight_floats covers both)
+ * and must be multiplied under the same path: set the path before packing, re-pack after changing it. */
+int toda_matrix_path(void);
+int toda_set_matrix_path(int mode);
+int toda_spconv_split_supported(int c_gather, int c_produce);
 int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int cin,
                             int transpose, int flip_k, float* wp, void* stream);
 /* The same for n weights in one launch (the forward and the data-gradient operand of every sparse convolution of a

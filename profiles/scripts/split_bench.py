@@ -1,0 +1,105 @@
+"""Native (fp32 MFMA) against split (bf16 hi/mid/lo, 6 terms) gather-GEMM on the C3 / C5 levels, alone: time per launch and the error of
+both against an fp64 evaluation of the same sums (rms and max, relative to the rms of the exact result).
+    python profiles/scripts/split_bench.py [c3|c5] [quick]
+"""
+import os
+import sys
+
+R = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
+sys.path.insert(0, R)
+sys.path.insert(0, R + '/tests/golden')
+import torch
+
+import make_counts as MC
+from toda_amd import ops
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'c3'
+quick = len(sys.argv) > 2 and sys.argv[2] == 'quick'
+ds = MC.load_dataset(name)
+vc = ds.voxel_cfg
+clouds = [torch.from_numpy(ds[i]['points']).cuda() for i in range(2)]
+vox, coords, num = ops.voxelize_batch(clouds, vc['point_cloud_range'], vc['voxel_size'], vc['max_points_per_voxel'], vc['max_num_voxels'])
+gx, gy, gz = (int(v) for v in ds.grid_size)
+shape = [gz + 1, gy, gx]
+steps = [dict(kind=k, key=key, **{a: b for a, b in kw.items()}) for key, k, kw in MC.PLAN]
+for st in steps:
+    if st['kind'] == 'conv':
+        st['padding'] = st.pop('pad')
+plan = ops.build_index_plan(coords, 2, shape, steps)
+
+
+def timeit(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(n):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / n
+
+
+def exact(feat, w, nbr, transpose, flip):
+    """fp64 sums over the table: out[o] = sum_k feat[nbr[k, o]] @ W_k (W_k = w[:, k, :]^T forward, w[:, K-1-k or k, :] for the data gradient)."""
+    K, n_out = nbr.shape
+    cout, cin = w.shape[0], w.shape[-1]
+    wk = w.reshape(cout, K, cin).double()
+    f64 = torch.cat([feat.double(), torch.zeros(1, feat.shape[1], dtype=torch.float64, device=feat.device)], 0)
+    out = torch.zeros(n_out, cin if transpose else cout, dtype=torch.float64, device=feat.device)
+    for k in range(K):
+        idx = nbr[k].long()
+        idx = torch.where(idx >= 0, idx, torch.full_like(idx, feat.shape[0]))
+        kk = K - 1 - k if flip else k
+        m = wk[:, kk, :] if transpose else wk[:, kk, :].t()
+        out += f64[idx] @ m
+    return out
+
+
+def run(tag, feat, w, nbr, c_produce, transpose=False, flip=False, order=None):
+    res = {}
+    for mm in ("native", "split"):
+        ops.set_matrix_path(mm)
+        wp = ops.pack_weight(w, transpose, flip)
+        out = ops.gather_gemm(feat, wp, nbr, c_produce, None, order=order)
+        t = timeit(lambda: ops.gather_gemm(feat, wp, nbr, c_produce, None, order=order), 5 if quick else 20)
+        res[mm] = (t, out)
+    ref = exact(feat, w, nbr, transpose, flip)
+    scale = float(ref.pow(2).mean().sqrt())
+    pairs = int((nbr >= 0).sum())
+    fl = 2.0 * pairs * feat.shape[1] * c_produce
+    line = f"{tag}: rows {nbr.shape[1]} pairs {pairs} {feat.shape[1]}->{c_produce}"
+    for mm in ("native", "split"):
+        t, out = res[mm]
+        d = out.double() - ref
+        line += f" | {mm} {t:.4f} ms {fl / t / 1e9:.1f} TF/s rms {float(d.pow(2).mean().sqrt()) / scale:.3e} max {float(d.abs().max()) / scale:.3e}"
+    same = bool((res['native'][1] == res['split'][1]).all())
+    o2 = None
+    ops.set_matrix_path("split")
+    wp = ops.pack_weight(w, transpose, flip)
+    o2 = ops.gather_gemm(feat, wp, nbr, c_produce, None, order=order)
+    line += f" | split/native time {res['split'][0] / res['native'][0]:.3f} rerun-identical {bool((o2 == res['split'][1]).all())} bit-equal-native {same}"
+    print(line, flush=True)
+    ops.set_matrix_path("native")
+
+
+torch.manual_seed(0)
+chan = {'c3': {'subm2': 32, 'subm3': 64, 'subm4': 64}, 'c5': {'subm2': 32, 'subm3': 64, 'subm4': 128}}.get(name, {})
+for key, c in chan.items():
+    if c > 64:
+        continue
+    rb = plan[key]['rb']
+    n = rb.n_out
+    feat = torch.relu(torch.randn(n, c, device='cuda')) * (1.0 + 3.0 * torch.rand(1, c, device='cuda'))     # post-ReLU-like, channel scales differ
+    w = torch.randn(c, 3, 3, 3, c, device='cuda') * 0.05
+    run(key + " fwd", feat, w, rb.nbr_fwd, c)
+    g = torch.randn(n, c, device='cuda')
+    run(key + " dgrad", g, w, rb.nbr_bwd, c, True, rb.flip_bwd)
+for key, cin, cout in (('spconv3', 32, 64), ('spconv4', 64, 64)):
+    rb = plan[key]['rb']
+    feat = torch.relu(torch.randn(rb.n_in, cin, device='cuda'))
+    w = torch.randn(cout, 3, 3, 3, cin, device='cuda') * 0.05
+    run(key + " fwd", feat, w, rb.nbr_fwd, cout)
+    g = torch.randn(rb.n_out, cout, device='cuda')
+    run(key + " dgrad(plain)", g, w, rb.nbr_bwd, cin, True, rb.flip_bwd)

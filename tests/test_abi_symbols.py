@@ -30,7 +30,11 @@ def test_host_side_size_queries_need_no_gpu():
     nbytes = lib.toda_gridindex_bytes(2, L.hptr(shape))
     cells = (2 * 41 * 1504 * 1504 + 31) // 32
     assert nbytes >= cells * 8
-    assert lib.toda_spconv_packed_weight_floats(27, 64, 64) == 27 * 4 * 4 * 256
+    assert lib.toda_spconv_packed_weight_floats(27, 16, 32) == 27 * 1 * 2 * 256          # fp32 fragment format only
+    # a pair the split matrix path covers: the larger of the fp32 (4 B) and the three-plane bf16 (6 B per weight) formats
+    assert lib.toda_spconv_packed_weight_floats(27, 64, 64) == 27 * 64 * 64 * 6 // 4
+    assert lib.toda_spconv_split_supported(64, 64) == 1 and lib.toda_spconv_split_supported(16, 16) == 0
+    assert lib.toda_matrix_path() in (0, 1) and lib.toda_set_matrix_path(7) != 0
     assert lib.toda_spconv_packed_weight_floats(27, 5, 16) == 27 * 256
     assert lib.toda_voxelize_workspace_bytes(180000, 150000) > 180000 * 4 * 5
 

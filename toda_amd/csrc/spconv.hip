@@ -1211,10 +1211,46 @@ static void wgrad_plan(int n_out, int k_vol, int cin, int cout, int* chunks, int
 
 }  // namespace toda
 
+#include "spconv_split.cuh"
+
 using namespace toda;
 
+// ---- matrix path (include/toda.h): 0 = native fp32 MFMA, 1 = exact bf16 hi/mid/lo split for the channel pairs split_shape_ok names.
+// Process-wide like the kernels' environment knobs; initial value from TODA_MM (native | split).  The packed operand of a supported
+// channel pair is written in the format of the path that is current at pack time and must be multiplied under the same path.
+#include <atomic>
+static std::atomic<int> g_matrix_path{-1};
+static int matrix_path() {
+    int m = g_matrix_path.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("TODA_MM");
+        m = (e && (e[0] == 's' || e[0] == '1')) ? 1 : 0;
+        g_matrix_path.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+static inline bool use_split(int c_gather, int c_produce) { return matrix_path() == 1 && toda::split_shape_ok(c_gather, c_produce); }
+
+extern "C" int toda_matrix_path(void) { return matrix_path(); }
+extern "C" int toda_set_matrix_path(int mode) {
+    TODA_CHECK_ARG(mode == 0 || mode == 1, "set_matrix_path: mode must be 0 (native) or 1 (split)");
+    g_matrix_path.store(mode, std::memory_order_relaxed);
+    return TODA_OK;
+}
+extern "C" int toda_spconv_split_supported(int c_gather, int c_produce) { return toda::split_shape_ok(c_gather, c_produce) ? 1 : 0; }
+
 extern "C" size_t toda_spconv_packed_weight_floats(int k_vol, int c_gather, int c_produce) {
-    return (size_t)k_vol * tiles_pow2(c_gather) * tiles_pow2(c_produce) * 256;
+    const size_t native = (size_t)k_vol * tiles_pow2(c_gather) * tiles_pow2(c_produce) * 256;
+    if (!toda::split_shape_ok(c_gather, c_produce)) return native;
+    const size_t split = toda::split_packed_bytes(k_vol, c_gather, c_produce) / 4;      // the larger of the two formats, whatever the path
+    return split > native ? split : native;
+}
+
+static void split_pack_fill(toda::SplitPackBatch& b, int i, const float* w, int cout, int k_vol, int cin, int transpose, int flip_k, float* wp) {
+    const int cgather = transpose ? cout : cin, cprod = transpose ? cin : cout;
+    b.w[i] = w, b.wps[i] = reinterpret_cast<toda::u32x4*>(wp), b.cout[i] = cout, b.K[i] = k_vol, b.cin[i] = cin;
+    b.transpose[i] = transpose != 0, b.flip[i] = flip_k != 0;
+    b.KC[i] = (unsigned char)(cgather / 32), b.NT[i] = (unsigned char)(cprod / 16);
 }
 
 extern "C" int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int cin, int transpose, int flip_k,
@@ -1223,6 +1259,14 @@ extern "C" int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int 
     const int cgather = transpose ? cout : cin, cprod = transpose ? cin : cout;
     TODA_CHECK_ARG(cgather <= 128 && cprod <= 128, "pack_weight: channels > 128 unsupported (gather %d, produce %d)",
                    cgather, cprod);
+    if (use_split(cgather, cprod)) {
+        toda::SplitPackBatch b = {};
+        split_pack_fill(b, 0, w, cout, k_vol, cin, transpose, flip_k, wp);
+        hipLaunchKernelGGL(split_pack_batch_kernel, dim3(cdiv((long long)k_vol * b.KC[0] * b.NT[0] * 192, SC_BLOCK), 1), dim3(SC_BLOCK), 0,
+                           (hipStream_t)stream, b);
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
     const int Q = tiles_pow2(cgather), NT = tiles_pow2(cprod);
     const long long total = (long long)k_vol * Q * NT * 256;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(total, SC_BLOCK)), dim3(SC_BLOCK), 0, (hipStream_t)stream, w, cout,
@@ -1234,25 +1278,57 @@ extern "C" int toda_spconv_pack_weight(const float* w, int cout, int k_vol, int 
 extern "C" int toda_spconv_pack_weights(int n, const float* const* w, const int32_t* cout, const int32_t* k_vol, const int32_t* cin,
                                         const int32_t* transpose, const int32_t* flip_k, float* const* wp, void* stream) {
     TODA_CHECK_ARG(n >= 0 && w && cout && k_vol && cin && transpose && flip_k && wp, "pack_weights: null argument");
-    for (int base = 0; base < n; base += PACK_MAX_SEG) {
-        const int m = n - base < PACK_MAX_SEG ? n - base : PACK_MAX_SEG;
-        PackBatch b = {};
-        long long most = 0;
-        for (int i = 0; i < m; ++i) {
-            const int s = base + i;
-            TODA_CHECK_ARG(w[s] && wp[s] && cout[s] >= 1 && cin[s] >= 1 && k_vol[s] >= 1, "pack_weights: bad segment %d", s);
-            const int cgather = transpose[s] ? cout[s] : cin[s], cprod = transpose[s] ? cin[s] : cout[s];
-            TODA_CHECK_ARG(cgather <= 128 && cprod <= 128, "pack_weights: channels > 128 unsupported (segment %d)", s);
-            b.w[i] = w[s], b.wp[i] = wp[s], b.cout[i] = cout[s], b.K[i] = k_vol[s], b.cin[i] = cin[s];
-            b.transpose[i] = transpose[s] != 0, b.flip[i] = flip_k[s] != 0;
-            b.Q[i] = (unsigned char)tiles_pow2(cgather), b.NT[i] = (unsigned char)tiles_pow2(cprod);
-            const long long total = (long long)k_vol[s] * b.Q[i] * b.NT[i] * 256;
-            if (total > most) most = total;
+    // two launches at most per PACK_MAX_SEG operands: the fp32 fragment format and (matrix path "split") the three-plane bf16 format
+    PackBatch b = {};
+    toda::SplitPackBatch sb = {};
+    int m = 0, sm = 0;
+    long long most = 0, smost = 0;
+    auto flush = [&]() -> int {
+        if (m > 0) {
+            hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(cdiv(most, SC_BLOCK), m), dim3(SC_BLOCK), 0, (hipStream_t)stream, b);
+            TODA_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(pack_weight_batch_kernel, dim3(cdiv(most, SC_BLOCK), m), dim3(SC_BLOCK), 0, (hipStream_t)stream, b);
-        TODA_LAUNCH_CHECK();
+        m = 0, most = 0;
+        return TODA_OK;
+    };
+    auto sflush = [&]() -> int {
+        if (sm > 0) {
+            hipLaunchKernelGGL(split_pack_batch_kernel, dim3(cdiv(smost, SC_BLOCK), sm), dim3(SC_BLOCK), 0, (hipStream_t)stream, sb);
+            TODA_LAUNCH_CHECK();
+        }
+        sm = 0, smost = 0;
+        return TODA_OK;
+    };
+    for (int s = 0; s < n; ++s) {
+        TODA_CHECK_ARG(w[s] && wp[s] && cout[s] >= 1 && cin[s] >= 1 && k_vol[s] >= 1, "pack_weights: bad segment %d", s);
+        const int cgather = transpose[s] ? cout[s] : cin[s], cprod = transpose[s] ? cin[s] : cout[s];
+        TODA_CHECK_ARG(cgather <= 128 && cprod <= 128, "pack_weights: channels > 128 unsupported (segment %d)", s);
+        if (use_split(cgather, cprod)) {
+            split_pack_fill(sb, sm, w[s], cout[s], k_vol[s], cin[s], transpose[s], flip_k[s], wp[s]);
+            const long long total = (long long)k_vol[s] * sb.KC[sm] * sb.NT[sm] * 192;
+            if (total > smost) smost = total;
+            if (++sm == toda::SPLIT_PACK_MAX_SEG) {
+                const int rc = sflush();
+                if (rc != TODA_OK) return rc;
+            }
+            continue;
+        }
+        const int i = m;
+        b.w[i] = w[s], b.wp[i] = wp[s], b.cout[i] = cout[s], b.K[i] = k_vol[s], b.cin[i] = cin[s];
+        b.transpose[i] = transpose[s] != 0, b.flip[i] = flip_k[s] != 0;
+        b.Q[i] = (unsigned char)tiles_pow2(cgather), b.NT[i] = (unsigned char)tiles_pow2(cprod);
+        const long long total = (long long)k_vol[s] * b.Q[i] * b.NT[i] * 256;
+        if (total > most) most = total;
+        if (++m == PACK_MAX_SEG) {
+            const int rc = flush();
+            if (rc != TODA_OK) return rc;
+        }
     }
-    return TODA_OK;
+    {
+        const int rc = flush();
+        if (rc != TODA_OK) return rc;
+    }
+    return sflush();
 }
 
 namespace toda {
@@ -1549,6 +1625,24 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     // weight staging: the LDS-shared slice when it measured faster (Q >= 2 and NT >= Q); TODA_GG_LDS = 0 never, 2 always
     static const int env_lds_raw = getenv("TODA_GG_LDS") ? atoi(getenv("TODA_GG_LDS")) : 1;
     const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);
+    if (use_split(c_gather, c_produce)) {     // matrix path "split": wp holds the three-plane bf16 operand (spconv_split.cuh)
+        TODA_CHECK_ARG(k_vol >= 2, "gather_gemm (split path): at least two kernel offsets");
+        const toda::u32x4* wps = reinterpret_cast<const toda::u32x4*>(wp);
+#define SPL(KK, NN)                                                                                                                     \
+    GG_LAUNCH(HIP_KERNEL_NAME(gg_split_kernel<KK, NN, 2>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, wps, nbr, \
+              n_out, k_vol, c_produce, bias, out, order, stats)
+        if (c_gather == 32 && c_produce == 32) SPL(1, 2);
+        else if (c_gather == 32) SPL(1, 4);
+        else if (c_produce == 32) SPL(2, 2);
+        else SPL(2, 4);
+#undef SPL
+        TODA_LAUNCH_CHECK();
+        if (stats) {
+            fold_or_defer(stats, cdiv(cdiv(n_out, 32), SC_BLOCK / 64), c_produce, s);
+            TODA_LAUNCH_CHECK();
+        }
+        return TODA_OK;
+    }
 #if TODA_VARIANTS
     {   // opt-in kernels (environment knobs, the submanifold hint): spconv_variants.cuh
         bool handled = false;

@@ -35,6 +35,9 @@ SIGNATURES = {
     "toda_gridindex_clear": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "toda_gridindex_from_bitmap": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "toda_spconv_packed_weight_floats": (_sz, [_i, _i, _i]),
+    "toda_matrix_path": (_i, []),
+    "toda_set_matrix_path": (_i, [_i]),
+    "toda_spconv_split_supported": (_i, [_i, _i]),
     "toda_spconv_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "toda_spconv_pack_weights": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "toda_spconv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

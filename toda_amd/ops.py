@@ -522,6 +522,37 @@ def build_input_plan(clouds, voxel_cfg, batch, shape, steps, training=True, whil
 
 
 # --------------------------------------------------------------------------- sparse conv
+MATRIX_PATHS = ("native", "split")
+_MM = None          # the library's current path, read once (the library is only switched through set_matrix_path)
+
+
+def matrix_path():
+    """'native' (fp32 MFMA) or 'split' (exact bf16 hi/mid/lo split, 6 terms, fp32 accumulate) - toda_matrix_path; initial value TODA_MM."""
+    global _MM
+    if _MM is None:
+        _MM = MATRIX_PATHS[L.load().toda_matrix_path()]
+    return _MM
+
+
+def set_matrix_path(name):
+    """Switch the matrix path of the sparse gather-GEMMs.  Packed operands remember the path they were packed under (`_toda_mm`);
+    the module caches (spconv/conv.py) are keyed on it, so the next forward re-packs."""
+    global _MM
+    L.check(L.load().toda_set_matrix_path(MATRIX_PATHS.index(name)), "toda_set_matrix_path")
+    _MM = name
+
+
+def _tag_mm(wp, cg, cp):
+    wp._toda_mm = matrix_path() if L.load().toda_spconv_split_supported(int(cg), int(cp)) else None
+    return wp
+
+
+def _check_mm(wp):
+    mm = getattr(wp, "_toda_mm", None)
+    if mm is not None and mm != matrix_path():
+        raise RuntimeError(f"packed sparse-conv operand was written under matrix path {mm!r}, the current path is {matrix_path()!r}: re-pack it")
+
+
 def pack_weight(weight, transpose, flip_k):
     """weight [Cout, kz, ky, kx, Cin] -> MFMA fragment order (see csrc/spconv.hip)."""
     lib = L.load()
@@ -533,7 +564,7 @@ def pack_weight(weight, transpose, flip_k):
     rc = lib.toda_spconv_pack_weight(L.ptr(weight.contiguous()), cout, K, cin, int(transpose), int(flip_k), L.ptr(wp),
                                      L.stream())
     L.check(rc, "toda_spconv_pack_weight")
-    return wp
+    return _tag_mm(wp, cg, cp)
 
 
 def pack_weights_batched(items):
@@ -543,17 +574,17 @@ def pack_weights_batched(items):
     if not items:
         return []
     dev = items[0][0].device
-    sizes, couts, ks, cins = [], [], [], []
+    sizes, couts, ks, cins, pairs = [], [], [], [], []
     for w, tr, _ in items:
         cout, cin = w.shape[0], w.shape[-1]
         K = w.numel() // (cout * cin)
         cg, cp = (cout, cin) if tr else (cin, cout)
         sizes.append(lib.toda_spconv_packed_weight_floats(K, cg, cp))
-        couts.append(cout), ks.append(K), cins.append(cin)
+        couts.append(cout), ks.append(K), cins.append(cin), pairs.append((cg, cp))
     flat = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
     outs, off = [], 0
-    for n in sizes:
-        outs.append(flat[off:off + n])
+    for n, (cg, cp) in zip(sizes, pairs):
+        outs.append(_tag_mm(flat[off:off + n], cg, cp))
         off += n
     ws = [w.contiguous() for w, _, _ in items]
     rc = lib.toda_spconv_pack_weights(len(items), L.host_ptrs(ws), L.hptr(L.host_i32(couts)), L.hptr(L.host_i32(ks)), L.hptr(L.host_i32(cins)),
@@ -817,6 +848,8 @@ class _SparseConv(torch.autograd.Function):
         compact = _compact_route(features.shape[1], weight.shape[0], rb.nbr_fwd, rb.order_for(rb.nbr_fwd))
         if wp_fwd is None and not compact:
             wp_fwd = pack_weight(weight, False, False)
+        if wp_fwd is not None:
+            _check_mm(wp_fwd)
         sums, blocks = None, 0
         plan = rb.halo.get(weight.shape[-1]) if (rb.kind == "subm" and weight.shape[0] == weight.shape[-1] and features.shape[0] == rb.n_out) else None
         line = plan is None and not compact and features.shape[0] == rb.n_out and _line_route(features.shape[1], weight.shape[0], rb, rb.nbr_fwd)
@@ -876,6 +909,7 @@ class _SparseConv(torch.autograd.Function):
             gfeat = gather_gemm_compact(gout, weight.contiguous(), rb.nbr_bwd, weight.shape[-1], None, True, rb.flip_bwd)
         elif need_d:
             wp_t = ctx.wp_bwd if ctx.wp_bwd is not None else pack_weight(weight, True, rb.flip_bwd)
+            _check_mm(wp_t)
             co = rb.class_order()
             if ctx.halo_plan is not None:      # SubM: the forward table with the offsets reversed in wp_t - the same plan
                 gfeat = gather_gemm_halo(gout, wp_t, rb.nbr_bwd, weight.shape[-1], ctx.halo_plan)

@@ -59,7 +59,7 @@ class SparseConvolution(SparseModule):
 
     def _packed_forward_weight(self):
         w = self.weight
-        tag = (w._version, w.data_ptr())
+        tag = (w._version, w.data_ptr(), ops.matrix_path())
         if self._packed is None or self._packed[0] != tag:
             with torch.no_grad():
                 self._packed = (tag, ops.pack_weight(w.detach(), False, False))
@@ -68,7 +68,7 @@ class SparseConvolution(SparseModule):
     def _dgrad_operand(self):
         """The dgrad operand packed together with the forward one by prepack(), if it matches the current weights."""
         w = self.weight
-        if self._packed_dgrad is not None and self._packed_dgrad[0] == (w._version, w.data_ptr()):
+        if self._packed_dgrad is not None and self._packed_dgrad[0] == (w._version, w.data_ptr(), ops.matrix_path()):
             return self._packed_dgrad[1]
         return None
 
@@ -152,8 +152,9 @@ def prepack(module):
         return
     want_dgrad = torch.is_grad_enabled()
     stale = []
+    mm = ops.matrix_path()
     for c in convs:
-        tag = (c.weight._version, c.weight.data_ptr())
+        tag = (c.weight._version, c.weight.data_ptr(), mm)
         if c._packed is None or c._packed[0] != tag or (want_dgrad and c.weight.requires_grad and (c._packed_dgrad is None or c._packed_dgrad[0] != tag)):
             stale.append((c, tag))
     if len(stale) < 2:

@@ -100,17 +100,17 @@ class KernelTimer:
     kernel's own - the number rocprofv3 --kernel-trace reports - and no host sync happens while the clock runs.
     ops.gather_gemm is wrapped only to remember each launch's shape in launch order."""
 
-    CAPACITY = 512          # launches timed and labelled (their neighbour tables stay referenced until the summary)
+    CAPACITY = 512          # launches timed and labelled (the pair counters of their tables stay referenced until the summary)
 
     def __init__(self):
-        self.records = []          # (nbr table, n_src, c_gather, c_produce) in launch order
+        self.records = []          # (pair counters [K] of the table, n_out, K, n_src, c_gather, c_produce) in launch order
         self.ms = []
         self._enabled = False
         self._orig = ops.gather_gemm
 
         def labelled(feat, wp, nbr, c_produce, bias=None, order=None):
             if self._enabled and len(self.records) < self.CAPACITY:
-                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+                self.records.append(self._record_of(nbr, feat, c_produce))
             return self._orig(feat, wp, nbr, c_produce, bias, order)
 
         ops.gather_gemm = labelled
@@ -118,7 +118,7 @@ class KernelTimer:
 
         def labelled_stats(feat, wp, nbr, c_produce, bias=None, **kw):
             if self._enabled and len(self.records) < self.CAPACITY:
-                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+                self.records.append(self._record_of(nbr, feat, c_produce))
             return self._orig_stats(feat, wp, nbr, c_produce, bias, **kw)
 
         ops.gather_gemm_with_stats = labelled_stats
@@ -126,7 +126,7 @@ class KernelTimer:
 
         def labelled_classed(feat, wp, nbr, c_produce, *rest):
             if self._enabled and len(self.records) < self.CAPACITY:
-                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+                self.records.append(self._record_of(nbr, feat, c_produce))
             return self._orig_classed(feat, wp, nbr, c_produce, *rest)
 
         ops.gather_gemm_classed = labelled_classed
@@ -135,7 +135,7 @@ class KernelTimer:
 
         def labelled_halo(feat, wp, nbr, c_produce, *rest, **kw):
             if self._enabled and len(self.records) < self.CAPACITY:
-                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+                self.records.append(self._record_of(nbr, feat, c_produce))
                 self.halo_tables.add((nbr.shape[1], nbr.shape[0], feat.shape[1], c_produce))
             return self._orig_halo(feat, wp, nbr, c_produce, *rest, **kw)
 
@@ -144,7 +144,7 @@ class KernelTimer:
 
         def labelled_subm(feat, wp, nbr, c_produce, *rest, **kw):
             if self._enabled and len(self.records) < self.CAPACITY:
-                self.records.append((nbr, feat.shape[0], feat.shape[1], c_produce))
+                self.records.append(self._record_of(nbr, feat, c_produce))
             return self._orig_subm(feat, wp, nbr, c_produce, *rest, **kw)
 
         ops.gather_gemm_subm = labelled_subm
@@ -173,17 +173,23 @@ class KernelTimer:
         self._enabled = bool(on)
 
     def summary(self):
-        """Per launch shape: mean ms, algorithmic bytes and flops (valid pairs counted exactly)."""
-        groups, pair_cache = {}, {}
-        for (nbr, n_src, cg, cp), ms in zip(self.records, self.ms):
-            if nbr.data_ptr() not in pair_cache:
-                pair_cache[nbr.data_ptr()] = int((nbr >= 0).sum().item())
-            pairs = pair_cache[nbr.data_ptr()]
-            key = (nbr.shape[1], nbr.shape[0], pairs, n_src, cg, cp)      # one group per rulebook and channel pair, over all steps
-            g = groups.setdefault(key, {"ms": [], "pairs": pairs, "n_out": nbr.shape[1],
-                                        "K": nbr.shape[0], "n_src": n_src, "cg": cg, "cp": cp})
+        """Per launch shape: mean ms, algorithmic bytes and flops (valid pairs counted exactly, from the counters the rulebook
+        kernels left - never from the tables: with the arena those are views into slots later batches have overwritten)."""
+        groups = {}
+        cnts = torch.stack([c.to(torch.int64).sum() for c, *_ in self.records]).tolist() if self.records else []
+        for (cnt, n_out, K, n_src, cg, cp), ms, pairs in zip(self.records, self.ms, cnts):
+            pairs = int(pairs)
+            key = (n_out, K, pairs, n_src, cg, cp)      # one group per rulebook (its row AND pair count) and channel pair, over all steps
+            g = groups.setdefault(key, {"ms": [], "pairs": pairs, "n_out": n_out, "K": K, "n_src": n_src, "cg": cg, "cp": cp})
             g["ms"].append(ms)
         return groups
+
+    @staticmethod
+    def _record_of(nbr, feat, c_produce):
+        cnt = getattr(nbr, "_toda_pair_cnt", None)
+        if cnt is None:          # a table that did not come out of ops.Rulebook: count now (one reduction on the current stream)
+            cnt = (nbr >= 0).sum().reshape(1)
+        return (cnt, nbr.shape[1], nbr.shape[0], feat.shape[0], feat.shape[1], c_produce)
 
 
 def run_gpu(args, rank, world, device):

@@ -14,7 +14,7 @@ import make_counts as MC
 from toda_amd import ops
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'c3'
-quick = len(sys.argv) > 2 and sys.argv[2] == 'quick'
+quick = (len(sys.argv) > 2 and sys.argv[2] == 'quick') or bool(os.environ.get('SPLIT_ONLY'))
 ds = MC.load_dataset(name)
 vc = ds.voxel_cfg
 clouds = [torch.from_numpy(ds[i]['points']).cuda() for i in range(2)]
@@ -85,18 +85,23 @@ def run(tag, feat, w, nbr, c_produce, transpose=False, flip=False, order=None):
 
 
 torch.manual_seed(0)
+ONLY = os.environ.get("SPLIT_ONLY")          # e.g. subm3: that level's forward alone (counter passes)
 chan = {'c3': {'subm2': 32, 'subm3': 64, 'subm4': 64}, 'c5': {'subm2': 32, 'subm3': 64, 'subm4': 128}}.get(name, {})
 for key, c in chan.items():
-    if c > 64:
+    if c > 64 or (ONLY and key != ONLY):
         continue
     rb = plan[key]['rb']
     n = rb.n_out
     feat = torch.relu(torch.randn(n, c, device='cuda')) * (1.0 + 3.0 * torch.rand(1, c, device='cuda'))     # post-ReLU-like, channel scales differ
     w = torch.randn(c, 3, 3, 3, c, device='cuda') * 0.05
     run(key + " fwd", feat, w, rb.nbr_fwd, c)
+    if ONLY:
+        continue
     g = torch.randn(n, c, device='cuda')
     run(key + " dgrad", g, w, rb.nbr_bwd, c, True, rb.flip_bwd)
 for key, cin, cout in (('spconv3', 32, 64), ('spconv4', 64, 64)):
+    if ONLY:
+        break
     rb = plan[key]['rb']
     feat = torch.relu(torch.randn(rb.n_in, cin, device='cuda'))
     w = torch.randn(cout, 3, 3, 3, cin, device='cuda') * 0.05

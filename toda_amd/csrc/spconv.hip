@@ -1628,17 +1628,30 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     if (use_split(c_gather, c_produce)) {     // matrix path "split": wp holds the three-plane bf16 operand (spconv_split.cuh)
         TODA_CHECK_ARG(k_vol >= 2, "gather_gemm (split path): at least two kernel offsets");
         const toda::u32x4* wps = reinterpret_cast<const toda::u32x4*>(wp);
-#define SPL(KK, NN)                                                                                                                     \
-    GG_LAUNCH(HIP_KERNEL_NAME(gg_split_kernel<KK, NN, 2>), dim3(cdiv(cdiv(n_out, 32), SC_BLOCK / 64)), dim3(SC_BLOCK), 0, s, in, n_in, wps, nbr, \
+#define SPL(KK, NN, BB)                                                                                                                 \
+    GG_LAUNCH(HIP_KERNEL_NAME(gg_split_kernel<KK, NN, 2, BB>), dim3(cdiv(cdiv(n_out, 32), BB / 64)), dim3(BB), 0, s, in, n_in, wps, nbr, \
               n_out, k_vol, c_produce, bias, out, order, stats)
-        if (c_gather == 32 && c_produce == 32) SPL(1, 2);
-        else if (c_gather == 32) SPL(1, 4);
-        else if (c_produce == 32) SPL(2, 2);
-        else SPL(2, 4);
+#define SPL_B(KK, NN)                      \
+    do {                                   \
+        if (blk == 768) SPL(KK, NN, 768);  \
+        else if (blk == 384) SPL(KK, NN, 384); \
+        else SPL(KK, NN, 256);             \
+    } while (0)
+        // workgroup size (measured on the C3 levels, ms per launch 256 / 384 / 768 threads): 64 -> 64 @ 389 k rows 0.367 / 0.465 / 0.353,
+        // @ 117 k rows 0.135 / 0.192 / 0.179 (305 workgroups of 768 threads on 256 CUs: a second, nearly empty round), 32 -> 32 @ 682 k
+        // 0.239 / 0.258 / 0.248, 32 -> 64 @ 389 k 0.151 / 0.191 / 0.168.  384 threads leave the SIMDs of a CU unevenly filled (2 x 6 waves).
+        static const int env_blk = getenv("TODA_SPLIT_BLK") ? atoi(getenv("TODA_SPLIT_BLK")) : 0;
+        const int blk = env_blk == 768 || env_blk == 384 || env_blk == 256 ? env_blk
+                                                                           : ((c_gather == 64 && c_produce == 64 && n_out >= 262144) ? 768 : 256);
+        if (c_gather == 32 && c_produce == 32) SPL_B(1, 2);
+        else if (c_gather == 32) SPL_B(1, 4);
+        else if (c_produce == 32) SPL_B(2, 2);
+        else SPL_B(2, 4);
+#undef SPL_B
 #undef SPL
         TODA_LAUNCH_CHECK();
         if (stats) {
-            fold_or_defer(stats, cdiv(cdiv(n_out, 32), SC_BLOCK / 64), c_produce, s);
+            fold_or_defer(stats, cdiv(cdiv(n_out, 32), blk / 64), c_produce, s);
             TODA_LAUNCH_CHECK();
         }
         return TODA_OK;

@@ -18,8 +18,11 @@
 //   * the rows of offset k + 1 are requested before the matrix work of offset k (one offset of look-ahead per wave) and land under it.
 // MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane & 15][k = 8 (lane >> 4) + j], B[k = 8 (lane >> 4) + j][lane & 15],
 // D: col = lane & 15, row = 4 (lane >> 4) + reg (the map of the fp32 instruction: the epilogue is the one of gather_gemm_lds_kernel).
-// k-permutation: lane (r, g) contracts chunk kc over the gathered channels 8 KC g + 8 kc + j - the 32 KC bytes a lane loads from its
-// row are contiguous - and the packed planes follow the same map.  Produced channel of column c of tile n: NT c + n (vector stores).
+// k-permutation: lane (r, g) contracts element j of chunk kc over the gathered channel 32 kc + 16 (j >> 2) + 4 g + (j & 3): its two
+// 16-byte loads per chunk are the pieces 4 g .. 4 g + 3 of the 64-byte segments 2 kc and 2 kc + 1 of its row, so ONE load instruction
+// of the wave reads 16 rows x one whole 64-byte segment (a lane reading 32 KC contiguous bytes makes every instruction touch all
+// segments of all 16 rows for a quarter of their bytes: 4 x the cache-line accesses).  The packed planes follow the same map.
+// Produced channel of column c of tile n: NT c + n (vector stores).
 #pragma once
 
 namespace toda {
@@ -33,12 +36,35 @@ __device__ __forceinline__ unsigned sp_pack_hi(float x0, float x1) {
 __device__ __forceinline__ float sp_trunc(float x) {
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
 }
+#ifndef SP_STAMPS
+#define SP_STAMPS 0      // diagnostic build only: per-wave cycle sums of the loop's segments through the statistics pointer (no statistics)
+#endif
+#if SP_STAMPS
+#define SP_STAMP(i)                                                                               \
+    do {                                                                                          \
+        unsigned long long t_;                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        seg[i] += t_ - t_prev;                                                                    \
+        t_prev = t_;                                                                              \
+    } while (0)
+#else
+#define SP_STAMP(i)
+#endif
+#ifndef SP_ABLATE
+#define SP_ABLATE 0      // measurement builds only (wrong numbers): 1 = no operand split, 2 = no matrix instructions
+#endif
 // 8 consecutive fp32 values -> the three bf16 planes of an A fragment
 __device__ __forceinline__ void sp_split8(const f32x4& v0, const f32x4& v1, u32x4& h, u32x4& m, u32x4& l) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const float x0 = p < 2 ? v0[2 * p] : v1[2 * p - 4], x1 = p < 2 ? v0[2 * p + 1] : v1[2 * p - 3];
         h[p] = sp_pack_hi(x0, x1);
+#if SP_ABLATE & 1
+        m[p] = h[p] ^ 0x00010001u, l[p] = h[p] ^ 0x00020002u;
+        continue;
+#endif
         const float r0 = x0 - sp_trunc(x0), r1 = x1 - sp_trunc(x1);
         m[p] = sp_pack_hi(r0, r1);
         const float l0 = r0 - sp_trunc(r0), l1 = r1 - sp_trunc(r1);
@@ -81,7 +107,7 @@ split_pack_batch_kernel(const SplitPackBatch b) {
     unsigned short v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int gch = 8 * KC * g + 8 * kc + j;
+        const int gch = 32 * kc + 16 * (j >> 2) + 4 * g + (j & 3);
         float x = 0.0f;
         if (!b.transpose[sg]) {
             if (gch < cin && pch < cout) x = w[((size_t)pch * K + kk) * cin + gch];
@@ -94,17 +120,18 @@ split_pack_batch_kernel(const SplitPackBatch b) {
                          (unsigned)v[6] | ((unsigned)v[7] << 16)};
 }
 
-__host__ __device__ constexpr int sp_waves(int KC, int NT, int RT) { return (KC * NT * 6 * 3 <= 160 && KC * NT * RT <= 16) ? 3 : 2; }
-
 // ---- the kernel -------------------------------------------------------------------------------------------------------------------
-template <int KC, int NT, int RT>
-__global__ void __launch_bounds__(SC_BLOCK, sp_waves(KC, NT, RT))
+// BLK threads = BLK / 64 waves share one double-buffered weight slice: every workgroup re-reads the whole packed operand (24 KiB per
+// offset at 64 -> 64), so with 256-thread workgroups the slices are HALF of the kernel's vector-memory traffic (2.0 GB beside 1.9 GB of
+// gathered rows at 389 k rows) and the waves spend 39 % of their time pushing loads into a full memory pipeline (in-kernel stamps,
+// profiles/r05_split_stamps.txt).  Three waves per SIMD either way (168 registers): 256 threads x 3 workgroups or 768 x 1 per CU.
+template <int KC, int NT, int RT, int BLK>
+__global__ void __launch_bounds__(BLK, 3)
 gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict__ wps, const int* __restrict__ nbr, int n_out, int K, int cp,
                 const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stats) {
     constexpr int CG = 32 * KC;
     constexpr int UNITS = KC * NT * 3;      // 1 KiB wave-instruction images per offset
     constexpr int SLICE = UNITS * 64;       // u32x4 per offset
-    constexpr int BLK = SC_BLOCK;
     static_assert(2 * SLICE * 16 >= (BLK / 64) * 2 * 16 * NT * 4, "the statistics scratch aliases the weight buffers");
     __shared__ u32x4 wl[2 * SLICE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -126,25 +153,24 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
     bool live[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        live[rt] = row0 + rt * 16 + r < n_out;
+        live[rt] = row0 + rt * 16 + r < n_out;       // rows past the end read the ids of the last row and are never stored
         rows[rt] = live[rt] ? (order ? order[row0 + rt * 16 + r] : row0 + rt * 16 + r) : n_out - 1;
     }
     auto load_ids = [&](int k, int (&dst)[RT]) {
         const int kk = k < K ? k : K - 1;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const int v = __builtin_nontemporal_load(nbr + (size_t)kk * n_out + rows[rt]);      // past the last offset: its ids again, never used
-            dst[rt] = live[rt] ? v : -1;
+            dst[rt] = __builtin_nontemporal_load(nbr + (size_t)kk * n_out + rows[rt]);      // past the last offset: its ids again, never used
         }
     };
     auto gather = [&](const int (&src)[RT], bool valid, f32x4 (&raw)[RT][2 * KC]) {      // valid (wave-uniform): the offset exists
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const bool ok = src[rt] >= 0 && valid;
-            const unsigned base = (unsigned)src[rt] * (unsigned)(CG * 4) + (unsigned)(32 * KC * g);
+            const unsigned base = (unsigned)src[rt] * (unsigned)(CG * 4) + (unsigned)(16 * g);
 #pragma unroll
             for (int i = 0; i < 2 * KC; ++i)
-                raw[rt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? base + 16u * i : OOB, 0, 0));
+                raw[rt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? base + 64u * i : OOB, 0, 0));
         }
     };
     auto stage = [&](int k, int buf) {       // the slice of offset k: global -> LDS, 1 KiB per wave-instruction, no registers
@@ -158,23 +184,26 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
         }
     };
 
-    int ids_cur[RT], ids_nxt[RT];
+    // ids live in three register sets that rotate by NAME (the loop body is written three times): a copy of a set whose load is
+    // still in flight, or the "row exists" select applied at load time, would be a wait for that load at the end of every offset
+    int idA[RT], idB[RT], idC[RT];
     f32x4 raw[RT][2 * KC];
-    load_ids(0, ids_cur);
-    load_ids(1, ids_nxt);
+    load_ids(0, idA);
+    load_ids(1, idB);
     stage(0, 0);
-    gather(ids_cur, true, raw);
+    gather(idA, true, raw);
     __syncthreads();
 
-    for (int k = 0; k < K; ++k) {
+#if SP_STAMPS
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, t_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
+    auto body = [&](int k, const int (&ids_cur)[RT], const int (&ids_nxt)[RT], int (&ids_new)[RT]) {
         const int cur = k & 1;
-        bool hit[RT];
+        SP_STAMP(5);
         bool any = false;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            hit[rt] = __any(ids_cur[rt] >= 0);
-            any = any || hit[rt];
-        }
+        for (int rt = 0; rt < RT; ++rt) any = any || __any(ids_cur[rt] >= 0);
         // one straight-line body per (wave, offset) that has a neighbour in any of its rows: on the submanifold tables 0.83 of the
         // executed tile rows are pairs this way against 0.85 with a test per 16-row tile (C3, 389 k rows) - not worth three bodies
         // (hipcc joins them with 32 accumulator copies per offset)
@@ -185,16 +214,23 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
 #pragma unroll
                 for (int kc = 0; kc < KC; ++kc) sp_split8(raw[rt][2 * kc], raw[rt][2 * kc + 1], ah[rt][kc], am[rt][kc], al[rt][kc]);
         }
-        int ids_nn[RT];
-        load_ids(k + 2, ids_nn);
-        gather(ids_nxt, k + 1 < K, raw);          // rows of offset k + 1: in flight under the matrix work below
+        SP_STAMP(0);
+        // issue order = the order the waits below and at the top of the next offset retire them in: the slice of offset k + 1 (needed
+        // by every wave behind the barrier), the rows of offset k + 1, the ids of offset k + 2
         stage(k + 1, cur ^ 1);
+        asm volatile("" ::: "memory");
+        gather(ids_nxt, k + 1 < K, raw);          // rows of offset k + 1: in flight under the matrix work below
+        asm volatile("" ::: "memory");
+        load_ids(k + 2, ids_new);
+        asm volatile("" ::: "memory");
+        SP_STAMP(1);
         if (any) {
             const u32x4* __restrict__ wb = wl + cur * SLICE + lane;
             constexpr int S = KC * NT;           // steps: (kc, n), the three planes of a step one step ahead of its 6 RT instructions
             u32x4 bq[2][3];
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) bq[0][pl] = wb[pl * 64];
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
             for (int st = 0; st < S; ++st) {
                 const int kc = st / NT, n = st % NT;
@@ -204,9 +240,15 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
                 }
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[st & 1][0]), bm = __builtin_bit_cast(bf16x8, bq[st & 1][1]),
                              bl = __builtin_bit_cast(bf16x8, bq[st & 1][2]);
+#if SP_ABLATE & 2
+#define SP_TERM(AA, BB)                                                                                                              \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                                \
+        acc[rt][n][0] += __builtin_bit_cast(float, AA[rt][kc][0] ^ __builtin_bit_cast(u32x4, BB)[0])
+#else
 #define SP_TERM(AA, BB)                                                                                                              \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                                \
         acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AA[rt][kc]), BB, acc[rt][n], 0, 0, 0)
+#endif
                 SP_TERM(al, bh);
                 SP_TERM(ah, bl);
                 SP_TERM(am, bm);
@@ -214,17 +256,38 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
                 SP_TERM(ah, bm);
                 SP_TERM(ah, bh);
 #undef SP_TERM
+                // keep the order written here: the next step's three fragment reads, then this step's matrix instructions
+                if (st + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * RT, 0);
             }
         }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            ids_cur[rt] = ids_nxt[rt];
-            ids_nxt[rt] = ids_nn[rt];
-        }
-        __syncthreads();
+        // The barrier only hands over the LDS slice: wait for this wave's share of it (the oldest of the loads above) and leave the
+        // rows and ids in flight across the barrier - __syncthreads() would drain them all (vmcnt(0): an LDS-DMA is a pending LDS write),
+        // which put one full memory round trip, the far-ahead id loads included, into every offset (1.6 us of the 3.7 us per offset)
+        SP_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * 2 * KC + RT) : "memory");
+        SP_STAMP(3);
+        __builtin_amdgcn_s_barrier();
+        SP_STAMP(4);
+    };
+    for (int k = 0;;) {
+        body(k, idA, idB, idC);
+        if (++k >= K) break;
+        body(k, idB, idC, idA);
+        if (++k >= K) break;
+        body(k, idC, idA, idB);
+        if (++k >= K) break;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (row0 >= n_out && !stats) return;
 
+#if SP_STAMPS
+    if (stats) {
+        if (lane == 0)
+            for (int i = 0; i < 6; ++i) reinterpret_cast<unsigned long long*>(stats)[(size_t)wave * 6 + i] = seg[i];
+        stats = nullptr;
+    }
+#endif
     // BatchNorm statistics of the layer's output from the accumulators - as gather_gemm_lds_kernel (same scratch layout and fold)
     if (stats) {
         float (*st_sh)[2][16 * NT] = reinterpret_cast<float (*)[2][16 * NT]>(wl);      // every wave is past its last slice read (barrier above)

@@ -281,6 +281,11 @@ class Rulebook:
         self.nbr_bwd = nbr_bwd    # [K, n_in]: output row per input row and offset (dgrad)
         self.flip_bwd = flip_bwd  # SubM: dgrad reuses nbr_fwd with the offsets reversed
         self.pair_cnt = pair_cnt  # [K] int32 on device
+        # the tables carry their counters (python attribute, no device work): what sees only a table - bench.py's launch records -
+        # can still count its pairs without reading the table itself, which may sit in a recycled arena slot by then
+        nbr_fwd._toda_pair_cnt = pair_cnt
+        if nbr_bwd is not nbr_fwd:
+            nbr_bwd._toda_pair_cnt = pair_cnt
         self.geom = geom
         self._order = {}
         self.in_indices = None    # strided conv: coordinates of its input sites (rows of the data-gradient table)
@@ -449,8 +454,9 @@ def _plan_tables(levels, level_counts, batch, steps, training):
     for st in steps:
         if st["key"] not in keys:
             keys.append(st["key"])
-    cnts = _alloc((len(keys), 64), torch.int32, dev)
-    cnts.zero_()                        # the pair counters of every table: one fill
+    # the pair counters of every table: one fill.  NOT from the arena slot: they outlive the batch (bench.py's per-launch records sum
+    # them after the timed region, when the slot's tables have long been overwritten by later batches) - 2 KB from torch's allocator
+    cnts = torch.zeros((len(keys), 64), dtype=torch.int32, device=dev)
     out = {}
     li = 0
     for st in steps:

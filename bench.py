@@ -56,6 +56,11 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 MFMA peak (dense)
+# matrix path "split" (toda_amd/csrc/spconv_split.cuh): six bf16 matrix instructions stand for one fp32 product, so a kernel on that
+# path is priced in fp32-EQUIVALENT FLOPs against the dense BF16 peak / 6 (the BF16 rate is 16 x the fp32 one: MI355X_MICROARCH.md,
+# Matrix cores) - never against 157.3
+MFMA_BF16_PEAK_TF = 16 * MFMA_F32_PEAK_TF
+MFMA_SPLIT_PEAK_TF = round(MFMA_BF16_PEAK_TF / 6.0, 1)
 
 
 def load_cfg(path):
@@ -387,8 +392,11 @@ def run_gpu(args, rank, world, device):
     import gc
     gc.collect()
     gc.disable()
+    loss_log = [] if os.environ.get("TODA_BENCH_LOSSES") else None       # every step's loss (device tensors, read after the clock has stopped)
     for it in range(args.warmup):
         loss = step(it)
+        if loss_log is not None:
+            loss_log.append(loss.detach())
     # everything the timed region needs is set up BEFORE the synchronisation (1024 + K events, the library's dispatch stamps): the GPU
     # should idle for microseconds, not milliseconds, between the last warm-up kernel and the first timed one (an idle GPU drops its
     # clocks; the first timed step of a run measured 1-1.6 ms longer than the steps after it)
@@ -414,6 +422,8 @@ def run_gpu(args, rank, world, device):
     for k, it in enumerate(range(args.warmup, args.warmup + args.steps)):
         th = time.perf_counter()
         loss = step(it)
+        if loss_log is not None:
+            loss_log.append(loss.detach())
         marks[k + 1].record()        # no sync: the median step time is read after the clock has stopped
         host_step_s.append(time.perf_counter() - th)
         alloc_marks.append(alloc_counters())
@@ -438,6 +448,8 @@ def run_gpu(args, rank, world, device):
     if phases is not None and rank == 0:
         print("[host phases, ms per step] " + ", ".join(f"{k} {v / args.steps * 1e3:.2f}" for k, v in phases.items()), file=sys.stderr)
     final_loss = float(loss.item())
+    if loss_log is not None and rank == 0:
+        print("[losses] " + " ".join(f"{float(v):.7g}" for v in torch.stack([v.float().reshape(()) for v in loss_log]).tolist()), file=sys.stderr)
     assert np.isfinite(final_loss), "training diverged"
     step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
     op_rows = None
@@ -487,8 +499,13 @@ def run_gpu(args, rank, world, device):
 
 # (gathered channels, produced channels, K) of a dominant launch shape -> (PMC summary under profiles/, kernel instantiation,
 # threads per output row of that instantiation, slack of the grid in threads)
-PMC_FILES = {(64, 64, 27): ("r04_pmc_gather_gemm_64x64.json", "<4, 4, 2", 2, 1024),        # C3: 64 lanes per 32-row tile
-             (128, 128, 27): ("r04_pmc_gather_gemm_128x128.json", "<8, 8, 1", 4, 2048)}   # C5: 512 threads per 128 rows
+PMC_FILES = {("native", 64, 64, 27): ("r05_pmc_gather_gemm_64x64.json", "gather_gemm_lds_kernel<4, 4, 2", 2, 1024),       # 64 lanes per 32-row tile
+             ("native", 128, 128, 27): ("r05_pmc_gather_gemm_128x128.json", "gather_gemm_lds_kernel<8, 8, 1", 4, 2048),  # 512 threads per 128 rows
+             ("split", 64, 64, 27): ("r05_pmc_split_64x64.json", "gg_split_kernel<2, 1, 4, 2", 2, 1024),
+             ("split", 128, 128, 27): ("r05_pmc_split_128x128.json", "gg_split_kernel<4, 1, 8, 2", 2, 1024),
+             ("native", 32, 32, 27): ("r05_pmc_gather_gemm_32x32.json", "gather_gemm_lds_kernel<2, 2, 2", 2, 1024),
+             ("split", 32, 32, 27): ("r05_pmc_split_32x32.json", "gg_split_kernel<1, 1, 2, 2", 2, 1024)}
+PMC_SOURCES = ("toda_amd/csrc/spconv.hip", "toda_amd/csrc/spconv_split.cuh")
 
 
 def _sha256(path):
@@ -501,17 +518,17 @@ def pmc_traffic(d):
     passes of this same command; PMC counters cannot be read from inside bench.py).  The summary records the SHA-256 of the
     kernel source it was collected on: when toda_amd/csrc/spconv.hip has changed since, or no profiled launch shape matches,
     the traffic is reported as null instead of a stale number.  Returns (bytes or None, where it came from)."""
-    ent = PMC_FILES.get((d["c_gather"], d["c_produce"], d["K"]))
+    ent = PMC_FILES.get((d["path"], d["c_gather"], d["c_produce"], d["K"]))
     if ent is None:
-        return None, "dominant launch shape is not one of the profiled kernels (64->64, 128->128 at K=27)"
+        return None, "dominant launch shape is not one of the profiled kernels (32->32, 64->64, 128->128 at K=27)"
     name, inst, per_row, slack = ent
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None, f"no PMC summary profiles/{name} committed"
     pmc = json.load(open(path))
-    src = os.path.join(ROOT, "toda_amd", "csrc", "spconv.hip")
-    if pmc.get("source_sha256", {}).get("toda_amd/csrc/spconv.hip") != _sha256(src):
-        return None, f"profiles/{name} was collected on another version of spconv.hip (stale)"
+    for rel in PMC_SOURCES:
+        if pmc.get("source_sha256", {}).get(rel) != _sha256(os.path.join(ROOT, rel)):
+            return None, f"profiles/{name} was collected on another version of {rel} (stale)"
     for shape in pmc["launch_shapes"]:
         if inst not in shape.get("kernel", "") or "hbm_bytes" not in shape:
             continue
@@ -523,31 +540,43 @@ def pmc_traffic(d):
 
 def roofline_from_timer(timer):
     """Dominant gather-GEMM launch shape (largest total time inside the timed region)."""
+    from toda_amd import lib as L
     groups = timer.summary()
     if not groups:
         return None, []
+    split_on = ops.matrix_path() == "split"
     rows = []
     for g in groups.values():
         ms = float(np.mean(g["ms"]))
         # SURVEY.md §8(d): B = 4*(N_in*Cin + N_out*Cout + K*Cin*Cout) + 8*Pairs ; FLOPs = 2*Pairs*Cin*Cout
         bytes_alg = 4.0 * (g["n_src"] * g["cg"] + g["n_out"] * g["cp"] + g["K"] * g["cg"] * g["cp"]) + 8.0 * g["pairs"]
         flops = 2.0 * g["pairs"] * g["cg"] * g["cp"]
-        t_hbm, t_mfma = bytes_alg / (HBM_PEAK_GBS * 1e9), flops / (MFMA_F32_PEAK_TF * 1e12)
+        # which matrix instructions this launch ran on: the split path covers the pairs toda_spconv_split_supported names (and only
+        # the launches that go through the packed operand: the narrow layers' compaction kernel never does)
+        path = "split" if (split_on and L.load().toda_spconv_split_supported(int(g["cg"]), int(g["cp"]))) else "native"
+        mfma_peak = MFMA_SPLIT_PEAK_TF if path == "split" else MFMA_F32_PEAK_TF
+        t_hbm, t_mfma = bytes_alg / (HBM_PEAK_GBS * 1e9), flops / (mfma_peak * 1e12)
         rows.append({"n_out": g["n_out"], "K": g["K"], "c_gather": g["cg"], "c_produce": g["cp"], "pairs": g["pairs"],
                      "launches": len(g["ms"]), "ms": ms, "total_ms": float(np.sum(g["ms"])), "bytes": bytes_alg,
-                     "flops": flops, "bound": "hbm" if t_hbm >= t_mfma else "mfma",
-                     "frac": max(t_hbm, t_mfma) / (ms * 1e-3)})
+                     "flops": flops, "bound": "hbm" if t_hbm >= t_mfma else "mfma", "path": path, "mfma_peak": mfma_peak,
+                     "frac": max(t_hbm, t_mfma) / (ms * 1e-3),
+                     "frac_of_fp32_mfma_peak": flops / (MFMA_F32_PEAK_TF * 1e12) / (ms * 1e-3)})
     rows.sort(key=lambda r: -r["total_ms"])
     d = rows[0]
     if d["bound"] == "hbm":
         achieved, peak, unit = d["bytes"] / (d["ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
     else:
-        achieved, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, MFMA_F32_PEAK_TF, "TFLOP/s"
+        achieved, peak, unit = d["flops"] / (d["ms"] * 1e-3) / 1e12, d["mfma_peak"], "TFLOP/s"
     traffic, traffic_source = pmc_traffic(d)
     roof = {"bound": d["bound"], "achieved": round(achieved, 3), "peak": peak, "unit": unit,
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": f"gather_gemm_kernel rows={d['n_out']} K={d['K']} {d['c_gather']}->{d['c_produce']} pairs={d['pairs']}",
-            "avg_launch_ms": round(d["ms"], 4)}
+            "kernel": f"{'gg_split_kernel' if d['path'] == 'split' else 'gather_gemm_kernel'} rows={d['n_out']} K={d['K']} "
+                      f"{d['c_gather']}->{d['c_produce']} pairs={d['pairs']}",
+            "avg_launch_ms": round(d["ms"], 4), "algorithmic_bytes": int(d["bytes"])}
+    if d["path"] == "split":
+        roof["peak_note"] = (f"fp32-equivalent FLOPs (2 x pairs x Cin x Cout) against the dense BF16 MFMA peak {MFMA_BF16_PEAK_TF:.0f} / 6: each fp32 product "
+                             f"is six bf16 matrix instructions (hi/mid/lo split, fp32 accumulate); the same launch is "
+                             f"{d['flops'] / (d['ms'] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF:.3f} of the fp32 MFMA peak {MFMA_F32_PEAK_TF}")
     return roof, rows
 
 
@@ -838,6 +867,9 @@ def main(argv=None):
             "config": {"workload": res["desc"], "global_batch": per_gpu * world,
                        "points_per_cloud": {"c3": 180000, "c2": 60000}.get(args.workload, "180000/35000 alternating"),
                        "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4),
+                       "matrix_path": ("bf16 hi/mid/lo split, 6 terms, fp32 accumulate (sparse gather-GEMMs of the 32/64/128-channel pairs; exact "
+                                       "operand split, TODA_MM=split)" if ops.matrix_path() == "split"
+                                       else "native fp32 MFMA (TODA_MM=native)"),
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
                        "alloc_retries": int(torch.cuda.memory_stats(device).get("num_alloc_retries", 0)),
                        "reserved_gib": round(torch.cuda.memory_reserved(device) / 2 ** 30, 2),

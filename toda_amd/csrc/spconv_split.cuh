@@ -121,17 +121,24 @@ split_pack_batch_kernel(const SplitPackBatch b) {
 }
 
 // ---- the kernel -------------------------------------------------------------------------------------------------------------------
-// BLK threads = BLK / 64 waves share one double-buffered weight slice: every workgroup re-reads the whole packed operand (24 KiB per
-// offset at 64 -> 64), so with 256-thread workgroups the slices are HALF of the kernel's vector-memory traffic (2.0 GB beside 1.9 GB of
-// gathered rows at 389 k rows) and the waves spend 39 % of their time pushing loads into a full memory pipeline (in-kernel stamps,
-// profiles/r05_split_stamps.txt).  Three waves per SIMD either way (168 registers): 256 threads x 3 workgroups or 768 x 1 per CU.
-template <int KC, int NT, int RT, int BLK>
-__global__ void __launch_bounds__(BLK, 3)
+// A STAGE is KCS of the KC 32-channel chunks of one offset: its weight slice (KCS NT 3 KiB) is what the workgroup shares through LDS
+// (double buffered, LDS-DMA), its rows' 128 KCS bytes per row are what a lane gathers one stage ahead.  64 -> 64: one stage per offset
+// (24 KiB); 128 -> 128: four stages per offset (24 KiB each: the whole 96 KiB slice of an offset would not fit twice).
+// BLK threads = BLK / 64 waves share the slice: every workgroup re-reads the whole packed operand, so with 256-thread workgroups the
+// slices are HALF of the kernel's vector-memory traffic at 64 -> 64 (2.0 GB beside 1.9 GB of gathered rows at 389 k rows).
+// Measured (C3 / C5 levels, ms per launch): ONE chunk per stage wins wherever it was tried - 64 -> 64 @ 389 k rows 0.346 (256 threads,
+// KCS 1: 122 registers, 4 waves per SIMD, 24 KiB of LDS) against 0.354 (768 threads, KCS 2) and 0.367 (256, KCS 2: 168 registers, 3 waves);
+// @ 117 k rows 0.124 / 0.179 / 0.135; strided 64 -> 64 forward 0.104 / 0.154 / 0.122: more resident waves hide more of the gathers.
+template <int KC, int KCS, int NT, int RT, int BLK, int WAVES>
+__global__ void __launch_bounds__(BLK, WAVES)
 gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict__ wps, const int* __restrict__ nbr, int n_out, int K, int cp,
-                const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stats) {
+                const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stats,
+                const unsigned char* __restrict__ cls_sorted, const GatherClasses classes) {
+    static_assert(KC % KCS == 0, "whole stages per offset");
     constexpr int CG = 32 * KC;
-    constexpr int UNITS = KC * NT * 3;      // 1 KiB wave-instruction images per offset
-    constexpr int SLICE = UNITS * 64;       // u32x4 per offset
+    constexpr int SPO = KC / KCS;            // stages per offset
+    constexpr int UNITS = KCS * NT * 3;      // 1 KiB wave-instruction images per stage
+    constexpr int SLICE = UNITS * 64;        // u32x4 per stage
     static_assert(2 * SLICE * 16 >= (BLK / 64) * 2 * 16 * NT * 4, "the statistics scratch aliases the weight buffers");
     __shared__ u32x4 wl[2 * SLICE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -156,30 +163,58 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
         live[rt] = row0 + rt * 16 + r < n_out;       // rows past the end read the ids of the last row and are never stored
         rows[rt] = live[rt] ? (order ? order[row0 + rt * 16 + r] : row0 + rt * 16 + r) : n_out - 1;
     }
-    auto load_ids = [&](int k, int (&dst)[RT]) {
-        const int kk = k < K ? k : K - 1;
+    // Data gradient of a strided convolution over class-sorted rows (GatherClasses, spconv.hip): when all rows of the WORKGROUP share one
+    // residue class it walks only that class's offset list (<= 8 of 27, ascending: the same sums in the same order); the barriers
+    // are the workgroup's, so one wave of another class sends the whole workgroup over all K offsets.
+    int KE = K;                                  // offsets this workgroup walks
+    bool listed = false;
+    unsigned long long kpack = 0;                // their indices, one byte each (a class has <= 8), in a scalar register pair
+    if (cls_sorted) {
+        const int p = row0 + (lane & (16 * RT - 1));
+        const int c = cls_sorted[p < n_out ? p : n_out - 1], c0 = __builtin_amdgcn_readfirstlane(c);
+        const bool same = __all(c == c0 || p >= n_out);
+        int* cw = reinterpret_cast<int*>(wl);
+        if (lane == 0) cw[wv] = same ? c0 : -1;
+        __syncthreads();
+        int cb = cw[0];
+#pragma unroll
+        for (int w = 1; w < BLK / 64; ++w) cb = (cw[w] == cb) ? cb : -1;
+        __syncthreads();                          // before the first slice lands in wl
+        if (cb >= 0 && classes.count[cb & 7] > 0 && classes.count[cb & 7] <= 8) {
+            listed = true;
+            KE = classes.count[cb & 7];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kpack |= (unsigned long long)classes.k[cb & 7][i] << (8 * i);
+            kpack = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(kpack >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)kpack);
+        }
+    }
+    auto kof = [&](int j) { return listed ? (int)((kpack >> (8 * j)) & 0xFF) : j; };
+    auto load_ids = [&](int j, int (&dst)[RT]) {
+        const int kk = kof(j < KE ? j : KE - 1);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             dst[rt] = __builtin_nontemporal_load(nbr + (size_t)kk * n_out + rows[rt]);      // past the last offset: its ids again, never used
         }
     };
-    auto gather = [&](const int (&src)[RT], bool valid, f32x4 (&raw)[RT][2 * KC]) {      // valid (wave-uniform): the offset exists
+    // rows of stage `part` of an offset: the lane's 16 bytes of the 64-byte segments 2 KCS part .. 2 KCS (part + 1) - 1
+    auto gather = [&](const int (&src)[RT], int part, bool valid, f32x4 (&raw)[RT][2 * KCS]) {      // valid (wave-uniform): the offset exists
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const bool ok = src[rt] >= 0 && valid;
-            const unsigned base = (unsigned)src[rt] * (unsigned)(CG * 4) + (unsigned)(16 * g);
+            const unsigned base = (unsigned)src[rt] * (unsigned)(CG * 4) + (unsigned)(16 * g) + (unsigned)(128 * KCS) * (unsigned)part;
 #pragma unroll
-            for (int i = 0; i < 2 * KC; ++i)
+            for (int i = 0; i < 2 * KCS; ++i)
                 raw[rt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? base + 64u * i : OOB, 0, 0));
         }
     };
-    auto stage = [&](int k, int buf) {       // the slice of offset k: global -> LDS, 1 KiB per wave-instruction, no registers
-        const int kk = k < K ? k : K - 1;
+    auto stage = [&](int st, int buf) {       // the slice of stage st = j SPO + part: global -> LDS, 1 KiB per wave-instruction, no registers
+        const int sc = st < KE * SPO ? st : KE * SPO - 1;
+        const int ss = kof(sc / SPO) * SPO + sc % SPO;
 #pragma unroll
         for (int t = 0; t < (UNITS + BLK / 64 - 1) / (BLK / 64); ++t) {
             const int u = t * (BLK / 64) + wv;
             if (UNITS % (BLK / 64) == 0 || u < UNITS)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(wps + (size_t)kk * SLICE + u * 64 + lane),
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(wps + (size_t)ss * SLICE + u * 64 + lane),
                                                  reinterpret_cast<float*>(&wl[buf * SLICE + u * 64]), 16, 0, 0);
         }
     };
@@ -187,11 +222,11 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
     // ids live in three register sets that rotate by NAME (the loop body is written three times): a copy of a set whose load is
     // still in flight, or the "row exists" select applied at load time, would be a wait for that load at the end of every offset
     int idA[RT], idB[RT], idC[RT];
-    f32x4 raw[RT][2 * KC];
+    f32x4 raw[RT][2 * KCS];
     load_ids(0, idA);
     load_ids(1, idB);
     stage(0, 0);
-    gather(idA, true, raw);
+    gather(idA, 0, true, raw);
     __syncthreads();
 
 #if SP_STAMPS
@@ -199,47 +234,43 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
 #endif
     auto body = [&](int k, const int (&ids_cur)[RT], const int (&ids_nxt)[RT], int (&ids_new)[RT]) {
-        const int cur = k & 1;
         SP_STAMP(5);
         bool any = false;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) any = any || __any(ids_cur[rt] >= 0);
-        // one straight-line body per (wave, offset) that has a neighbour in any of its rows: on the submanifold tables 0.83 of the
-        // executed tile rows are pairs this way against 0.85 with a test per 16-row tile (C3, 389 k rows) - not worth three bodies
-        // (hipcc joins them with 32 accumulator copies per offset)
-        u32x4 ah[RT][KC], am[RT][KC], al[RT][KC];
-        if (any) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+        for (int part = 0; part < SPO; ++part) {
+            const int cur = (k * SPO + part) & 1;
+            // one straight-line body per (wave, offset) that has a neighbour in any of its rows: on the submanifold tables 0.83 of the
+            // executed tile rows are pairs this way against 0.85 with a test per 16-row tile (C3, 389 k rows) - not worth three bodies
+            // (hipcc joins them with 32 accumulator copies per offset)
+            u32x4 ah[RT][KCS], am[RT][KCS], al[RT][KCS];
+            if (any) {
 #pragma unroll
-                for (int kc = 0; kc < KC; ++kc) sp_split8(raw[rt][2 * kc], raw[rt][2 * kc + 1], ah[rt][kc], am[rt][kc], al[rt][kc]);
-        }
-        SP_STAMP(0);
-        // issue order = the order the waits below and at the top of the next offset retire them in: the slice of offset k + 1 (needed
-        // by every wave behind the barrier), the rows of offset k + 1, the ids of offset k + 2
-        stage(k + 1, cur ^ 1);
-        asm volatile("" ::: "memory");
-        gather(ids_nxt, k + 1 < K, raw);          // rows of offset k + 1: in flight under the matrix work below
-        asm volatile("" ::: "memory");
-        load_ids(k + 2, ids_new);
-        asm volatile("" ::: "memory");
-        SP_STAMP(1);
-        if (any) {
-            const u32x4* __restrict__ wb = wl + cur * SLICE + lane;
-            constexpr int S = KC * NT;           // steps: (kc, n), the three planes of a step one step ahead of its 6 RT instructions
-            u32x4 bq[2][3];
+                for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) bq[0][pl] = wb[pl * 64];
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    for (int kc = 0; kc < KCS; ++kc) sp_split8(raw[rt][2 * kc], raw[rt][2 * kc + 1], ah[rt][kc], am[rt][kc], al[rt][kc]);
+            }
+            SP_STAMP(0);
+            // issue order = the order the waits below and at the top of the next stage retire them in: the slice of the next stage (needed
+            // by every wave behind the barrier), the rows of the next stage, the ids of offset k + 2
+            stage(k * SPO + part + 1, cur ^ 1);
+            asm volatile("" ::: "memory");
+            if (part + 1 < SPO) gather(ids_cur, part + 1, true, raw);
+            else gather(ids_nxt, 0, k + 1 < KE, raw);          // in flight under the matrix work below
+            asm volatile("" ::: "memory");
+            if (part == SPO - 1) load_ids(k + 2, ids_new);
+            asm volatile("" ::: "memory");
+            SP_STAMP(1);
+            if (any) {
+                const u32x4* __restrict__ wb = wl + cur * SLICE + lane;
+                // (reading the three planes of a step one step ahead of its matrix instructions - 12 more registers, the order pinned
+                // with sched_group_barrier - measured nothing at three waves per SIMD and spilled in the widest variants)
 #pragma unroll
-            for (int st = 0; st < S; ++st) {
-                const int kc = st / NT, n = st % NT;
-                if (st + 1 < S) {
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bq[(st + 1) & 1][pl] = wb[((st + 1) * 3 + pl) * 64];
-                }
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[st & 1][0]), bm = __builtin_bit_cast(bf16x8, bq[st & 1][1]),
-                             bl = __builtin_bit_cast(bf16x8, bq[st & 1][2]);
+                for (int st = 0; st < KCS * NT; ++st) {
+                    const int kc = st / NT, n = st % NT;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wb[(st * 3 + 0) * 64]), bm = __builtin_bit_cast(bf16x8, wb[(st * 3 + 1) * 64]),
+                                 bl = __builtin_bit_cast(bf16x8, wb[(st * 3 + 2) * 64]);
 #if SP_ABLATE & 2
 #define SP_TERM(AA, BB)                                                                                                              \
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                                \
@@ -249,34 +280,32 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
     _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                                \
         acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AA[rt][kc]), BB, acc[rt][n], 0, 0, 0)
 #endif
-                SP_TERM(al, bh);
-                SP_TERM(ah, bl);
-                SP_TERM(am, bm);
-                SP_TERM(am, bh);
-                SP_TERM(ah, bm);
-                SP_TERM(ah, bh);
+                    SP_TERM(al, bh);
+                    SP_TERM(ah, bl);
+                    SP_TERM(am, bm);
+                    SP_TERM(am, bh);
+                    SP_TERM(ah, bm);
+                    SP_TERM(ah, bh);
 #undef SP_TERM
-                // keep the order written here: the next step's three fragment reads, then this step's matrix instructions
-                if (st + 1 < S) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6 * RT, 0);
+                }
             }
+            // The barrier only hands over the LDS slice: wait for this wave's share of it (the oldest of the loads above) and leave the
+            // rows and ids in flight across the barrier - __syncthreads() would drain them all (vmcnt(0): an LDS-DMA is a pending LDS write)
+            SP_STAMP(2);
+            if (part == SPO - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * 2 * KCS + RT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * 2 * KCS) : "memory");
+            SP_STAMP(3);
+            __builtin_amdgcn_s_barrier();
+            SP_STAMP(4);
         }
-        // The barrier only hands over the LDS slice: wait for this wave's share of it (the oldest of the loads above) and leave the
-        // rows and ids in flight across the barrier - __syncthreads() would drain them all (vmcnt(0): an LDS-DMA is a pending LDS write),
-        // which put one full memory round trip, the far-ahead id loads included, into every offset (1.6 us of the 3.7 us per offset)
-        SP_STAMP(2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * 2 * KC + RT) : "memory");
-        SP_STAMP(3);
-        __builtin_amdgcn_s_barrier();
-        SP_STAMP(4);
     };
-    for (int k = 0;;) {
+    for (int k = 0;;) {          // k counts walked offsets (positions of the class list when there is one)
         body(k, idA, idB, idC);
-        if (++k >= K) break;
+        if (++k >= KE) break;
         body(k, idB, idC, idA);
-        if (++k >= K) break;
+        if (++k >= KE) break;
         body(k, idC, idA, idB);
-        if (++k >= K) break;
+        if (++k >= KE) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (row0 >= n_out && !stats) return;
@@ -351,7 +380,7 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
 static inline bool split_shape_ok(int c_gather, int c_produce) {
-    return (c_gather == 32 || c_gather == 64) && (c_produce == 32 || c_produce == 64);
+    return (c_gather == 32 || c_gather == 64 || c_gather == 128) && (c_produce == 32 || c_produce == 64 || c_produce == 128);
 }
 static inline size_t split_packed_bytes(int k_vol, int c_gather, int c_produce) {
     return (size_t)k_vol * (c_gather / 32) * (c_produce / 16) * 3 * 1024;

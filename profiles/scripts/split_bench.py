@@ -92,8 +92,37 @@ def run(tag, feat, w, nbr, c_produce, transpose=False, flip=False, order=None, c
     ops.set_matrix_path("native")
 
 
+def run_wgrad(tag, feat, g, nbr, wshape):
+    """weight gradient, both paths, against fp64: dW[co][k][ci] = sum over the pairs of offset k of feat[i][ci] g[o][co]."""
+    K, n_out = nbr.shape
+    cout, cin = wshape[0], wshape[-1]
+    f64 = torch.cat([feat.double(), torch.zeros(1, cin, dtype=torch.float64, device=feat.device)], 0)
+    ref = torch.zeros(cout, K, cin, dtype=torch.float64, device=feat.device)
+    for k in range(K):
+        idx = nbr[k].long()
+        idx = torch.where(idx >= 0, idx, torch.full_like(idx, feat.shape[0]))
+        ref[:, k, :] = g.double().t() @ f64[idx]
+    scale = float(ref.pow(2).mean().sqrt())
+    pairs = int((nbr >= 0).sum())
+    fl = 2.0 * pairs * cin * cout
+    line = f"{tag}: rows {n_out} pairs {pairs} wgrad {cin}x{cout}"
+    outs = {}
+    for mm in ("native", "split"):
+        ops.set_matrix_path(mm)
+        dw = ops.wgrad(feat, g, nbr, wshape)
+        t = timeit(lambda: ops.wgrad(feat, g, nbr, wshape), 5 if quick else 20)
+        d = dw.reshape(cout, K, cin).double() - ref
+        outs[mm] = dw
+        line += f" | {mm} {t:.4f} ms {fl / t / 1e9:.1f} TF/s rms {float(d.pow(2).mean().sqrt()) / scale:.3e} max {float(d.abs().max()) / scale:.3e}"
+    ops.set_matrix_path("split")
+    line += f" | rerun {bool((ops.wgrad(feat, g, nbr, wshape) == outs['split']).all())}"
+    print(line, flush=True)
+    ops.set_matrix_path("native")
+
+
 torch.manual_seed(0)
 ONLY = os.environ.get("SPLIT_ONLY")          # e.g. subm3: that level's forward alone (counter passes)
+WG_ONLY = os.environ.get("SPLIT_WGRAD_ONLY")  # e.g. subm3: that level's weight gradient alone
 chan = {'c3': {'subm2': 32, 'subm3': 64, 'subm4': 64}, 'c5': {'subm2': 32, 'subm3': 64, 'subm4': 128}}.get(name, {})
 for key, c in chan.items():
     if ONLY and key != ONLY:
@@ -102,19 +131,27 @@ for key, c in chan.items():
     n = rb.n_out
     feat = torch.relu(torch.randn(n, c, device='cuda')) * (1.0 + 3.0 * torch.rand(1, c, device='cuda'))     # post-ReLU-like, channel scales differ
     w = torch.randn(c, 3, 3, 3, c, device='cuda') * 0.05
+    if WG_ONLY:
+        if key == WG_ONLY:
+            run_wgrad(key, feat, torch.randn(n, c, device='cuda'), rb.nbr_fwd, tuple(w.shape))
+        continue
     run(key + " fwd", feat, w, rb.nbr_fwd, c)
     if ONLY:
         continue
     g = torch.randn(n, c, device='cuda')
     run(key + " dgrad", g, w, rb.nbr_bwd, c, True, rb.flip_bwd)
+    if c <= 64:
+        run_wgrad(key, feat, g, rb.nbr_fwd, tuple(w.shape))
 for key, cin, cout in {'c5': (('spconv3', 32, 64), ('spconv4', 64, 128))}.get(name, (('spconv3', 32, 64), ('spconv4', 64, 64))):
-    if ONLY:
+    if ONLY or WG_ONLY:
         break
     rb = plan[key]['rb']
     feat = torch.relu(torch.randn(rb.n_in, cin, device='cuda'))
     w = torch.randn(cout, 3, 3, 3, cin, device='cuda') * 0.05
     run(key + " fwd", feat, w, rb.nbr_fwd, cout)
     g = torch.randn(rb.n_out, cout, device='cuda')
+    if cin <= 64 and cout <= 64:
+        run_wgrad(key, feat, g, rb.nbr_fwd, tuple(w.shape))
     run(key + " dgrad(plain)", g, w, rb.nbr_bwd, cin, True, rb.flip_bwd)
     co = rb.class_order()
     if co is not None:

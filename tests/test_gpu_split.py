@@ -50,6 +50,18 @@ def exact_sums(feat, w, nbr, transpose, flip):
     return out
 
 
+def exact_wgrad(feat, g, nbr, cout, cin):
+    """fp64 on the device: dW[co][k][ci] = sum over the pairs (i, o) of offset k of feat[i][ci] g[o][co]."""
+    K = nbr.shape[0]
+    f64 = torch.cat([feat.double(), torch.zeros(1, cin, dtype=torch.float64, device=feat.device)], 0)
+    ref = torch.zeros(cout, K, cin, dtype=torch.float64, device=feat.device)
+    for k in range(K):
+        idx = nbr[k].long()
+        idx = torch.where(idx >= 0, idx, torch.full_like(idx, feat.shape[0]))
+        ref[:, k, :] = g.double().t() @ f64[idx]
+    return ref
+
+
 def both(ops, fn):
     res = {}
     for mm in ("native", "split"):
@@ -103,6 +115,36 @@ def test_both_paths_against_the_oracle_and_fp64(cin, cout, paths):
     ops.set_matrix_path("split")
     again = run()
     assert torch.equal(again[0], res["split"][0]) and torch.equal(again[1], res["split"][1])      # bit-reproducible
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64)])
+@pytest.mark.parametrize("strided", [False, True])
+def test_both_paths_weight_gradient(cin, cout, strided, paths):
+    """Weight gradient of a submanifold and of a strided layer: the oracle at the unchanged tolerance, fp64, reproducibility."""
+    ops = paths
+    shape, batch = [9, 40, 44], 2
+    idx, feat = H.clustered_sparse(batch, shape, 2300, cin, seed=cin * 7 + cout)
+    rng = np.random.default_rng(5)
+    feat = (np.maximum(feat, 0) * (1 + 3 * rng.random((1, cin)))).astype(np.float32)
+    if strided:
+        rb = ops.build_conv_rulebook(dev(idx), batch, shape, 3, 2, 1)[2]
+    else:
+        rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
+    n_out = rb.n_out
+    g = rng.standard_normal((n_out, cout)).astype(np.float32)
+    wshape = (cout, 3, 3, 3, cin)
+    dw0 = O.spconv_wgrad(feat, g, np.ascontiguousarray(rb.nbr_fwd.cpu().numpy()), wshape)
+    x, gt = dev(feat), dev(g)
+    ref = exact_wgrad(x, gt, rb.nbr_fwd, cout, cin)
+    res = both(ops, lambda: ops.wgrad(x, gt, rb.nbr_fwd, wshape))
+    scale = float(np.sqrt((dw0.astype(np.float64) ** 2).mean()))
+    for mm, dw in res.items():
+        np.testing.assert_allclose(dw.cpu().numpy(), dw0, rtol=1e-4, atol=1e-4 * max(scale, 1.0), err_msg=mm)
+    n_rms, n_max = rel_err(res["native"].reshape(cout, 27, cin), ref)
+    s_rms, s_max = rel_err(res["split"].reshape(cout, 27, cin), ref)
+    assert s_rms <= 1.5 * n_rms + 1e-8 and s_max <= 2.5 * n_max + 1e-7, (n_rms, s_rms, n_max, s_max)
+    ops.set_matrix_path("split")
+    assert torch.equal(ops.wgrad(x, gt, rb.nbr_fwd, wshape), res["split"])
 
 
 def test_split_row_order_and_empty_offsets(paths):
@@ -206,3 +248,10 @@ def test_split_error_on_the_full_size_level(paths):
         s_rms, s_max = rel_err(res["split"][which], ref)
         assert s_rms <= 1.5 * n_rms and s_max <= 1.5 * n_max, (which, n_rms, s_rms, n_max, s_max)
         assert s_rms < 2e-6          # both are fp32-exact sums: ~5e-7 of the output's rms
+    # the weight gradient of the same level: a contraction over ~233 k pairs per element
+    wshape = (c, 3, 3, 3, c)
+    ref_w = exact_wgrad(feat, g, rb.nbr_fwd, c, c)
+    res_w = both(ops, lambda: ops.wgrad(feat, g, rb.nbr_fwd, wshape))
+    n_rms, n_max = rel_err(res_w["native"].reshape(c, 27, c), ref_w)
+    s_rms, s_max = rel_err(res_w["split"].reshape(c, 27, c), ref_w)
+    assert s_rms <= 1.5 * n_rms and s_max <= 1.5 * n_max, ("wgrad", n_rms, s_rms, n_max, s_max)

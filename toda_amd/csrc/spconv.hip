@@ -1886,6 +1886,20 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
         TODA_LAUNCH_CHECK();
         return TODA_OK;
     }
+    if (matrix_path() == 1 && toda::wgrad_split_shape_ok(cin, cout)) {      // matrix path "split": spconv_split.cuh
+        const dim3 g(chunks_launch * k_vol);
+#define WGS(MM, NN)                                                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<MM, NN>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, \
+                       xcd_chunks)
+        if (cin == 32 && cout == 32) WGS(2, 2);
+        else if (cin == 32) WGS(2, 4);
+        else if (cout == 32) WGS(4, 2);
+        else WGS(4, 4);
+#undef WGS
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slab, chunks, elems, dw);
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
     const dim3 grid(chunks_launch * k_vol * nsub_m * nsub_n);
     const bool exact = cin == 16 * MT && cout == 16 * NT;
 #define WG(MM, NN)                                                                                                  \

@@ -36,6 +36,32 @@ __device__ __forceinline__ unsigned sp_pack_hi(float x0, float x1) {
 __device__ __forceinline__ float sp_trunc(float x) {
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
 }
+#ifndef SP_RNE
+#define SP_RNE 0         // experiment: 1 = round-to-nearest planes (v_cvt_pk_bf16_f32) instead of truncated ones
+#endif
+#ifndef WGS_ACCS
+#define WGS_ACCS 2       // accumulator sets of the split weight gradient (see wgrad_split_kernel; 1 and 3 are measurement builds)
+#endif
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sp_pack_rne(float x0, float x1) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{x0, x1}), bf16x2v));
+}
+// two fp32 values -> their three packed bf16 planes
+__device__ __forceinline__ void sp_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#if SP_RNE
+    h = sp_pack_rne(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
+    m = sp_pack_rne(r0, r1);
+    const float l0 = r0 - __builtin_bit_cast(float, m << 16), l1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
+    l = sp_pack_rne(l0, l1);
+#else
+    h = sp_pack_hi(x0, x1);
+    const float r0 = x0 - sp_trunc(x0), r1 = x1 - sp_trunc(x1);
+    m = sp_pack_hi(r0, r1);
+    l = sp_pack_hi(r0 - sp_trunc(r0), r1 - sp_trunc(r1));
+#endif
+}
 #ifndef SP_STAMPS
 #define SP_STAMPS 0      // diagnostic build only: per-wave cycle sums of the loop's segments through the statistics pointer (no statistics)
 #endif
@@ -377,6 +403,240 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
         }
     }
 }
+
+// ---- weight gradient on the split path -----------------------------------------------------------------------------------------------
+// dW[co][k][ci] = sum over the pairs (i, o) of offset k of in[i][ci] dout[o][co]: the structure of wgrad_kernel (spconv.hip: one workgroup
+// per (row chunk, offset), every wave compacts the valid pairs of its rows into an LDS queue and contracts over PAIRS, per-chunk slabs
+// folded in fixed order) with 32 pairs per matrix instruction instead of 4: lane (ii, g) holds the pairs 8 g .. 8 g + 7 of a round for the
+// channels MT ii .. MT ii + MT - 1 of both sides - one 16-byte (MT = 4) or 8-byte (MT = 2) load per pair and side, the 16 lanes of a
+// group read one whole row -, splits the 8 MT values of a side into three bf16 planes whose registers already ARE the fragments
+// (element j of tile m = pair 8 g + j, channel MT ii + m), and the six cross terms go to v_mfma_f32_16x16x32_bf16.  Both operands are
+// activations here, so both are split in registers: 11 vector instructions per 2 values and side.
+// TWO accumulator sets: the three terms of order 2^-16 (al.bh, ah.bl, am.bm) go to their own registers and are added once at the end.
+// A contraction over hundreds of pairs makes the accumulator large against one instruction's contribution, and every matrix
+// instruction rounds its accumulator: six roundings per 32 pairs into ONE set measured 1.88 x the native kernel's rms error against fp64
+// (64 x 64 @ 389 k rows: 7.8e-7 against 4.2e-7 of the result's rms), the small terms apart 0.91 x (3.8e-7), three sets (hh alone) 0.55 x
+// but 192 accumulator registers spill; rounded-to-nearest planes instead of truncated ones change nothing (the dropped cross terms are
+// not what is measured).  Same time per launch as one set.
+template <int MTB, int NTB>
+// 32 x 64 wants 175 registers: two waves per SIMD without spills (0.129 ms at spconv3 of C3) beat three with 13 spilled dwords (0.162)
+__global__ void __launch_bounds__(SC_BLOCK, (MTB * NTB <= 4) ? 4 : ((MTB == 4 && NTB == 2) ? 3 : 2))
+wgrad_split_kernel(const float* __restrict__ in, int n_in, const float* __restrict__ dout, const int* __restrict__ nbr, int n_out, int K,
+                   int rows_per_chunk, float* __restrict__ slab, int xcd_chunks) {
+    static_assert((MTB == 2 || MTB == 4) && (NTB == 2 || NTB == 4), "32 or 64 channels a side");
+    constexpr int cin = 16 * MTB, cout = 16 * NTB;
+    constexpr int QCAP = 64 + 32;
+    __shared__ float red[MTB * NTB * 4 * 64];
+    __shared__ int q_in[SC_BLOCK / 64][QCAP], q_out[SC_BLOCK / 64][QCAP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ii = lane & 15, g = lane >> 4;
+    const int n_chunks = xcd_chunks < 0 ? -xcd_chunks : xcd_chunks;
+    int chunk, k;
+    {
+        const int b = blockIdx.x;
+        if (xcd_chunks > 0) {      // the K offset-blocks of a chunk side by side on ONE XCD (see wgrad_kernel)
+            const int xcd = b & 7, t = (b >> 3) / K;
+            k = (b >> 3) - t * K;
+            chunk = t * 8 + xcd;
+        } else {
+            chunk = b % n_chunks;
+            k = b / n_chunks;
+        }
+    }
+    const int row_begin = chunk * rows_per_chunk;
+    if (row_begin >= n_out) return;      // a padding chunk of the XCD-ordered grid (whole block, before any barrier)
+    const int row_end = min(n_out, row_begin + rows_per_chunk);
+    int* qi = q_in[wv];
+    int* qo = q_out[wv];
+
+    f32x4 acc[MTB][NTB];
+#if WGS_ACCS >= 2
+    f32x4 acc_s[MTB][NTB];
+#endif
+#if WGS_ACCS >= 3
+    f32x4 acc_m[MTB][NTB];
+#endif
+#pragma unroll
+    for (int m = 0; m < MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+            acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if WGS_ACCS >= 2
+            acc_s[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+#if WGS_ACCS >= 3
+            acc_m[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+        }
+    const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cin * 4u);
+    const __amdgpu_buffer_rsrc_t dout_rsrc = table_rsrc(dout, (unsigned)n_out * (unsigned)cout * 4u);
+    const unsigned lane_a = (unsigned)(MTB * ii) * 4u, lane_b = (unsigned)(NTB * ii) * 4u;
+    constexpr unsigned row_a = (unsigned)cin * 4u, row_b = (unsigned)cout * 4u;
+
+    // one round: queue entries [d, d + 32); entries >= limit contribute zeros (out-of-range buffer offsets)
+    auto round32 = [&](int d, int limit, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        float a[8][MTB], b[8][NTB];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = d + 8 * g + j;
+            const bool ok = FULL || p < limit;
+            const int pc = ok ? p : d;
+            const unsigned ia = (unsigned)qi[pc] + lane_a, ib = (unsigned)qo[pc] + lane_b;
+            if constexpr (MTB == 4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? ia : OOB, 0, 0));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[j][m] = v[m];
+            } else {
+                const f32x2w v = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, ok ? ia : OOB, 0, 0));
+                a[j][0] = v[0], a[j][1] = v[1];
+            }
+            if constexpr (NTB == 4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dout_rsrc, ok ? ib : OOB, 0, 0));
+#pragma unroll
+                for (int n = 0; n < 4; ++n) b[j][n] = v[n];
+            } else {
+                const f32x2w v = __builtin_bit_cast(f32x2w, __builtin_amdgcn_raw_buffer_load_b64(dout_rsrc, ok ? ib : OOB, 0, 0));
+                b[j][0] = v[0], b[j][1] = v[1];
+            }
+        }
+        // planes: element j of tile m = a[j][m]
+        u32x4 ah[MTB], am[MTB], al[MTB];
+#pragma unroll
+        for (int m = 0; m < MTB; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h_, m_, l_;
+                sp_split2(a[2 * q][m], a[2 * q + 1][m], h_, m_, l_);
+                ah[m][q] = h_, am[m][q] = m_, al[m][q] = l_;
+            }
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+            u32x4 bh, bm, bl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h_, m_, l_;
+                sp_split2(b[2 * q][n], b[2 * q + 1][n], h_, m_, l_);
+                bh[q] = h_, bm[q] = m_, bl[q] = l_;
+            }
+#define WS_TERM(ACC, AA, BB)                                                                                             \
+    _Pragma("unroll") for (int m = 0; m < MTB; ++m)                                                                       \
+        ACC[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AA[m]), __builtin_bit_cast(bf16x8, BB), ACC[m][n], 0, 0, 0)
+#if WGS_ACCS == 1
+            WS_TERM(acc, al, bh);
+            WS_TERM(acc, ah, bl);
+            WS_TERM(acc, am, bm);
+            WS_TERM(acc, am, bh);
+            WS_TERM(acc, ah, bm);
+            WS_TERM(acc, ah, bh);
+#elif WGS_ACCS == 2
+            WS_TERM(acc_s, al, bh);
+            WS_TERM(acc_s, ah, bl);
+            WS_TERM(acc_s, am, bm);
+            WS_TERM(acc, am, bh);
+            WS_TERM(acc, ah, bm);
+            WS_TERM(acc, ah, bh);
+#else
+            WS_TERM(acc_s, al, bh);
+            WS_TERM(acc_s, ah, bl);
+            WS_TERM(acc_s, am, bm);
+            WS_TERM(acc_m, am, bh);
+            WS_TERM(acc_m, ah, bm);
+            WS_TERM(acc, ah, bh);
+#endif
+#undef WS_TERM
+        }
+    };
+
+    int qn = 0;  // wave-uniform queue length (< 32 between batches)
+    const int base0 = row_begin + wv * 64;
+    int iv_next = nbr[(size_t)k * n_out + min(base0 + lane, n_out - 1)];  // clamped, unconditional: the ids of the NEXT 64 rows are in flight
+    for (int base = base0; base < row_end; base += SC_BLOCK) {            // under this batch's rounds
+        const int o = base + lane;
+        const int iv = iv_next;
+        iv_next = nbr[(size_t)k * n_out + min(o + SC_BLOCK, n_out - 1)];
+        const int i = o < row_end ? iv : -1;
+        const unsigned long long vote = __ballot(i >= 0);
+        if (vote == 0) continue;
+        if (i >= 0) {
+            const int pos = qn + __popcll(vote & ((1ull << lane) - 1));
+            qi[pos] = (int)((unsigned)i * row_a);      // byte offsets of the rows
+            qo[pos] = (int)((unsigned)o * row_b);
+        }
+        qn += __popcll(vote);
+        __builtin_amdgcn_wave_barrier();
+        int done = 0;
+        while (qn - done >= 32) {
+            round32(done, qn, std::true_type{});
+            done += 32;
+        }
+        const int left = qn - done;
+        if (done > 0 && left > 0) {  // move the tail (< 32 entries) to the front of the queue
+            int ti = 0, to = 0;
+            if (lane < left) {
+                ti = qi[done + lane];
+                to = qo[done + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < left) {
+                qi[lane] = ti;
+                qo[lane] = to;
+            }
+        }
+        qn = left;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (qn > 0) round32(0, qn, std::false_type{});
+#if WGS_ACCS >= 2
+#pragma unroll
+    for (int m = 0; m < MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+#if WGS_ACCS >= 3
+            acc[m][n] = (acc_s[m][n] + acc_m[m][n]) + acc[m][n];
+#else
+            acc[m][n] = acc_s[m][n] + acc[m][n];
+#endif
+        }
+#endif
+
+    // fold the 4 waves of the block in fixed order 0+1+2+3, then the chunk's slab (as wgrad_kernel)
+    for (int src = 1; src < SC_BLOCK / 64; ++src) {
+        if (wv == src) {
+#pragma unroll
+            for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) red[((m * NTB + n) * 4 + reg) * 64 + lane] = acc[m][n][reg];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int m = 0; m < MTB; ++m)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[m][n][reg] += red[((m * NTB + n) * 4 + reg) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wv != 0) return;
+    // D: col = lane & 15 -> produced-channel tile column, row = 4 (lane >> 4) + reg -> gathered-channel tile row
+    float* dst = slab + (size_t)chunk * cout * K * cin;
+#pragma unroll
+    for (int m = 0; m < MTB; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int ci = MTB * (4 * g + reg) + m;
+                const int co = NTB * ii + n;
+                dst[((size_t)co * K + k) * cin + ci] = acc[m][n][reg];
+            }
+}
+
+static inline bool wgrad_split_shape_ok(int cin, int cout) { return (cin == 32 || cin == 64) && (cout == 32 || cout == 64); }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
 static inline bool split_shape_ok(int c_gather, int c_produce) {

@@ -140,8 +140,7 @@ for key, c in chan.items():
         continue
     g = torch.randn(n, c, device='cuda')
     run(key + " dgrad", g, w, rb.nbr_bwd, c, True, rb.flip_bwd)
-    if c <= 64:
-        run_wgrad(key, feat, g, rb.nbr_fwd, tuple(w.shape))
+    run_wgrad(key, feat, g, rb.nbr_fwd, tuple(w.shape))
 for key, cin, cout in {'c5': (('spconv3', 32, 64), ('spconv4', 64, 128))}.get(name, (('spconv3', 32, 64), ('spconv4', 64, 64))):
     if ONLY or WG_ONLY:
         break

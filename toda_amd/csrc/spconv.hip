@@ -1875,6 +1875,21 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
     static const int env_wg_xcd = getenv("TODA_WG_XCD") ? atoi(getenv("TODA_WG_XCD")) : 1;
     const int chunks_launch = env_wg_xcd ? (chunks + 7) / 8 * 8 : chunks;      // padded to whole rounds of the 8 XCDs: blocks of the padding chunks leave at once
     const int xcd_chunks = env_wg_xcd ? chunks_launch : -chunks;
+    if (matrix_path() == 1 && toda::wgrad_split_shape_ok(cin, cout)) {      // matrix path "split": spconv_split.cuh
+        const dim3 g(chunks_launch * k_vol);
+#define WGS(MM, NN)                                                                                                                       \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<MM, NN>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, \
+                       xcd_chunks)
+        if (cin == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<4, 4, true>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, xcd_chunks);
+        else if (cin == 32 && cout == 32) WGS(2, 2);
+        else if (cin == 32) WGS(2, 4);
+        else if (cout == 32) WGS(4, 2);
+        else WGS(4, 4);
+#undef WGS
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slab, chunks, elems, dw);
+        TODA_LAUNCH_CHECK();
+        return TODA_OK;
+    }
     if (MT == 8 && NT == 8 && (env_sub & 4)) {   // cooperative quarters: 0.75 -> 0.68 ms on 97.5k x 27 x 128 x 128
         if (cin == 128 && cout == 128)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true, true>), dim3(chunks_launch * k_vol), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
@@ -1882,20 +1897,6 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_kernel<4, 4, true>), dim3(chunks_launch * k_vol), dim3(SC_BLOCK), 0, s, in, n_in, cin, dout,
                                cout, nbr, n_out, k_vol, rpc, MT, NT, 2, slab, xcd_chunks);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slab, chunks, elems, dw);
-        TODA_LAUNCH_CHECK();
-        return TODA_OK;
-    }
-    if (matrix_path() == 1 && toda::wgrad_split_shape_ok(cin, cout)) {      // matrix path "split": spconv_split.cuh
-        const dim3 g(chunks_launch * k_vol);
-#define WGS(MM, NN)                                                                                                                       \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<MM, NN>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, \
-                       xcd_chunks)
-        if (cin == 32 && cout == 32) WGS(2, 2);
-        else if (cin == 32) WGS(2, 4);
-        else if (cout == 32) WGS(4, 2);
-        else WGS(4, 4);
-#undef WGS
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(elems, SC_BLOCK)), dim3(SC_BLOCK), 0, s, slab, chunks, elems, dw);
         TODA_LAUNCH_CHECK();
         return TODA_OK;

@@ -9,8 +9,10 @@ started plain, in which case this process is only a launcher: before anything to
 lets rank 0's JSON line through and exits with the child's status (reference: tools/scripts/dist_train.sh:18,
 tools/train.py:65-74,143, pcdet/utils/common_utils.py:161-176).
 
-A step = one pass of the hot path over one batch of synthetic clouds that are already resident in
-HBM: GPU voxelisation + MeanVFE -> VoxelBackBone8x (rulebooks + sparse convs) -> HeightCompression
+A step = one pass of the hot path over one batch of synthetic clouds.  --input host (default): the collated batch sits in PINNED
+HOST memory and every step uploads it (points + boxes, 7.2 MB at C3) on the input stream inside the timed region, as the reference's
+load_data_to_gpu does every iteration (pcdet/models/__init__.py:23-34); --input resident keeps the raw clouds in HBM (the line says
+which one ran).  Then: GPU voxelisation + MeanVFE -> VoxelBackBone8x (rulebooks + sparse convs) -> HeightCompression
 -> BaseBEVBackbone -> CenterHead (GPU target assignment, losses) -> backward -> grad-norm clip ->
 Adam one-cycle step.  Workload at every N: BASELINE.json configs[2]/[3] (CenterPoint-Voxel on
 180k-point Waymo-shape clouds, 2 samples per GPU, fp32) — the configuration the "training
@@ -69,22 +71,28 @@ def load_cfg(path):
     return cfg
 
 
-def make_device_batches(dataset, per_gpu, n_batches, rank, device):
-    """Collated batches with `points` / `gt_boxes` already on the device (inputs resident in HBM)."""
+def _place(a, device, host):
+    """fp32 tensor of a collated array: pinned host memory (uploaded per step by load_data_to_gpu) or resident on the device."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).float()
+    return t.pin_memory() if host else t.to(device)
+
+
+def make_device_batches(dataset, per_gpu, n_batches, rank, device, host=False):
+    """Collated batches with `points` / `gt_boxes` in pinned host memory (host=True) or already on the device."""
     batches = []
     for b in range(n_batches):
         base = (rank * n_batches + b) * per_gpu
         samples = [dataset[(base + i) % len(dataset)] for i in range(per_gpu)]
         col = dataset.collate_batch(samples)
         out = {"batch_size": col["batch_size"], "points_per_sample": col["points_per_sample"]}
-        out["points"] = torch.from_numpy(col["points"]).float().to(device)
-        out["gt_boxes"] = torch.from_numpy(col["gt_boxes"]).float().to(device)
+        out["points"] = _place(col["points"], device, host)
+        out["gt_boxes"] = _place(col["gt_boxes"], device, host)
         batches.append(out)
     return batches
 
 
-def make_device_pair_batches(dataset, per_gpu, n_batches, rank, device):
-    """(adv, org) batches of the stage-2 consistency step, tensors resident on the device."""
+def make_device_pair_batches(dataset, per_gpu, n_batches, rank, device, host=False):
+    """(adv, org) batches of the stage-2 consistency step, tensors in pinned host memory or resident on the device."""
     out = []
     for b in range(n_batches):
         base = (rank * n_batches + b) * per_gpu
@@ -92,8 +100,8 @@ def make_device_pair_batches(dataset, per_gpu, n_batches, rank, device):
         dev = []
         for col in pair:
             d = {k: v for k, v in col.items() if k in ("batch_size", "points_per_sample", "augmentation_list", "augmentation_params")}
-            d["points"] = torch.from_numpy(col["points"]).float().to(device)
-            d["gt_boxes"] = torch.from_numpy(col["gt_boxes"]).float().to(device)
+            d["points"] = _place(col["points"], device, host)
+            d["gt_boxes"] = _place(col["gt_boxes"], device, host)
             dev.append(d)
         out.append(tuple(dev))
     return out
@@ -205,13 +213,16 @@ def run_gpu(args, rank, world, device):
     cfg = load_cfg(yaml_path)
     pair = args.workload.endswith("cl")
     mixed = args.workload.endswith("mix")
+    host_input = getattr(args, "input", "host") == "host" and os.environ.get("TODA_PREFETCH", "1") == "1"
     if pair:
         from toda_amd.pcdet.datasets import SyntheticPairDataset
         from toda_amd.pcdet.models import DistModel, model_fn_decorator_cl
         dataset = SyntheticPairDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
     elif mixed:
         from toda_amd.pcdet.datasets import SyntheticMixDataset
-        cfg.DATA_CONFIG.CACHE_FRAMES = True      # raw clouds of both domains stay resident in HBM
+        # the raw clouds of both domains are generated before the clock starts and kept in pinned host memory (every access uploads the
+        # frame: the mix runs on the device) or, --input resident, in HBM
+        cfg.DATA_CONFIG.CACHE_FRAMES = "host" if host_input else True
         for step_cfg in cfg.DATA_CONFIG.DATA_PROCESSOR:
             if step_cfg.NAME == "shuffle_points":
                 step_cfg.SHUFFLE_ON_DEVICE = True   # permutation drawn by torch on the device instead of numpy on the host
@@ -248,7 +259,7 @@ def run_gpu(args, rank, world, device):
         from toda_amd.pcdet.utils.common_utils import wrap_ddp
         model = wrap_ddp(model, device_ids=[device.index], **ddp_kw)
     if pair:
-        batches = make_device_pair_batches(dataset, per_gpu, args.batches, rank, device)
+        batches = make_device_pair_batches(dataset, per_gpu, args.batches, rank, device, host_input)
         cl_fn = model_fn_decorator_cl()
     elif mixed:
         batches = None
@@ -256,7 +267,7 @@ def run_gpu(args, rank, world, device):
             dataset._frame(dataset.source_kind, i % dataset.num_source)
             dataset._frame(dataset.target_kind, 100_000 + i % dataset.num_target)
     else:
-        batches = make_device_batches(dataset, per_gpu, args.batches, rank, device)
+        batches = make_device_batches(dataset, per_gpu, args.batches, rank, device, host_input)
     params = [p for p in net.parameters() if p.requires_grad]
     clip = cfg.OPTIMIZATION.GRAD_NORM_CLIP
     timer = KernelTimer()
@@ -298,6 +309,7 @@ def run_gpu(args, rank, world, device):
 
     # experiments (not a workload): TODA_BENCH_REUSE_BATCH=1 prepares ONE batch and trains on it every step (no input pipeline at all);
     # TODA_BENCH_THROTTLE=k holds the host at most k steps ahead of the GPU (host-side wait for the end of step t - k)
+    step_sizes = []          # (points, voxels) of every timed step
     reuse = None
     throttle = int(os.environ.get("TODA_BENCH_THROTTLE", "0"))
     step_done = []
@@ -359,6 +371,8 @@ def run_gpu(args, rank, world, device):
                 batch = dict(batches[it % len(batches)])
             if prefetch is None:
                 voxelize_on_gpu(batch, dataset.voxel_cfg)
+            if timer.enabled:       # shapes only (no read-back): the step's input size beside its time
+                step_sizes.append((int(batch["points"].shape[0]), int(batch["voxel_coords"].shape[0])))
             if ph is not None:
                 ph["next"] += time.perf_counter() - t_ph
                 t_ph = time.perf_counter()
@@ -490,7 +504,7 @@ def run_gpu(args, rank, world, device):
     comm = None
     if world > 1 and not fwd_only:
         comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3)
-    return {"elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
+    return {"host_input": host_input, "step_sizes": step_sizes, "elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
             "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows, "issue_s": t_issued, "cpu_s": cpu_busy,
             "host_step_ms": [t * 1e3 for t in host_step_s],
             "device_allocs": [alloc_marks[k + 1][0] - alloc_marks[k][0] for k in range(args.steps)],
@@ -641,7 +655,9 @@ def cpu_baseline(cfg, workload, n_scenes=5):
         cl_fn, cl_model = model_fn_decorator_cl(), DistModel(model)
     with oracle_backend():
         t0 = time.perf_counter()
-        for i, batch in enumerate(batches):        # one step per scene (bs 1)
+        for i, batch in enumerate([batches[0]] + batches):        # one step per scene (bs 1); the first one is an UNTIMED warm-up
+            if i == 1:                                             # (first-touch of the worker threads' buffers, torch's thread pool: 2.1 s against 1.7 s)
+                t0 = time.perf_counter()
             if fwd_only:
                 with torch.no_grad():
                     b = dict(batch)
@@ -658,12 +674,14 @@ def cpu_baseline(cfg, workload, n_scenes=5):
                     loss = fn(model, dict(batch)).loss
                 loss.backward()
                 clip_and_step(optimizer, list(model.parameters()), cfg.OPTIMIZATION.GRAD_NORM_CLIP)
-            say(f"step {i + 1}/{len(batches)} done after {time.perf_counter() - t0:.1f} s")
+            say(f"warm-up step done after {time.perf_counter() - t0:.1f} s" if i == 0 else f"step {i}/{len(batches)} done after {time.perf_counter() - t0:.1f} s")
         dt = time.perf_counter() - t0 + mix_s
     what = {"c2": "forward pass voxel features -> VoxelBackBone8x -> dense BEV (no gradients)",
             "c5cl": "consistency step (2 forwards + 1 backward + optimizer)"}.get(workload, "full train step (fwd + bwd + clip + Adam)")
     return {"value": round(len(batches) / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{len(batches)} scene(s) of {sorted(set(npts))} points from this workload's own generator (bs 1), one {what} each = "
+            "cores_note": f"{avail} CPUs in this rank's affinity mask; threads capped at the GPU box's share for one GPU (16) unless "
+                          "TODA_CPU_BASELINE_THREADS says otherwise",
+            "sample": f"one untimed warm-up step, then {len(batches)} scene(s) of {sorted(set(npts))} points from this workload's own generator (bs 1), one {what} each = "
                       f"{dt:.1f} s in total; sparse part = oracle/ C port (OpenMP, AVX2), dense part = torch CPU"}
 
 
@@ -812,6 +830,8 @@ def main(argv=None):
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batches", type=int, default=2, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--input", default="host", choices=("host", "resident"),
+                    help="host: collated batches in pinned host memory, uploaded every step inside the timed region; resident: in HBM")
     ap.add_argument("--per-gpu", type=int, default=None, help="override the workload's samples per GPU (exploration)")
     ap.add_argument("--layers", action="store_true",
                     help="after the timed region run 3 more steps with every hand-written kernel bracketed by HIP events and print the "
@@ -859,6 +879,10 @@ def main(argv=None):
             print("[host_enqueue_ms] " + " ".join(f"{t:.2f}" for t in res["host_step_ms"]), file=sys.stderr)
             print("[device_allocs] " + " ".join(str(v) for v in res["device_allocs"]) + "  [alloc_retries] " +
                   " ".join(str(v) for v in res["alloc_retries"]), file=sys.stderr)
+            if len(res["step_sizes"]) == len(step_ms):
+                print("[step table] step points voxels gpu_ms host_enqueue_ms device_allocs", file=sys.stderr)
+                for k, ((npt, nvx), t, h, a) in enumerate(zip(res["step_sizes"], step_ms, res["host_step_ms"], res["device_allocs"])):
+                    print(f"[step table] {k} {npt} {nvx} {t:.2f} {h:.2f} {a}", file=sys.stderr)
         line = {
             "metric": "LiDAR training samples/sec" if args.workload != "c2" else "LiDAR backbone forward samples/sec", "value": round(total_samples / res["elapsed"], 3),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -867,6 +891,8 @@ def main(argv=None):
             "config": {"workload": res["desc"], "global_batch": per_gpu * world,
                        "points_per_cloud": {"c3": 180000, "c2": 60000}.get(args.workload, "180000/35000 alternating"),
                        "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4),
+                       "input": ("pinned host memory, uploaded every step on the input stream inside the timed region (--input host)"
+                                 if res["host_input"] else "raw clouds resident in HBM before the clock starts (--input resident)"),
                        "matrix_path": ("bf16 hi/mid/lo split, 6 terms, fp32 accumulate (sparse gather-GEMMs of the 32/64/128-channel pairs; exact "
                                        "operand split, TODA_MM=split)" if ops.matrix_path() == "split"
                                        else "native fp32 MFMA (TODA_MM=native)"),
@@ -884,6 +910,15 @@ def main(argv=None):
             "ms_per_step_p10_p90": [round(float(np.percentile(step_ms, q)), 3) for q in (10, 90)] if step_ms else None,
             "roofline": roof,
         }
+        if len(res["step_sizes"]) == len(step_ms) and len(set(res["step_sizes"])) > 2:
+            # input size varies from step to step (the mix): how much of the step-time spread is the voxel count
+            vx = np.array([v for _, v in res["step_sizes"]], np.float64)
+            tm = np.array(step_ms, np.float64)
+            slope, icpt = np.polyfit(vx, tm, 1)
+            resid = tm - (slope * vx + icpt)
+            line["step_time_vs_voxels"] = {"corr": round(float(np.corrcoef(vx, tm)[0, 1]), 3), "ms_per_100k_voxels": round(float(slope * 1e5), 3),
+                                           "intercept_ms": round(float(icpt), 3), "residual_p10_p90_ms": [round(float(np.percentile(resid, q)), 3) for q in (10, 90)],
+                                           "voxels_min_max": [int(vx.min()), int(vx.max())]}
         if res.get("comm"):
             line["comm"] = res["comm"]
         if world == 1 and not args.no_cpu_baseline:

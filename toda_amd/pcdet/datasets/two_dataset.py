@@ -52,7 +52,8 @@ class SyntheticMixDataset(DatasetTemplate):
         self.laser_pitch_angle = dataset_cfg.get("LASERMIX_PITCH_ANGLE", [-20, 0])
         self.laser_num_areas = dataset_cfg.get("LASERMIX_NUM_AREAS", 3)
         self.laser_num_angles = dataset_cfg.get("LASERMIX_NUM_ANGLES", None)
-        self.cache_frames = bool(dataset_cfg.get("CACHE_FRAMES", False))   # keep generated frames resident (bench: inputs in HBM)
+        # keep generated frames: True = resident on the device, "host" = points in pinned host memory, uploaded at every access
+        self.cache_frames = dataset_cfg.get("CACHE_FRAMES", False)
         self._cache = {}
         self.train_percent = 0.0          # the trainer moves it from 0 to 1 (reference train_utils: cur_it / total_it)
 
@@ -64,11 +65,18 @@ class SyntheticMixDataset(DatasetTemplate):
 
     # ---- one domain's frame: raw points (+ upload), boxes with the class-id column, encoded features
     def _frame(self, kind, index):
+        host = self.cache_frames == "host" and self.on_device
         if self.cache_frames and (kind, index) in self._cache:
-            return dict(self._cache[(kind, index)])
+            data = dict(self._cache[(kind, index)])
+            if host:
+                data["points"] = data["points"].cuda(non_blocking=True)      # on the caller's current stream
+            return data
         data = self._make_frame(kind, index)
         if self.cache_frames:
-            self._cache[(kind, index)] = dict(data)
+            kept = dict(data)
+            if host:
+                kept["points"] = data["points"].cpu().pin_memory()
+            self._cache[(kind, index)] = kept
         return data
 
     def _make_frame(self, kind, index):

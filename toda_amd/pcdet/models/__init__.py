@@ -15,8 +15,12 @@ def build_network(model_cfg, num_class, dataset):
 
 
 def load_data_to_gpu(batch_dict):
-    """Every ndarray -> fp32 CUDA tensor, integers included (reference :23-34)."""
+    """Every ndarray -> fp32 CUDA tensor, integers included (reference :23-34).  A host TENSOR (a collate function that pins its
+    output) is uploaded on the current stream without blocking the host."""
     for key, val in batch_dict.items():
+        if torch.is_tensor(val) and not val.is_cuda and key not in ("frame_id", "metadata", "calib"):
+            batch_dict[key] = val.cuda(non_blocking=True)
+            continue
         if not isinstance(val, np.ndarray):
             continue
         if key in ("frame_id", "metadata", "calib"):

@@ -143,24 +143,6 @@ class KernelTimer:
             return self._orig_classed(feat, wp, nbr, c_produce, *rest)
 
         ops.gather_gemm_classed = labelled_classed
-        self._orig_halo = ops.gather_gemm_halo              # SubM layers on the LDS-staged halo kernel (same dispatch-stamped launches)
-        self.halo_tables = set()
-
-        def labelled_halo(feat, wp, nbr, c_produce, *rest, **kw):
-            if self._enabled and len(self.records) < self.CAPACITY:
-                self.records.append(self._record_of(nbr, feat, c_produce))
-                self.halo_tables.add((nbr.shape[1], nbr.shape[0], feat.shape[1], c_produce))
-            return self._orig_halo(feat, wp, nbr, c_produce, *rest, **kw)
-
-        ops.gather_gemm_halo = labelled_halo
-        self._orig_subm = ops.gather_gemm_subm              # 64 -> 64 / 32 -> 32 SubM layers on the line kernel (same dispatch-stamped launches)
-
-        def labelled_subm(feat, wp, nbr, c_produce, *rest, **kw):
-            if self._enabled and len(self.records) < self.CAPACITY:
-                self.records.append(self._record_of(nbr, feat, c_produce))
-            return self._orig_subm(feat, wp, nbr, c_produce, *rest, **kw)
-
-        ops.gather_gemm_subm = labelled_subm
 
     @property
     def enabled(self):

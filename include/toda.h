@@ -48,11 +48,6 @@ extern "C" {
 const char* toda_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int toda_abi_version(void);
-/* 1 when the library was built with the opt-in kernel variants (make VARIANTS=1: halo tiles, dout-stationary wgrad, mask-sorted row
- * order and the experiment kernels behind the TODA_GG_* knobs), 0 for the default build, in which the entry points of those families
- * (toda_halo_*, toda_spconv_gather_gemm_halo, toda_spconv_wgrad_tiled*, toda_rulebook_row_order) report "not supported" /
- * TODA_EINVAL.  No reference counterpart. */
-int toda_variants_built(void);
 /* Reads and clears the fault word (host-mapped memory: no device synchronisation).  TODA_OK, or TODA_EFAULT with the
  * kernels named in toda_last_error().  toda_bn2d_* and toda_conv3x3_fwd poll it on entry as well, so a fault raised by
  * one launch is reported by the next call of that family at the latest; call it after a synchronisation point to learn
@@ -208,24 +203,8 @@ int toda_spconv_pack_weights(int n, const float* const* w_host, const int32_t* c
 int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp,
                             const int32_t* nbr, int n_out, int k_vol, int c_produce,
                             const float* bias /*nullable*/, float* out, void* stream);
-/* The same over the table of a SUBMANIFOLD 3 x 3 x 3 convolution (toda_rulebook_subm; spconv.SubMConv3d,
- * pcdet/models/backbones_3d/spconv_backbone.py:12,78-105) - forward, or the data gradient over the same table with the
- * reversed operand.  The caller vouches for the table's kind: nbr[12] / nbr[14] are then a row's x-neighbours, and where
- * such a neighbour is the adjacent row of the 16-row tile the kernel takes the outer offsets' operands of a stencil line from
- * the centre offset's gather by a lane shift instead of gathering them again (64 -> 64 and 32 -> 32; other shapes run the
- * kernels of toda_spconv_gather_gemm).  Bit-identical results.  sums / blocks_out: NULL, or as
- * toda_spconv_gather_gemm_stats / _stats_partials. */
-int toda_spconv_gather_gemm_subm(const float* in, int n_in, int c_gather, const float* wp,
-                                 const int32_t* nbr, int n_out, int k_vol, int c_produce,
-                                 const float* bias, float* out, double* sums, size_t sums_doubles,
-                                 int* blocks_out, void* stream);
-
 /* Same, visiting the output rows in the order `order[n_out]` (a permutation, nullable = canonical): results are
- * identical, only the assignment of rows to waves changes.  toda_rulebook_row_order builds the order that sorts
- * rows by their K-bit neighbour mask inside blocks of 2048 canonical rows, which lets whole (32-row tile, offset)
- * pairs drop out of the gather + MFMA loop. */
-int toda_rulebook_row_order(const int32_t* nbr, int n_out, int k_vol /*<= 31*/, int32_t* order /*[n_out]*/,
-                            void* stream);
+ * identical, only the assignment of rows to waves changes (the class-sorted data gradient below is built on it). */
 int toda_spconv_gather_gemm_ordered(const float* in, int n_in, int c_gather, const float* wp,
                                     const int32_t* nbr, int n_out, int k_vol, int c_produce,
                                     const float* bias, float* out, const int32_t* order, void* stream);
@@ -243,39 +222,6 @@ int toda_spconv_gather_gemm_classed(const float* in, int n_in, int c_gather, con
                                     int k_vol, int c_produce, const float* bias, float* out, const int32_t* order,
                                     const unsigned char* cls_sorted, const int32_t* ksize_host, const int32_t* stride_host,
                                     const int32_t* padding_host, void* stream);
-/* ------------------------------------------------------------------------
- * LDS-staged halo tiles for submanifold layers (north star: "gather -> MFMA-GEMM ->
- * scatter sparse conv with ... LDS-staged feature tiles").  Replaces, for the SubM
- * layers whose channel count has a halo geometry (64 -> 64, 32 -> 32), the per-offset
- * row gathers of toda_spconv_gather_gemm* in the forward and data-gradient passes of
- * spconv SubMConv3d (pcdet/models/backbones_3d/spconv_backbone.py:21-25,54-64,
- * 128-180; backward through autograd, tools/train_utils/train_utils.py:55).
- *
- *   toda_halo_supported            1 when (c_gather, c_produce, k_vol) has a halo kernel
- *   toda_halo_plan_bytes           size of the plan buffer for n rows
- *   toda_halo_plan_workspace_bytes scratch of the plan builder (Morton bitmap of the lattice)
- *   toda_halo_plan_build           from the level's coordinates and its SubM neighbour table
- *                                  nbr[k_vol][n]: output rows regrouped into blocks that are
- *                                  compact in space (Morton order over (y, x), z innermost), each
- *                                  block's unique neighbour rows and 16-bit local ids.  One plan
- *                                  serves every SubM layer (forward and dgrad) on that table.
- *                                  Deterministic; results of the convolution do not depend on it.
- *   toda_spconv_gather_gemm_halo   out[n][c] = conv(in; wp, table) with the block's unique input
- *                                  rows staged in LDS (32 channels of them at a time); equal to
- *                                  toda_spconv_gather_gemm to fp32 rounding (64 channels sum in two
- *                                  passes of 32), run-to-run deterministic.  sums (nullable,
- *                                  >= toda_spconv_gather_gemm_stats_doubles): BatchNorm moments of
- *                                  the output as toda_spconv_gather_gemm_stats.
- * ---------------------------------------------------------------------- */
-int toda_halo_supported(int c_gather, int c_produce, int k_vol);
-size_t toda_halo_plan_bytes(int n, int k_vol, int c_gather);
-size_t toda_halo_plan_workspace_bytes(int n, int batch, const int32_t* shape_host);
-int toda_halo_plan_build(const int32_t* indices, int n, int batch, const int32_t* shape_host, const int32_t* nbr,
-                         int k_vol, int c_gather, void* plan, size_t plan_bytes, void* ws, size_t ws_bytes, void* stream);
-int toda_spconv_gather_gemm_halo(const float* in, int n, int c_gather, const float* wp, const int32_t* nbr, int k_vol,
-                                 int c_produce, const float* bias, float* out, const void* plan, size_t plan_bytes,
-                                 double* sums, size_t sums_doubles, void* stream);
-
 /* The same contraction for the narrow K = 27 layers (<= 32 gathered, <= 32 produced channels: conv_input, the 16-channel SubM
  * level, the strided 16 -> 32 and their data gradients - reference pcdet/models/backbones_3d/spconv_backbone.py:92-115): per
  * offset a wave compacts the rows that have a neighbour, so only real pairs are gathered and multiplied.  w is the PLAIN weight
@@ -298,16 +244,6 @@ size_t toda_spconv_wgrad_workspace_bytes(int n_out, int k_vol, int cin, int cout
 int toda_spconv_wgrad(const float* in, int n_in, const float* dout, const int32_t* nbr,
                       int n_out, int k_vol, int cin, int cout, float* dw,
                       void* ws, size_t ws_bytes, void* stream);
-/* The same contraction with the output-gradient rows of a 128-row tile staged in LDS once for all 27 offsets (one third of
- * the HBM traffic of toda_spconv_wgrad on the 32 -> 32 level; measured slower in the step, so the host picks it only on request:
- * profiles/r03_wgrad_tiled.md).  K = 27, channels in {32, 64} with cin <= cout, 0 < rows < 2^23; same summation structure
- * (per-workgroup slabs + fixed-order fold): deterministic. */
-int toda_spconv_wgrad_tiled_supported(int n_in, int n_out, int k_vol, int cin, int cout);
-size_t toda_spconv_wgrad_tiled_workspace_bytes(int n_out, int cin, int cout);
-int toda_spconv_wgrad_tiled(const float* in, int n_in, const float* dout, const int32_t* nbr,
-                            int n_out, int k_vol, int cin, int cout, float* dw,
-                            void* ws, size_t ws_bytes, void* stream);
-
 /* SparseConvTensor.dense() as used by HeightCompression
  * (pcdet/models/backbones_2d/map_to_bev/height_compression.py:21-23):
  * dense[b, c, z, y, x] = feat[row, c]; the caller views it as [B, C*D, H, W].

@@ -98,18 +98,3 @@ class abi_calls:
         for n, orig in self._orig.items():
             setattr(self._lib, n, orig)
         return False
-
-
-def variants_built():
-    """True when the loaded libtoda_hip.so carries the opt-in kernel families (make -C toda_amd/csrc VARIANTS=1)."""
-    try:
-        from toda_amd import lib as L
-        return L.variants_built()
-    except Exception:
-        return False
-
-
-import pytest as _pytest
-
-# tests of the measured-and-rejected kernel families: they run against a VARIANTS=1 build only (the default library does not contain them)
-needs_variants = _pytest.mark.skipif(not variants_built(), reason="libtoda_hip.so built without the opt-in kernel variants (make VARIANTS=1)")

@@ -21,7 +21,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, s), f"{s} declared in include/toda.h but not exported"
         assert s in L.SIGNATURES, f"{s} has no ctypes prototype in toda_amd/lib.py"
     assert sorted(L.SIGNATURES) == syms
-    assert lib.toda_abi_version() == 2
+    assert lib.toda_abi_version() == 3
 
 
 def test_host_side_size_queries_need_no_gpu():
@@ -64,7 +64,6 @@ def test_more_argument_checks_and_size_queries():
     assert lib.toda_points_polar_cell(None, 10, None, 4, 0.0, ep, 33, ep, 2, 0.0, 1.0, None, None) == -1 and b"bins" in lib.toda_last_error()
     assert lib.toda_points_in_boxes(None, 10, None, 4, None, 3, 7, 5, None, None) == -1 and b"mode" in lib.toda_last_error()
     assert lib.toda_points_in_boxes(None, 10, None, 2, None, 3, 7, 0, None, None) == -1                              # needs x, y, z
-    assert lib.toda_rulebook_row_order(None, 10, 64, None, None) == -1 and (b"offsets" if lib.toda_variants_built() else b"VARIANTS=1") in lib.toda_last_error()
     assert lib.toda_timing_begin(0) == -1
     # zero-sized problems succeed without touching any pointer
     assert lib.toda_spconv_gather_gemm_ordered(None, 0, 64, None, None, 0, 27, 64, None, None, None, None) == 0
@@ -82,7 +81,7 @@ def test_host_tensors_are_refused():
 
 
 def test_round3_entry_points_validate_before_they_launch():
-    """The entry points added in round 3 (compacting gather-GEMM, dout-stationary wgrad, slice BatchNorm2d, optimizer step):
+    """The entry points added in round 3 (compacting gather-GEMM, slice BatchNorm2d, optimizer step):
     support queries, workspace sizes, argument errors - no GPU needed."""
     lib = L.load()
     assert lib.toda_spconv_gather_gemm_compact_supported(16, 16, 27) == 1 and lib.toda_spconv_gather_gemm_compact_supported(5, 16, 27) == 1
@@ -91,17 +90,6 @@ def test_round3_entry_points_validate_before_they_launch():
     assert lib.toda_spconv_gather_gemm_compact(None, 10, 64, None, 16, 64, 0, 0, None, 10, 27, 16, None, None, None) == -1 and b"K = 27" in lib.toda_last_error()
     assert lib.toda_spconv_gather_gemm_compact(None, 10, 16, None, 32, 16, 1, 0, None, 10, 27, 16, None, None, None) == -1 and b"does not map" in lib.toda_last_error()
     assert lib.toda_spconv_gather_gemm_compact(None, 10, 16, None, 16, 16, 0, 0, None, 0, 27, 16, None, None, None) == 0       # no output rows: nothing to do
-    if lib.toda_variants_built():
-        assert lib.toda_spconv_wgrad_tiled_supported(100000, 100000, 27, 32, 32) == 1 and lib.toda_spconv_wgrad_tiled_supported(100000, 100000, 27, 64, 32) == 0
-        assert lib.toda_spconv_wgrad_tiled_supported(1 << 23, 100000, 27, 32, 32) == 0                          # queue entries hold 23 bits of input row
-        need = lib.toda_spconv_wgrad_tiled_workspace_bytes(100000, 64, 64)
-        assert need >= 27 * 64 * 64 * 4 * 8 and lib.toda_spconv_wgrad_tiled_workspace_bytes(100000, 64, 32) == 0
-        assert lib.toda_spconv_wgrad_tiled(None, 10, None, None, 10, 3, 64, 64, None, None, 0, None) == -1 and b"K = 27" in lib.toda_last_error()
-        assert lib.toda_spconv_wgrad_tiled(None, 100000, None, None, 100000, 27, 64, 64, None, None, need - 1, None) != 0 and b"workspace" in lib.toda_last_error()
-    else:   # the default build: the opt-in families answer "not supported" / name the build switch
-        assert lib.toda_spconv_wgrad_tiled_supported(100000, 100000, 27, 32, 32) == 0 and lib.toda_halo_supported(64, 64, 27) == 0
-        assert lib.toda_spconv_wgrad_tiled(None, 10, None, None, 10, 27, 64, 64, None, None, 0, None) == -1 and b"VARIANTS=1" in lib.toda_last_error()
-        assert lib.toda_spconv_gather_gemm_halo(None, 10, 64, None, None, 27, 64, None, None, None, 0, None, 0, None) == -1 and b"VARIANTS=1" in lib.toda_last_error()
     one = L.host_f32([0.0])
     p = L.hptr(one)
     assert lib.toda_bn2d_fwd_into(p, 2, 64, 100, p, p, None, None, 0.01, 1e-3, 1, p, 96, 40, p, None, 0, None) == -1 and b"outside" in lib.toda_last_error()

@@ -314,45 +314,6 @@ def test_bn2d_cat_equals_batchnorm_relu_cat():
             assert int(bn.num_batches_tracked) == 1
 
 
-_REG_WGRAD_CHILD = r"""
-import sys, torch
-sys.path.insert(0, sys.argv[1])
-from toda_amd import ops
-torch.manual_seed(1)
-worst = 0.0
-# full and partial tiles in x and y, one / several images, rows of the first image at index 0 (the only negative halo offset), both
-# neck shapes at full size, a channel pair with more co blocks than ci blocks
-for (B, ci, co, H, W) in [(1, 32, 64, 8, 16), (2, 32, 64, 10, 18), (1, 64, 128, 6, 18), (3, 32, 64, 14, 22), (1, 32, 64, 2, 16), (1, 32, 64, 4, 36),
-                          (2, 64, 64, 94, 94), (2, 128, 128, 188, 188), (2, 256, 256, 94, 94)]:
-    x = torch.randn(B, ci, H, W, device="cuda"); gy = torch.randn(B, co, H, W, device="cuda")
-    dw = ops.conv3x3_wgrad(x, gy, (co, ci, 3, 3))
-    ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 3, 3), gy.double(), padding=1)
-    err = float((dw.double() - ref).abs().max() / ref.abs().max())
-    again = ops.conv3x3_wgrad(x, gy, (co, ci, 3, 3))
-    assert bool((dw == again).all()), "two launches differ"
-    worst = max(worst, err)
-print("WORST", worst)
-"""
-
-
-def test_register_form_wgrad_matches_fp64_and_repeats_bit_for_bit():
-    """The opt-in register form of the Winograd weight gradient (conv2d_variants.cuh, `make VARIANTS=1`, TODA_WINO_WGRAD=2; the switch is
-    read once per process, hence the child process): 1e-5 of the gradient's scale against float64, identical bits on a second launch."""
-    import os
-    import subprocess
-    import sys
-    from tests import helpers as H
-
-    if not H.variants_built():
-        pytest.skip("libtoda_hip.so built without the opt-in kernel variants (make VARIANTS=1)")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TODA_WINO_WGRAD="2")
-    p = subprocess.run([sys.executable, "-c", _REG_WGRAD_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
-    worst = float(p.stdout.strip().split("WORST")[-1])
-    assert worst < 1e-5, worst
-
-
 _GANG_CHILD = r"""
 import sys, torch
 import torch.nn.functional as F

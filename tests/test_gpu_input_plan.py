@@ -222,109 +222,3 @@ def test_prefetcher_hands_out_arena_backed_batches_and_the_detector_trains_on_th
         assert l0 == l1, (l0, l1)                      # same kernels on the same bits
         assert torch.equal(g0, g1)
 
-
-@H.needs_variants
-@pytest.mark.parametrize("c", [32, 64])
-@pytest.mark.parametrize("canonical", [True, False])
-def test_line_kernel_is_bit_identical_to_the_per_offset_kernel(c, canonical):
-    """gather_gemm_line_kernel (x-run operand reuse over submanifold tables, toda_spconv_gather_gemm_subm) against
-    gather_gemm_lds_kernel: forward with bias, the data-gradient operand, the statistics epilogue (folded and unfolded), on rows in
-    canonical order (long x-runs: most outer-offset operands come from the lane next door) and in shuffled order (none do), with a
-    row count that is no multiple of the 32-row wave tile; against the oracle as well."""
-    from toda_amd import ops
-
-    shape, batch = [9, 96, 120], 2
-    idx, _ = H.clustered_sparse(batch, shape, 9000, 1, seed=31)
-    if canonical:
-        key = ((idx[:, 0].astype(np.int64) * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
-        idx = idx[np.argsort(key)]
-        # dense x-runs: fill every second gap so that runs of 3+ sites exist
-        extra = idx.copy()
-        extra[:, 3] = np.minimum(extra[:, 3] + 1, shape[2] - 1)
-        both = np.unique(np.concatenate([idx, extra]), axis=0)
-        key = ((both[:, 0].astype(np.int64) * shape[0] + both[:, 1]) * shape[1] + both[:, 2]) * shape[2] + both[:, 3]
-        idx = both[np.argsort(key)].astype(np.int32)
-    n = len(idx)
-    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
-    nbr = rb.nbr_fwd
-    adj = float(((nbr[12].cpu().numpy()[1:] == np.arange(n - 1))).mean())
-    assert (adj > 0.4) if canonical else (adj < 0.05)
-    rng = np.random.default_rng(c)
-    x = dev(rng.standard_normal((n, c)).astype(np.float32))
-    w = dev((rng.standard_normal((c, 3, 3, 3, c)) * 0.1).astype(np.float32))
-    bias = dev(rng.standard_normal(c).astype(np.float32))
-    for transpose, flip in ((False, False), (True, True)):
-        wp = ops.pack_weight(w, transpose, flip)
-        ref = ops.gather_gemm(x, wp, nbr, c, bias)
-        got = ops.gather_gemm_subm(x, wp, nbr, c, bias)
-        assert torch.equal(ref, got), (transpose, float((ref - got).abs().max()))
-        assert torch.equal(got, ops.gather_gemm_subm(x, wp, nbr, c, bias))
-    wp = ops.pack_weight(w, False, False)
-    y0 = O.spconv_fwd(x.cpu().numpy(), w.cpu().numpy(), nbr.cpu().numpy(), bias.cpu().numpy())
-    np.testing.assert_allclose(ops.gather_gemm_subm(x, wp, nbr, c, bias).cpu().numpy(), y0, rtol=0, atol=1e-4 * np.abs(y0).max())
-    # statistics epilogue: folded and unfolded partial sums equal the per-offset kernel's
-    ref, s_ref = ops.gather_gemm_with_stats(x, wp, nbr, c)
-    got, s_got = ops.gather_gemm_subm(x, wp, nbr, c, stats="fold")
-    assert torch.equal(ref, got) and torch.equal(s_ref[:2 * c], s_got[:2 * c])
-    got2, part, blocks = ops.gather_gemm_subm(x, wp, nbr, c, stats="partials")
-    assert torch.equal(ref, got2) and blocks > 0
-    folded = part[2 * c:2 * c + 2 * c * blocks].view(2 * c, blocks).sum(1)
-    np.testing.assert_allclose(folded.cpu().numpy(), s_ref[:2 * c].cpu().numpy(), rtol=1e-12)
-
-
-@H.needs_variants
-def test_sparse_conv_routes_submanifold_layers_to_the_line_kernel(monkeypatch):
-    """The autograd operator: 64 -> 64 SubM layer forward (with statistics) and backward take toda_spconv_gather_gemm_subm, results
-    identical to the route with TODA_GG_LINE off."""
-    from toda_amd import ops
-
-    shape, batch = [9, 96, 120], 2
-    idx, _ = H.clustered_sparse(batch, shape, 6000, 1, seed=33)
-    key = ((idx[:, 0].astype(np.int64) * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
-    idx = idx[np.argsort(key)]
-    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
-    rng = np.random.default_rng(2)
-    xs = rng.standard_normal((len(idx), 64)).astype(np.float32)
-    ws = (rng.standard_normal((64, 3, 3, 3, 64)) * 0.1).astype(np.float32)
-    gs = rng.standard_normal((len(idx), 64)).astype(np.float32)
-    outs = []
-    for line in (True, False):
-        monkeypatch.setattr(ops, "LINE", line)
-        x, w = dev(xs).requires_grad_(True), dev(ws).requires_grad_(True)
-        with H.abi_calls("toda_spconv_gather_gemm_subm") as calls:
-            y, sums = ops.sparse_conv(x, w, None, rb, want_stats=True)
-            y.backward(dev(gs))
-        assert calls["toda_spconv_gather_gemm_subm"] == (2 if line else 0), dict(calls)
-        outs.append((y.detach(), x.grad, w.grad))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-
-
-@H.needs_variants
-def test_wide_kernel_with_half_slices_is_bit_identical(monkeypatch):
-    """128 -> 128 (VoxelResBackBone8x stride-8 level, reference spconv_backbone.py:191-240): gather_gemm_wide_kernel (two 32 KiB half
-    slices by LDS-DMA, double buffered) against gather_gemm_lds_kernel<8, 8, 1, .., 512> (one 64 KiB slice through registers): forward
-    with bias on a submanifold table and the data-gradient operand on a strided table, row counts that are no multiple of 128."""
-    import os
-    from toda_amd import ops
-
-    shape, batch = [5, 94, 90], 2
-    idx, _ = H.clustered_sparse(batch, shape, 7001, 1, seed=41)
-    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
-    _, _, rbc, _ = ops.build_conv_rulebook(dev(idx), batch, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
-    rng = np.random.default_rng(7)
-    w = dev((rng.standard_normal((128, 3, 3, 3, 128)) * 0.05).astype(np.float32))
-    bias = dev(rng.standard_normal(128).astype(np.float32))
-    cases = [(rb.nbr_fwd, ops.pack_weight(w, False, False), len(idx), bias),
-             (rb.nbr_bwd, ops.pack_weight(w, True, True), len(idx), None),
-             (rbc.nbr_fwd, ops.pack_weight(w, False, False), len(idx), None)]
-    for nbr, wp, n_src, b in cases:
-        x = dev(rng.standard_normal((n_src, 128)).astype(np.float32))
-        monkeypatch.setenv("TODA_GG_LDS88", "3")
-        ref = ops.gather_gemm(x, wp, nbr, 128, b)
-        monkeypatch.setenv("TODA_GG_LDS88", "5")
-        got = ops.gather_gemm(x, wp, nbr, 128, b)
-        assert torch.equal(ref, got), float((ref - got).abs().max())
-        assert torch.equal(got, ops.gather_gemm(x, wp, nbr, 128, b))
-    y0 = O.spconv_fwd(x.cpu().numpy(), w.cpu().numpy(), rbc.nbr_fwd.cpu().numpy())
-    np.testing.assert_allclose(got.cpu().numpy(), y0, rtol=0, atol=1e-4 * np.abs(y0).max())

@@ -344,44 +344,6 @@ def test_compacting_narrow_gather_gemm_matches_the_output_stationary_kernel(cg, 
     assert torch.equal(got, bias.expand_as(got))
 
 
-@H.needs_variants
-@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 64)])
-def test_dout_stationary_wgrad_matches_oracle(cin, cout):
-    """toda_spconv_wgrad_tiled (wgrad_tile_kernel; opt-in, TODA_WG_TILE=1; K = 27, 32 / 64 channels: the output-gradient tile staged in
-    LDS for all 27 offsets, three or four offsets per wave, queue tails carried across tiles, ring of in-flight gathers) against the oracle's per-offset gather -> GEMM and a float64
-    contraction on the device; a row count that is no multiple of the 128-row tile; bit-reproducible (slabs, no atomics)."""
-    from toda_amd import ops
-
-    shape, batch = [21, 260, 250], 2
-    idx, feat = H.clustered_sparse(batch, shape, 40000, cin, seed=cin + 7 * cout)
-    n = len(idx)
-    assert n >= 65536 and n % 128 != 0, n
-    rng = np.random.default_rng(4)
-    g = rng.standard_normal((n, cout)).astype(np.float32)
-    nbr0, _ = O.rulebook_subm(idx, batch, shape)
-    wshape = (cout, 3, 3, 3, cin)
-    dw0 = O.spconv_wgrad(feat, g, nbr0, wshape)
-    rb, _ = ops.build_subm_rulebook(dev(idx), batch, shape)
-    assert np.array_equal(rb.nbr_fwd.cpu().numpy(), nbr0)
-    with H.abi_calls("toda_spconv_wgrad_tiled", "toda_spconv_wgrad") as calls:
-        dw = ops.wgrad(dev(feat), dev(g), rb.nbr_fwd, wshape, tiled=True)
-    assert calls["toda_spconv_wgrad_tiled"] == 1 and calls["toda_spconv_wgrad"] == 0
-    plain = ops.wgrad(dev(feat), dev(g), rb.nbr_fwd, wshape, tiled=False)      # the per-(chunk, offset) kernel on the same inputs
-    assert float((dw - plain).abs().max()) <= 2e-6 * float(plain.abs().max())
-    scale = np.abs(dw0).max()
-    np.testing.assert_allclose(dw.cpu().numpy(), dw0, rtol=1e-4, atol=1e-4 * scale)
-    # float64 contraction on the device, offset by offset
-    x64, g64, nb = dev(feat).double(), dev(g).double(), rb.nbr_fwd.long()
-    ref = torch.zeros((cout, 27, cin), dtype=torch.float64, device="cuda")
-    for k in range(27):
-        m = nb[k] >= 0
-        ref[:, k, :] = g64[m].T @ x64[nb[k][m]]
-    err = float((dw.double().reshape(cout, 27, cin) - ref).abs().max() / ref.abs().max())
-    assert err < 2e-6, err
-    assert torch.equal(ops.wgrad(dev(feat), dev(g), rb.nbr_fwd, wshape, tiled=True), dw)
-    assert not ops.L.load().toda_spconv_wgrad_tiled_supported(n, n, 27, 64, 32) and not ops.L.load().toda_spconv_wgrad_tiled_supported(n, n, 3, 64, 64)
-
-
 def test_conv_linearity_and_determinism_at_scale():
     """Size-independent properties at a Waymo-like row count (no oracle run needed)."""
     from toda_amd import ops
@@ -793,41 +755,6 @@ def test_full_size_waymo_cloud_properties():
     back = dense[oi[:, 0].long(), :, oi[:, 1].long(), oi[:, 2].long(), oi[:, 3].long()]
     assert torch.equal(back, f2)
     assert rb2.n_out == oi.shape[0]
-
-
-@H.needs_variants
-def test_mask_sorted_row_order_is_a_blockwise_permutation_and_changes_no_bit():
-    """toda_rulebook_row_order: inside each block of 2048 canonical rows the rows are listed by ascending neighbour mask
-    (ties in canonical order); gather-GEMM visiting rows in that order returns bit-identical output."""
-    from toda_amd import ops
-    rng = np.random.default_rng(5)
-    n, k_vol = 2048 * 3 + 777, 27
-    coords = np.unique(np.stack([np.zeros(n * 2, np.int64), rng.integers(0, 12, n * 2), rng.integers(0, 60, n * 2), rng.integers(0, 60, n * 2)], 1), axis=0)[:n]
-    idx = torch.from_numpy(coords.astype(np.int32)).cuda()
-    rb, _ = ops.build_subm_rulebook(idx, 1, [12, 60, 60], 3)
-    order = ops.rulebook_row_order(rb.nbr_fwd).cpu().numpy()
-    nbr = rb.nbr_fwd.cpu().numpy()
-    mask = np.zeros(nbr.shape[1], np.int64)
-    for k in range(k_vol):
-        mask |= (nbr[k] >= 0).astype(np.int64) << k
-    n_rows = nbr.shape[1]
-    assert sorted(order.tolist()) == list(range(n_rows))
-    for s in range(0, n_rows, 2048):
-        blk = order[s:s + 2048]
-        assert blk.min() >= s and blk.max() < min(n_rows, s + 2048)
-        want = s + np.lexsort((np.arange(len(blk)), mask[s:s + 2048]))
-        np.testing.assert_array_equal(blk, want)
-    gen = torch.Generator(device="cuda").manual_seed(1)
-    for cin, cout in [(64, 64), (32, 32), (16, 16), (5, 16), (128, 128), (64, 128), (24, 48)]:
-        feat = torch.randn((n_rows, cin), device="cuda", generator=gen)
-        w = torch.randn((cout, 3, 3, 3, cin), device="cuda", generator=gen) * 0.1
-        wp = ops.pack_weight(w, False, False)
-        bias = torch.randn(cout, device="cuda", generator=gen)
-        a = ops.gather_gemm(feat, wp, rb.nbr_fwd, cout, bias)
-        b = ops.gather_gemm(feat, wp, rb.nbr_fwd, cout, bias, order=torch.from_numpy(order).cuda())
-        assert torch.equal(a, b), (cin, cout)
-        rev = torch.arange(n_rows - 1, -1, -1, dtype=torch.int32, device="cuda")          # any permutation works
-        assert torch.equal(a, ops.gather_gemm(feat, wp, rb.nbr_fwd, cout, bias, order=rev))
 
 
 def test_batched_weight_pack_equals_single_packs():

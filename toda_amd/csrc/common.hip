@@ -58,7 +58,7 @@ unsigned fault_take() {
 }  // namespace toda
 
 extern "C" const char* toda_last_error(void) { return toda::g_err; }
-extern "C" int toda_abi_version(void) { return 2; }
+extern "C" int toda_abi_version(void) { return 3; }
 
 extern "C" int toda_device_fault(void) {
     const unsigned v = toda::fault_take();

@@ -29,9 +29,9 @@
 
 #include "common.h"
 
-#ifndef TODA_VARIANTS
-#define TODA_VARIANTS 0
-#endif
+#ifndef TODA_ABLATE
+#define TODA_ABLATE 0      // -DTODA_ABLATE=1: measurement builds only (WRONG numbers) - the TODA_WINO_ABLATE / TODA_WINO_WG_ABLATE knobs switch parts of
+#endif                     // the Winograd kernels off; in the library that ships the ablation branches fold away and the knobs are not read
 
 namespace toda {
 
@@ -530,7 +530,8 @@ __device__ __forceinline__ void ws_epilogue(const f32x4 (&acc)[WN_FREQ], float* 
 __global__ void __launch_bounds__(WS_BLOCK, 2)
 wino_fwd_ws_kernel(const float* __restrict__ x, const float* __restrict__ u, const float* __restrict__ bias,
                    float* __restrict__ y, const WinoGeom g, const int n_units, float* __restrict__ slabs,
-                   int* __restrict__ flags, const int gang, const int ablate, unsigned* __restrict__ fault) {
+                   int* __restrict__ flags, const int gang, const int ablate_arg, unsigned* __restrict__ fault) {
+    const int ablate = TODA_ABLATE ? ablate_arg : 0;
     __shared__ float lds[4 * WN_FREQ * WN_IMG];   // A0 | A1 | B0 | B1
     constexpr int IMG = WN_FREQ * WN_IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -903,7 +904,8 @@ struct WgradGeom {
 };
 
 __global__ void __launch_bounds__(WS_BLOCK, 2)
-wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const WgradGeom wg, float* __restrict__ slabs, const int ablate) {
+wino_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, const WgradGeom wg, float* __restrict__ slabs, const int ablate_arg) {
+    const int ablate = TODA_ABLATE ? ablate_arg : 0;
     __shared__ float lds[4 * WN_FREQ * WN_IMG];   // V0 | V1 | dM0 | dM1
     constexpr int IMG = WN_FREQ * WN_IMG;
     const WinoGeom& g = wg.g;
@@ -1118,9 +1120,6 @@ wino_wgrad_finish_kernel(const float* __restrict__ red, const WgradGeom wg, floa
         }
 }
 
-#if TODA_VARIANTS
-#include "conv2d_variants.cuh"
-#endif
 
 static int wino_geom(const char* who, int batch, int cin, int cout, int H, int W, WinoGeom* g) {
     TODA_CHECK_ARG(batch >= 1 && H >= 1 && W >= 2 && W % 2 == 0, "%s: needs batch >= 1, H >= 1 and an even W (got %d x %d x %d)", who, batch, H, W);
@@ -1213,7 +1212,7 @@ extern "C" int toda_conv3x3_fwd(const float* x, const float* u, const float* bia
         const int grid = gang ? n_cu : (steps < n_cu ? (int)steps : n_cu);
         int* flags = (int*)ws;                                  // 4 words per workgroup: zero on entry, zero again on exit
         float* slabs = (float*)((char*)ws + WS_FLAG_BYTES);
-        static const int ablate = getenv("TODA_WINO_ABLATE") ? atoi(getenv("TODA_WINO_ABLATE")) : 0;
+        static const int ablate = (TODA_ABLATE && getenv("TODA_WINO_ABLATE")) ? atoi(getenv("TODA_WINO_ABLATE")) : 0;
         if (const unsigned fv = fault_take()) {
             // a bounded wait of an earlier launch gave up: its flags may still be up - put the workspace back into its all-zero
             // state behind that launch and report
@@ -1241,22 +1240,9 @@ static int wgrad_geom(const char* who, int batch, int cin, int cout, int H, int 
     return TODA_OK;
 }
 
-#if TODA_VARIANTS
-static bool wgrad_reg_form(int batch, int cin, int cout, int H, int W) {
-    static const int pick = getenv("TODA_WINO_WGRAD") ? atoi(getenv("TODA_WINO_WGRAD")) : 1;       // 1: the staged kernel, 2: the register form (opt-in)
-    const long long bytes = 4LL * batch * (cin > cout ? cin : cout) * H * W;
-    return pick == 2 && cin % W2_CI == 0 && cout % W2_CO == 0 && bytes < (1LL << 31) && W >= 16;    // W >= 16: at least four tiles per row
-}
-#endif
 
 extern "C" size_t toda_conv3x3_wgrad_workspace_bytes(int batch, int cin, int cout, int H, int W) {
     // one slab per stream-K segment (index w + unit) + the per-unit sums
-#if TODA_VARIANTS
-    if (wgrad_reg_form(batch, cin, cout, H, W)) {
-        const size_t units = (size_t)(cin / W2_CI) * (cout / W2_CO);
-        return (WS_MAX_GRID + 2 * units) * W2_SLAB_FLOATS * sizeof(float);
-    }
-#endif
     (void)batch, (void)H, (void)W;
     const size_t units = (size_t)(cin / 32) * (cout / 32);
     return (WS_MAX_GRID + 2 * units) * WG_SLAB_FLOATS * sizeof(float);
@@ -1282,31 +1268,9 @@ extern "C" int toda_conv3x3_wgrad(const float* x, const float* dy, int batch, in
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (n_cu > WS_MAX_GRID) n_cu = WS_MAX_GRID;
     }
-#if TODA_VARIANTS
-    if (wgrad_reg_form(batch, cin, cout, H, W)) {
-        Wg2Geom w2;
-        w2.g = wg.g;
-        w2.n_cib = cin / W2_CI, w2.n_cob = cout / W2_CO;
-        w2.n_units = w2.n_cib * w2.n_cob;
-        w2.steps_per_unit = cdiv(wg.g.n_tiles, 4);
-        const long long steps2 = (long long)w2.n_units * w2.steps_per_unit;
-        const int grid2 = steps2 < n_cu ? (int)steps2 : n_cu;
-        static const int ablate2 = getenv("TODA_WINO_WG_ABLATE") ? atoi(getenv("TODA_WINO_WG_ABLATE")) : 0;   // measurement only: wrong numbers
-        hipLaunchKernelGGL(wino_wgrad_reg_kernel, dim3(grid2), dim3(W2_BLOCK), 0, (hipStream_t)stream, x, dy, w2, (float*)ws, ablate2);
-        TODA_LAUNCH_CHECK();
-        float* red2 = (float*)ws + (size_t)(WS_MAX_GRID + w2.n_units) * W2_SLAB_FLOATS;
-        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<W2_SLAB_FLOATS>, dim3(cdiv((long long)w2.n_units * W2_SLAB_FLOATS, WN_BLOCK)), dim3(WN_BLOCK),
-                           0, (hipStream_t)stream, (const float*)ws, w2.n_units, w2.steps_per_unit, grid2, red2);
-        TODA_LAUNCH_CHECK();
-        hipLaunchKernelGGL(wino_wgrad_reg_finish_kernel, dim3(cdiv((long long)cin * cout, WN_BLOCK)), dim3(WN_BLOCK), 0, (hipStream_t)stream,
-                           (const float*)red2, w2, dw);
-        TODA_LAUNCH_CHECK();
-        return TODA_OK;
-    }
-#endif
     const long long steps = (long long)wg.n_units * wg.steps_per_unit;
     const int grid = steps < n_cu ? (int)steps : n_cu;
-    static const int ablate = getenv("TODA_WINO_WG_ABLATE") ? atoi(getenv("TODA_WINO_WG_ABLATE")) : 0;   // measurement only: wrong numbers
+    static const int ablate = (TODA_ABLATE && getenv("TODA_WINO_WG_ABLATE")) ? atoi(getenv("TODA_WINO_WG_ABLATE")) : 0;   // measurement builds only
     hipLaunchKernelGGL(wino_wgrad_kernel, dim3(grid), dim3(WS_BLOCK), 0, (hipStream_t)stream, x, dy, wg, (float*)ws, ablate);
     TODA_LAUNCH_CHECK();
     float* red = (float*)ws + (size_t)(WS_MAX_GRID + wg.n_units) * WG_SLAB_FLOATS;

@@ -28,9 +28,6 @@
 
 #include "common.h"
 
-#ifndef TODA_VARIANTS
-#define TODA_VARIANTS 0      // make VARIANTS=1: also the opt-in kernel families of spconv_variants.cuh
-#endif
 
 namespace toda {
 
@@ -1567,37 +1564,6 @@ extern "C" int toda_spconv_gather_gemm_stats_partials(const float* in, int n_in,
     return rc;
 }
 
-static thread_local bool g_subm_table = false;      // set by toda_spconv_gather_gemm_subm around its launch
-
-#if TODA_VARIANTS
-#include "spconv_variants.cuh"
-#else
-// ---- the entry points of the opt-in kernel families in a library built without them --------------------------------------------
-#define TODA_NO_VARIANT(name)                                                                                             \
-    do {                                                                                                                  \
-        toda::set_error(name ": this libtoda_hip.so was built without the opt-in kernel variants (make VARIANTS=1)");     \
-        return TODA_EINVAL;                                                                                               \
-    } while (0)
-extern "C" int toda_rulebook_row_order(const int32_t*, int, int, int32_t*, void*) { TODA_NO_VARIANT("toda_rulebook_row_order"); }
-extern "C" int toda_halo_supported(int, int, int) { return 0; }
-extern "C" size_t toda_halo_plan_bytes(int, int, int) { return 0; }
-extern "C" size_t toda_halo_plan_workspace_bytes(int, int, const int32_t*) { return 0; }
-extern "C" int toda_halo_plan_build(const int32_t*, int, int, const int32_t*, const int32_t*, int, int, void*, size_t, void*, size_t, void*) {
-    TODA_NO_VARIANT("toda_halo_plan_build");
-}
-extern "C" int toda_spconv_gather_gemm_halo(const float*, int, int, const float*, const int32_t*, int, int, const float*, float*, const void*,
-                                            size_t, double*, size_t, void*) {
-    TODA_NO_VARIANT("toda_spconv_gather_gemm_halo");
-}
-extern "C" int toda_spconv_wgrad_tiled_supported(int, int, int, int, int) { return 0; }
-extern "C" size_t toda_spconv_wgrad_tiled_workspace_bytes(int, int, int) { return 0; }
-extern "C" int toda_spconv_wgrad_tiled(const float*, int, const float*, const int32_t*, int, int, int, int, float*, void*, size_t, void*) {
-    TODA_NO_VARIANT("toda_spconv_wgrad_tiled");
-}
-#undef TODA_NO_VARIANT
-#endif
-
-extern "C" int toda_variants_built(void) { return TODA_VARIANTS ? 1 : 0; }
 
 static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out, int k_vol,
                             int c_produce, const float* bias, float* out, const int32_t* order, double* stats, void* stream,
@@ -1618,10 +1584,6 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
     const int Q = tiles_pow2(c_gather), NT = tiles_pow2(c_produce);
     hipStream_t s = (hipStream_t)stream;
     const bool vec_ok = (c_gather & 3) == 0;
-    {   // measurement only (wrong numbers): TODA_GG_ABLATE=1 gives the gathers an empty table (same instruction stream, no row traffic)
-        static const int ablate = getenv("TODA_GG_ABLATE") ? atoi(getenv("TODA_GG_ABLATE")) : 0;
-        if (ablate & 1) n_in = 0;
-    }
     // weight staging: the LDS-shared slice when it measured faster (Q >= 2 and NT >= Q); TODA_GG_LDS = 0 never, 2 always
     static const int env_lds_raw = getenv("TODA_GG_LDS") ? atoi(getenv("TODA_GG_LDS")) : 1;
     const int env_lds = env_lds_raw == 2 ? 1 : (env_lds_raw == 1 ? (Q >= 2 && NT >= Q) : 0);
@@ -1631,20 +1593,15 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
 #define SPL(KK, SS, NN, BB, WW)                                                                                                            \
     GG_LAUNCH(HIP_KERNEL_NAME(gg_split_kernel<KK, SS, NN, 2, BB, WW>), dim3(cdiv(cdiv(n_out, 32), BB / 64)), dim3(BB), 0, s, in, n_in, wps, \
               nbr, n_out, k_vol, c_produce, bias, out, order, stats, cls_sorted, classes)
-        // one 32-channel chunk per stage (spconv_split.cuh has the numbers); TODA_SPLIT_KCS=2 / TODA_SPLIT_BLK=768: the 64 -> 64 A/B variants
-        static const int env_blk = getenv("TODA_SPLIT_BLK") ? atoi(getenv("TODA_SPLIT_BLK")) : 0;
-        static const int env_kcs = getenv("TODA_SPLIT_KCS") ? atoi(getenv("TODA_SPLIT_KCS")) : 0;
-        const int blk = (env_blk == 768 && c_gather == 64 && c_produce == 64) ? 768 : 256;
+        // one 32-channel chunk per stage, 256-thread workgroups (spconv_split.cuh has the numbers)
+        const int blk = 256;
         const int kc = c_gather / 32, nt = c_produce / 16;
-        if (kc == 1 && nt == 2) SPL(1, 1, 2, 256, 4);
+        if (0) {}
+        else if (kc == 1 && nt == 2) SPL(1, 1, 2, 256, 4);
         else if (kc == 1 && nt == 4) SPL(1, 1, 4, 256, 4);
         else if (kc == 1 && nt == 8) SPL(1, 1, 8, 256, 3);
         else if (kc == 2 && nt == 2) SPL(2, 1, 2, 256, 4);
-        else if (kc == 2 && nt == 4) {
-            if (blk == 768) SPL(2, 2, 4, 768, 3);
-            else if (env_kcs == 2) SPL(2, 2, 4, 256, 3);
-            else SPL(2, 1, 4, 256, 4);
-        }
+        else if (kc == 2 && nt == 4) SPL(2, 1, 4, 256, 4);
         else if (kc == 2 && nt == 8) SPL(2, 1, 8, 256, 3);
         else if (kc == 4 && nt == 2) SPL(4, 1, 2, 256, 4);
         else if (kc == 4 && nt == 4) SPL(4, 1, 4, 256, 4);
@@ -1657,14 +1614,6 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
         }
         return TODA_OK;
     }
-#if TODA_VARIANTS
-    {   // opt-in kernels (environment knobs, the submanifold hint): spconv_variants.cuh
-        bool handled = false;
-        const int rc = toda::variant_gather_gemm(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, order, stats, s, cls_sorted, Q, NT,
-                                                 vec_ok, env_lds, g_subm_table, &handled);
-        if (handled) return rc;
-    }
-#endif
     // 128 -> 128: one 64 KiB slice shared by a 512-thread workgroup, 16 rows per wave (0.67 ms against 0.76 for two row tiles per
     // wave and 0.70 for register-only weights on 97.5k x 27 x 128 x 128)
     if (vec_ok && Q == 8 && NT == 8 && !cls_sorted) {
@@ -1742,27 +1691,6 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
 #undef GGV
     TODA_LAUNCH_CHECK();
     return TODA_OK;
-}
-
-// Gather-GEMM over the table of a SUBMANIFOLD convolution (toda_rulebook_subm, 3 x 3 x 3: nbr[12] / nbr[14] are a row's x-neighbours):
-// the 64 -> 64 and 32 -> 32 layers take gather_gemm_line_kernel, every other shape the kernels of toda_spconv_gather_gemm.  sums
-// (nullable): BatchNorm moments as toda_spconv_gather_gemm_stats; blocks_out (nullable, host): leave the partial sums unfolded as
-// toda_spconv_gather_gemm_stats_partials.  The data gradient of a submanifold layer runs over the same table (reversed weights).
-extern "C" int toda_spconv_gather_gemm_subm(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr, int n_out,
-                                            int k_vol, int c_produce, const float* bias, float* out, double* sums, size_t sums_doubles,
-                                            int* blocks_out, void* stream) {
-    if (sums) {
-        TODA_CHECK_ARG(gg_stats_supported(c_gather, c_produce) && n_out > 0 && n_in > 0,
-                       "gather_gemm_subm: statistics on an unsupported channel pair (%d -> %d) or an empty table", c_gather, c_produce);
-        TODA_CHECK_ARG(sums_doubles >= toda_spconv_gather_gemm_stats_doubles(n_out, c_produce), "gather_gemm_subm: statistics buffer too small");
-    }
-    if (blocks_out) *blocks_out = 0;
-    g_subm_table = true;
-    g_stats_blocks_out = sums ? blocks_out : nullptr;
-    const int rc = gather_gemm_impl(in, n_in, c_gather, wp, nbr, n_out, k_vol, c_produce, bias, out, nullptr, sums, stream);
-    g_stats_blocks_out = nullptr;
-    g_subm_table = false;
-    return rc;
 }
 
 extern "C" int toda_spconv_gather_gemm(const float* in, int n_in, int c_gather, const float* wp, const int32_t* nbr,

@@ -18,7 +18,6 @@ _vp, _i, _sz, _dbl = C.c_void_p, C.c_int, C.c_size_t, C.c_double
 SIGNATURES = {
     "toda_last_error": (C.c_char_p, []),
     "toda_abi_version": (_i, []),
-    "toda_variants_built": (_i, []),
     "toda_device_fault": (_i, []),
     "toda_voxelize_workspace_bytes": (_sz, [_i, _i]),
     "toda_voxelize_hard": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -41,8 +40,6 @@ SIGNATURES = {
     "toda_spconv_pack_weight": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "toda_spconv_pack_weights": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "toda_spconv_gather_gemm": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "toda_spconv_gather_gemm_subm": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "toda_rulebook_row_order": (_i, [_vp, _i, _i, _vp, _vp]),
     "toda_spconv_gather_gemm_ordered": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "toda_rulebook_class_order": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "toda_spconv_gather_gemm_classed": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -50,20 +47,12 @@ SIGNATURES = {
     "toda_spconv_gather_gemm_stats_doubles": (_sz, [_i, _i]),
     "toda_spconv_gather_gemm_stats": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "toda_spconv_gather_gemm_stats_partials": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "toda_halo_supported": (_i, [_i, _i, _i]),
-    "toda_halo_plan_bytes": (_sz, [_i, _i, _i]),
-    "toda_halo_plan_workspace_bytes": (_sz, [_i, _i, _vp]),
-    "toda_halo_plan_build": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _sz, _vp, _sz, _vp]),
-    "toda_spconv_gather_gemm_halo": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "toda_spconv_gather_gemm_compact_supported": (_i, [_i, _i, _i]),
     "toda_spconv_gather_gemm_compact": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_spconv_gather_gemm_compact_stats_doubles": (_sz, [_i, _i]),
     "toda_spconv_gather_gemm_compact_stats": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "toda_spconv_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "toda_spconv_wgrad": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "toda_spconv_wgrad_tiled_supported": (_i, [_i, _i, _i, _i, _i]),
-    "toda_spconv_wgrad_tiled_workspace_bytes": (_sz, [_i, _i, _i]),
-    "toda_spconv_wgrad_tiled": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "toda_sparse_to_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_sparse_to_dense_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "toda_pillar_scatter_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -157,11 +146,6 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
-
-
-def variants_built():
-    """True when libtoda_hip.so carries the opt-in kernel families (make -C toda_amd/csrc VARIANTS=1)."""
-    return bool(load().toda_variants_built())
 
 
 def last_error():

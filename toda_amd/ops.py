@@ -218,7 +218,7 @@ class GridIndex:
     @classmethod
     def from_coords(cls, indices, batch, shape):
         """Canonical ranks (popcount scan over the lattice): for coordinate lists whose index is also DECODED or ranked in
-        canonical order (lazy single-layer builds, the halo plan)."""
+        canonical order (lazy single-layer builds)."""
         gi = cls(batch, shape, indices.device)
         n = indices.shape[0]
         gi.rowof = torch.empty((max(n, 1),), dtype=torch.int32, device=indices.device)
@@ -287,20 +287,9 @@ class Rulebook:
         if nbr_bwd is not nbr_fwd:
             nbr_bwd._toda_pair_cnt = pair_cnt
         self.geom = geom
-        self._order = {}
         self.in_indices = None    # strided conv: coordinates of its input sites (rows of the data-gradient table)
+        self._inverse = None
         self._class_order = None
-        self.halo = {}            # SubM: channel count -> halo plan (build_halo_plan), shared by forward and dgrad
-
-    def order_for(self, nbr):
-        """Mask-sorted visiting order of `nbr`'s rows (built once per table, reused by every conv and dgrad on it).
-        A SubM table read with reversed offsets has the same row grouping, so dgrad shares the forward order."""
-        if not ROW_ORDER or nbr.shape[0] > 31 or nbr.shape[1] < ROW_ORDER_MIN_ROWS:
-            return None
-        key = nbr.data_ptr()
-        if key not in self._order:
-            self._order[key] = rulebook_row_order(nbr)
-        return self._order[key]
 
     def class_order(self):
         """(order, cls_sorted) of the data-gradient table of a strided convolution: its rows regrouped by the residue class of
@@ -322,6 +311,17 @@ class Rulebook:
 
     def num_pairs(self):
         return int(self.pair_cnt.sum().item())
+
+    def inverse(self):
+        """The same pairs read the other way round (spconv's SparseInverseConv3d, reference spconv_backbone.py:16-17,22-23): rows of the
+        strided convolution's OUTPUT set are gathered, rows of its INPUT set are produced, offset k keeps its weight slice.  The
+        i2o table is the forward table of that layer, o2i the table of its data gradient; no new index work."""
+        if self.kind != "conv":
+            raise ValueError("only the tables of a strided SparseConv3d have an inverse")
+        if self._inverse is None:
+            inv = Rulebook("inverse", self.ksize, self.n_out, self.n_in, self.nbr_bwd, self.nbr_fwd, False, self.pair_cnt, **self.geom)
+            self._inverse = inv
+        return self._inverse
 
 
 def conv_out_shape(shape, ksize, stride, padding):
@@ -363,7 +363,7 @@ def _conv_tables(indices, n_in, idx_out, n_out, batch, shape, out_shape, ks, st,
                                 L.ptr(idx_out) if gi_in is not None else None, L.ptr(gi_in.buf) if gi_in is not None else None,
                                 L.ptr(gi_in.rowof) if gi_in is not None else None, int(zeroed), L.stream())
     L.check(rc, "toda_rulebook_conv")
-    rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=st, padding=pd)
+    rb = Rulebook("conv", ks, n_in, n_out, o2i, i2o, False, cnt, stride=st, padding=pd, in_shape=[int(v) for v in shape])
     rb.in_indices = indices
     return rb
 
@@ -468,9 +468,6 @@ def _plan_tables(levels, level_counts, batch, steps, training):
             rb, gi = build_subm_rulebook(cur["idx"], batch, cur["shape"], st["ksize"], st.get("dilation", 1), grid_index=cur["gi"],
                                          pair_cnt=cnts[keys.index(st["key"])][:ks[0] * ks[1] * ks[2]])
             out[st["key"]] = {"kind": "subm", "rb": rb, "n_in": cur["n"]}
-            for ch in st.get("halo_channels", ()):      # layers on this table that take the LDS-staged halo kernel
-                if cur["n"] >= HALO_MIN_ROWS and halo_supported(ch, ch, rb.k_vol):
-                    build_halo_plan(rb, cur["idx"], batch, cur["shape"], ch)
         else:
             nxt = levels[li + 1]
             ks, sd, pd = _triple(st["ksize"]), _triple(st["stride"]), _triple(st["padding"])
@@ -600,14 +597,6 @@ def pack_weights_batched(items):
     return outs
 
 
-def rulebook_row_order(nbr):
-    lib = L.load()
-    K, n_out = nbr.shape
-    order = torch.empty((n_out,), dtype=torch.int32, device=nbr.device)
-    L.check(lib.toda_rulebook_row_order(L.ptr(nbr), n_out, K, L.ptr(order), L.stream()), "toda_rulebook_row_order")
-    return order
-
-
 def gather_gemm_stats_supported(c_gather, c_produce):
     return bool(L.load().toda_spconv_gather_gemm_stats_supported(int(c_gather), int(c_produce)))
 
@@ -644,57 +633,20 @@ def gather_gemm(feat, wp, nbr, c_produce, bias=None, order=None):
     return out
 
 
-# x-run operand reuse for the 64 -> 64 / 32 -> 32 submanifold layers (gather_gemm_line_kernel): OPT-IN.  Bit-identical to the
-# per-offset kernel and 35-45 % fewer gathered rows, but SLOWER on every C3 level (round 4, same box, same run: 64 -> 64 @ 389 k rows
-# 0.616 against 0.578 ms, @ 117 k 0.250 against 0.208, 32 -> 32 @ 682 k 0.345 against 0.310; step 115.3 against 118.7 samples/s):
-# two operand sets (167 VGPRs: 3 waves per SIMD instead of 4) and a lane shift + select per operand register cost more than the
-# L2 -> L1 traffic they save - these kernels are not bound by gather bytes.
-LINE = _os.environ.get("TODA_GG_LINE", "0") == "1"
+def _refuse_retired_knobs():
+    """Environment knobs of kernel families that were measured, lost and are no longer in the library (profiles/EXPERIMENTS.md), and of
+    the measurement-only ablation builds: asking for one of them is an error, not a silent no-op."""
+    retired = [k for k in ("TODA_GG_LINE", "TODA_HALO", "TODA_WG_TILE", "TODA_ROW_ORDER", "TODA_GG_WS", "TODA_GG_STAGE", "TODA_GG_WRES", "TODA_GG_LDS_PF",
+                           "TODA_GG_BLK512", "TODA_GG_RT", "TODA_SPLIT_BLK", "TODA_SPLIT_KCS", "TODA_WINO_WGRAD") if _os.environ.get(k, "0") not in ("0", "")]
+    if retired:
+        raise RuntimeError(f"{', '.join(retired)}: these kernel variants were retired (profiles/EXPERIMENTS.md); unset the variable(s)")
+    ablate = [k for k in ("TODA_GG_ABLATE", "TODA_WINO_ABLATE", "TODA_WINO_WG_ABLATE") if _os.environ.get(k, "0") not in ("0", "")]
+    if ablate and not _os.environ.get("TODA_HIP_LIB"):
+        raise RuntimeError(f"{', '.join(ablate)} only act in a measurement build (-DTODA_ABLATE=1, loaded through TODA_HIP_LIB): the library "
+                           "that ships ignores them, and a run that believes it ablated something would report wrong conclusions")
 
 
-def _require_variants():
-    """The opt-in kernel families live in a library built with `make -C toda_amd/csrc VARIANTS=1`; asking for one of them through an
-    environment knob on the default library is an error, not a silent no-op."""
-    knobs = [k for k in ("TODA_GG_LINE", "TODA_HALO", "TODA_WG_TILE", "TODA_ROW_ORDER", "TODA_GG_WS", "TODA_GG_STAGE", "TODA_GG_WRES", "TODA_GG_LDS_PF",
-                         "TODA_GG_BLK512", "TODA_GG_RT") if _os.environ.get(k, "0") not in ("0", "")]
-    if _os.environ.get("TODA_GG_LDS88", "3") not in ("3", ""):
-        knobs.append("TODA_GG_LDS88")
-    if knobs and not L.variants_built():
-        raise RuntimeError(f"{', '.join(knobs)} select opt-in kernels that this libtoda_hip.so does not contain: "
-                           "rebuild with `make -C toda_amd/csrc VARIANTS=1`")
-
-
-_require_variants()
-
-
-def _line_route(c_gather, c_produce, rb, nbr):
-    return (LINE and rb.kind == "subm" and rb.k_vol == 27 and c_gather == c_produce and c_gather in (32, 64) and nbr.shape[1] >= 64
-            and all(int(d) == 1 for d in rb.geom.get("dilation", (1, 1, 1))))
-
-
-def gather_gemm_subm(feat, wp, nbr, c_produce, bias=None, stats=None):
-    """Gather-GEMM over a SUBMANIFOLD table (toda_spconv_gather_gemm_subm): forward, or the data gradient with the reversed operand.
-    stats: None | "fold" (returns (out, sums)) | "partials" (returns (out, sums, blocks) for toda_bn_finalize_partials)."""
-    lib = L.load()
-    K, n_out = nbr.shape
-    out = torch.empty((n_out, c_produce), dtype=torch.float32, device=feat.device)
-    if stats is None:
-        rc = lib.toda_spconv_gather_gemm_subm(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce, L.ptr(bias),
-                                              L.ptr(out), None, 0, None, L.stream())
-        L.check(rc, "toda_spconv_gather_gemm_subm")
-        return out
-    import ctypes
-    nd = lib.toda_spconv_gather_gemm_stats_doubles(n_out, c_produce)
-    sums = torch.empty((nd,), dtype=torch.float64, device=feat.device)
-    blocks = ctypes.c_int(0)
-    rc = lib.toda_spconv_gather_gemm_subm(L.ptr(feat), feat.shape[0], feat.shape[1], L.ptr(wp), L.ptr(nbr), n_out, K, c_produce, L.ptr(bias),
-                                          L.ptr(out), L.ptr(sums), nd, ctypes.addressof(blocks) if stats == "partials" else None, L.stream())
-    L.check(rc, "toda_spconv_gather_gemm_subm")
-    if stats == "partials":
-        if blocks.value <= 0:
-            raise RuntimeError("toda_spconv_gather_gemm_subm: the launch took no statistics")
-        return out, sums, int(blocks.value)
-    return out, sums
+_refuse_retired_knobs()
 
 
 # narrow K = 27 layers (conv_input, the 16-channel SubM level, the strided 16 -> 32 and its data gradient) by per-offset compaction:
@@ -702,8 +654,8 @@ def gather_gemm_subm(feat, wp, nbr, c_produce, bias=None, stats=None):
 COMPACT = _os.environ.get("TODA_GG_COMPACT", "1") == "1"
 
 
-def _compact_route(c_gather, c_produce, nbr, order):
-    return (COMPACT and order is None and nbr.shape[0] == 27 and nbr.shape[1] > 0 and c_produce in (16, 32) and c_gather <= 32
+def _compact_route(c_gather, c_produce, nbr):
+    return (COMPACT and nbr.shape[0] == 27 and nbr.shape[1] > 0 and c_produce in (16, 32) and c_gather <= 32
             and (c_gather <= 16 or c_produce == 16))
 
 
@@ -745,77 +697,11 @@ def gather_gemm_classed(feat, wp, nbr, c_produce, order, cls_sorted, ksize, stri
     return out
 
 
-# LDS-staged halo tiles for the SubM layers: OPT-IN.  Measured on the C3 levels (profiles/r03_halo_prototype.md): HBM traffic of the
-# dominant 64 -> 64 launch 2.10x -> 0.98x the algorithmic bytes and 0.59 ms against 0.60 in isolation, but inside the training step the
-# per-offset kernel is the faster one (0.58 against 0.62 ms; 18.1 against 18.4-18.5 ms per step with the plan builder on the side stream).
-HALO = _os_early.environ.get("TODA_HALO", "0") == "1"
-HALO_MIN_ROWS = int(_os_early.environ.get("TODA_HALO_MIN_ROWS", "32768"))
-
-
-HALO_CHANNELS = {int(v) for v in _os_early.environ.get("TODA_HALO_CHANNELS", "32,64").split(",") if v}
-
-
-def halo_supported(c_gather, c_produce, k_vol):
-    return HALO and int(c_gather) in HALO_CHANNELS and bool(L.load().toda_halo_supported(int(c_gather), int(c_produce), int(k_vol)))
-
-
-def build_halo_plan(rb, indices, batch, shape, channels):
-    """Halo plan of a SubM rulebook for layers with `channels` in and out (toda_halo_plan_build): Morton-ordered row blocks,
-    each block's unique neighbour rows and 16-bit local ids.  Cached on the rulebook; one plan serves every SubM layer on the
-    table, forward and data gradient."""
-    if channels in rb.halo:
-        return rb.halo[channels]
-    lib = L.load()
-    n, K = rb.nbr_fwd.shape[1], rb.nbr_fwd.shape[0]
-    dev = rb.nbr_fwd.device
-    nbytes = lib.toda_halo_plan_bytes(n, K, int(channels))
-    sh = L.host_i32([int(v) for v in shape])
-    ws_bytes = lib.toda_halo_plan_workspace_bytes(n, int(batch), L.hptr(sh))
-    plan = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
-    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=dev)
-    rc = lib.toda_halo_plan_build(L.ptr(indices.contiguous()), n, int(batch), L.hptr(sh), L.ptr(rb.nbr_fwd), K, int(channels), L.ptr(plan), nbytes,
-                                  L.ptr(ws), ws_bytes, L.stream())
-    L.check(rc, "toda_halo_plan_build")
-    rb.halo[channels] = plan
-    return plan
-
-
-def gather_gemm_halo(feat, wp, nbr, c_produce, plan, bias=None, want_stats=False):
-    """SubM gather-GEMM with the block's unique input rows staged once in LDS (toda_spconv_gather_gemm_halo); bit-identical to
-    gather_gemm.  want_stats: also the BatchNorm moments of the output, as gather_gemm_with_stats."""
-    lib = L.load()
-    K, n = nbr.shape
-    out = torch.empty((n, c_produce), dtype=torch.float32, device=feat.device)
-    sums, nd = None, 0
-    if want_stats:
-        nd = lib.toda_spconv_gather_gemm_stats_doubles(n, c_produce)
-        sums = torch.empty((nd,), dtype=torch.float64, device=feat.device)
-    rc = lib.toda_spconv_gather_gemm_halo(L.ptr(feat), n, feat.shape[1], L.ptr(wp), L.ptr(nbr), K, c_produce, L.ptr(bias), L.ptr(out),
-                                          L.ptr(plan), plan.numel(), L.ptr(sums), nd, L.stream())
-    L.check(rc, "toda_spconv_gather_gemm_halo")
-    return (out, sums) if want_stats else out
-
-
-# dout-stationary wgrad (toda_spconv_wgrad_tiled): opt-in.  Measured on C3 (profiles/r03_wgrad_tiled.md): 32 -> 32 @ 682 k rows
-# 0.298 ms against 0.277, 64 -> 64 @ 389 k rows 0.68 against 0.54; the step 17.63 (32-channel level only) / 18.29 ms against 17.59.
-WGRAD_TILED = _os.environ.get("TODA_WG_TILE", "0") == "1"
-WGRAD_TILED_MIN_ROWS = int(_os.environ.get("TODA_WG_TILE_MIN_ROWS", "65536"))
-
-
-def wgrad(feat, dout, nbr, wshape, tiled=None):
+def wgrad(feat, dout, nbr, wshape):
     lib = L.load()
     K, n_out = nbr.shape
     cout, cin = wshape[0], wshape[-1]
     dw = torch.empty(wshape, dtype=torch.float32, device=feat.device)
-    if tiled is None:
-        tiled = WGRAD_TILED and n_out >= WGRAD_TILED_MIN_ROWS and bool(lib.toda_spconv_wgrad_tiled_supported(feat.shape[0], n_out, K, cin, cout))
-    if tiled:
-        ws_bytes = lib.toda_spconv_wgrad_tiled_workspace_bytes(n_out, cin, cout)
-        ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=feat.device)
-        rc = lib.toda_spconv_wgrad_tiled(L.ptr(feat), feat.shape[0], L.ptr(dout), L.ptr(nbr), n_out, K, cin, cout, L.ptr(dw),
-                                         L.ptr(ws), ws_bytes, L.stream())
-        L.check(rc, "toda_spconv_wgrad_tiled")
-        return dw
     ws_bytes = lib.toda_spconv_wgrad_workspace_bytes(n_out, K, cin, cout)
     ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=feat.device)
     rc = lib.toda_spconv_wgrad(L.ptr(feat), feat.shape[0], L.ptr(dout), L.ptr(nbr), n_out, K, cin, cout, L.ptr(dw),
@@ -824,14 +710,9 @@ def wgrad(feat, dout, nbr, wshape, tiled=None):
     return dw
 
 
-# mask-sorted row order for gather-GEMM: opt-in.  Measured on C3 it LOSES on the SubM layers (64->64 @ 389k rows 0.536 ->
-# 0.562 ms, 32->32 @ 682k 0.321 -> 0.366 ms: rows of a tile are no longer x-neighbours, so their gathers stop sharing
-# input rows in L1/L2) and wins only on strided-conv dgrads (64->32 @ 682k 0.345 -> 0.274 ms); the sort costs 0.13 ms/table.
 # data gradient of strided convolutions over residue-class-sorted rows (1..8 candidate offsets per row instead of 27)
 CLASS_DGRAD = _os.environ.get("TODA_CLASS_DGRAD", "1") == "1"
 CLASS_DGRAD_MIN_ROWS = int(_os.environ.get("TODA_CLASS_DGRAD_MIN_ROWS", "4096"))
-ROW_ORDER = _os.environ.get("TODA_ROW_ORDER", "0") == "1"
-ROW_ORDER_MIN_ROWS = int(_os.environ.get("TODA_ROW_ORDER_MIN_ROWS", "4096"))
 WGRAD_ON_SIDE_STREAM = _os.environ.get("TODA_WGRAD_STREAM", "0") == "1"  # measured: no gain (each kernel already fills the chip)
 _SIDE_STREAMS = {}
 
@@ -851,27 +732,14 @@ class _SparseConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, weight, bias, rb, wp_fwd, want_stats=False, wp_bwd=None):
         features = features.contiguous()
-        compact = _compact_route(features.shape[1], weight.shape[0], rb.nbr_fwd, rb.order_for(rb.nbr_fwd))
+        compact = _compact_route(features.shape[1], weight.shape[0], rb.nbr_fwd)
         if wp_fwd is None and not compact:
             wp_fwd = pack_weight(weight, False, False)
         if wp_fwd is not None:
             _check_mm(wp_fwd)
         sums, blocks = None, 0
-        plan = rb.halo.get(weight.shape[-1]) if (rb.kind == "subm" and weight.shape[0] == weight.shape[-1] and features.shape[0] == rb.n_out) else None
-        line = plan is None and not compact and features.shape[0] == rb.n_out and _line_route(features.shape[1], weight.shape[0], rb, rb.nbr_fwd)
-        if line and want_stats:
-            if FOLD_IN_FINALIZE:
-                out, sums, blocks = gather_gemm_subm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, stats="partials")
-            else:
-                out, sums = gather_gemm_subm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, stats="fold")
-        elif line:
-            out = gather_gemm_subm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
-        elif compact and want_stats:
+        if compact and want_stats:
             out, sums, blocks = gather_gemm_compact(features, weight.contiguous(), rb.nbr_fwd, weight.shape[0], bias, stats=True)
-        elif plan is not None and want_stats:
-            out, sums = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias, True)
-        elif plan is not None:
-            out = gather_gemm_halo(features, wp_fwd, rb.nbr_fwd, weight.shape[0], plan, bias)
         elif want_stats and FOLD_IN_FINALIZE:
             out, sums, blocks = gather_gemm_with_stats(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, partials=True)
         elif want_stats:
@@ -879,8 +747,7 @@ class _SparseConv(torch.autograd.Function):
         elif compact:
             out = gather_gemm_compact(features, weight.contiguous(), rb.nbr_fwd, weight.shape[0], bias)
         else:
-            out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias, order=rb.order_for(rb.nbr_fwd))
-        ctx.halo_plan = plan
+            out = gather_gemm(features, wp_fwd, rb.nbr_fwd, weight.shape[0], bias)
         ctx.set_materialize_grads(False)     # the moments output takes no gradient: no zero-filled double tensor per layer and step
         ctx.save_for_backward(features, weight)
         ctx.rb = rb
@@ -911,20 +778,16 @@ class _SparseConv(torch.autograd.Function):
             for t in (features, gout, rb.nbr_fwd):
                 t.record_stream(side)
             need_w = False
-        if need_d and ctx.halo_plan is None and _compact_route(gout.shape[1], weight.shape[-1], rb.nbr_bwd, rb.order_for(rb.nbr_bwd)):
+        if need_d and _compact_route(gout.shape[1], weight.shape[-1], rb.nbr_bwd):
             gfeat = gather_gemm_compact(gout, weight.contiguous(), rb.nbr_bwd, weight.shape[-1], None, True, rb.flip_bwd)
         elif need_d:
             wp_t = ctx.wp_bwd if ctx.wp_bwd is not None else pack_weight(weight, True, rb.flip_bwd)
             _check_mm(wp_t)
             co = rb.class_order()
-            if ctx.halo_plan is not None:      # SubM: the forward table with the offsets reversed in wp_t - the same plan
-                gfeat = gather_gemm_halo(gout, wp_t, rb.nbr_bwd, weight.shape[-1], ctx.halo_plan)
-            elif gout.shape[0] == rb.n_out and _line_route(gout.shape[1], weight.shape[-1], rb, rb.nbr_bwd):
-                gfeat = gather_gemm_subm(gout, wp_t, rb.nbr_bwd, weight.shape[-1])
-            elif co is not None:
+            if co is not None:
                 gfeat = gather_gemm_classed(gout, wp_t, rb.nbr_bwd, weight.shape[-1], co[0], co[1], rb.ksize, rb.geom["stride"], rb.geom["padding"])
             else:
-                gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None, order=rb.order_for(rb.nbr_bwd))
+                gfeat = gather_gemm(gout, wp_t, rb.nbr_bwd, weight.shape[-1], None)
         if need_w:
             gw = wgrad(features, gout, rb.nbr_fwd, tuple(weight.shape))
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -946,9 +809,9 @@ def sparse_conv(features, weight, bias, rulebook, packed_weight=None, want_stats
     (returns (out, sums) with sums None when it cannot: empty tables, narrow channel pairs, mask-sorted row order)."""
     if not want_stats:
         return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, False, packed_dgrad)
-    narrow = FOLD_IN_FINALIZE and _compact_route(features.shape[1], weight.shape[0], rulebook.nbr_fwd, rulebook.order_for(rulebook.nbr_fwd))
+    narrow = FOLD_IN_FINALIZE and _compact_route(features.shape[1], weight.shape[0], rulebook.nbr_fwd)
     ok = (FUSE_BN_STATS and (narrow or gather_gemm_stats_supported(weight.shape[-1], weight.shape[0])) and rulebook.nbr_fwd.shape[1] > 1
-          and features.shape[0] > 0 and rulebook.order_for(rulebook.nbr_fwd) is None)
+          and features.shape[0] > 0)
     if not ok:
         return _SparseConv.apply(features, weight, bias, rulebook, packed_weight, False, packed_dgrad), None
     out, sums, blocks = _SparseConv.apply(features, weight, bias, rulebook, packed_weight, True, packed_dgrad)

@@ -24,8 +24,6 @@ class SparseConvolution(SparseModule):
             raise NotImplementedError("only 3-D sparse convolution is on this path")
         if groups != 1 or transposed:
             raise NotImplementedError("groups != 1 / transposed sparse conv are not on this path")
-        if inverse:
-            raise NotImplementedError("SparseInverseConv3d (UNetV2 only) is out of scope, see DESIGN.md")
         self.ndim = ndim
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size = _triple(kernel_size)
@@ -96,6 +94,19 @@ class SparseConvolution(SparseModule):
                                               "out_indices": out_idx, "out_shape": out_shape, "gi": gi}
         return rb, out_idx, out_shape, gi
 
+    def _inverse_rulebook(self, x):
+        """SparseInverseConv3d: the pairs of the strided convolution that wrote `indice_key`, read from its output set back to its input
+        set (Rulebook.inverse); the output tensor sits on that convolution's input sites."""
+        cached = x.find_indice_pair(self.indice_key)
+        if cached is None or cached["kind"] != "conv":
+            raise ValueError(f"SparseInverseConv3d: no strided convolution has written indice_key {self.indice_key!r}")
+        rb = cached["rb"]
+        if x.indices.shape[0] != rb.n_out:
+            raise ValueError(f"SparseInverseConv3d: the input has {x.indices.shape[0]} sites, the convolution of {self.indice_key!r} produced {rb.n_out}")
+        if rb.ksize != self.kernel_size:
+            raise ValueError(f"SparseInverseConv3d: kernel size {self.kernel_size} differs from the convolution's {rb.ksize}")
+        return rb.inverse(), rb.in_indices, rb.geom["in_shape"], None
+
     def forward(self, x, want_bn_stats=False):
         """want_bn_stats (used by SparseSequential / SparseBasicBlock when a training-mode BatchNorm1d follows): the output
         tensor carries `.bn_sums`, the moments of its features taken in the convolution's epilogue (None when unavailable)."""
@@ -103,7 +114,10 @@ class SparseConvolution(SparseModule):
             raise TypeError("sparse convolution expects a SparseConvTensor")
         if x.features.shape[1] != self.in_channels:
             raise ValueError(f"expected {self.in_channels} input channels, got {x.features.shape[1]}")
-        rb, out_idx, out_shape, gi = self._rulebook(x)
+        if self.inverse:
+            rb, out_idx, out_shape, gi = self._inverse_rulebook(x)
+        else:
+            rb, out_idx, out_shape, gi = self._rulebook(x)
         packed = self._packed_forward_weight()
         sums = None
         if want_bn_stats:

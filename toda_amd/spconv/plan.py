@@ -16,13 +16,7 @@ def conv_steps(module):
         if m.indice_key is None:
             return None
         if m.subm:
-            # halo_channels: channel counts of the SubM layers on this table that keep their width (candidates for the LDS-staged
-            # halo kernel); the plan step of the key's first layer collects them from every layer sharing the key
-            square = [m.in_channels] if (m.in_channels == m.out_channels and all(d == 1 for d in m.dilation)) else []
-            first = next((s for s in steps if s["kind"] == "subm" and s["key"] == m.indice_key), None)
-            if first is not None:
-                first["halo_channels"] = sorted(set(first["halo_channels"]) | set(square))
-            steps.append({"kind": "subm", "key": m.indice_key, "ksize": m.kernel_size, "dilation": m.dilation, "halo_channels": square})
+            steps.append({"kind": "subm", "key": m.indice_key, "ksize": m.kernel_size, "dilation": m.dilation})
         else:
             if any(d != 1 for d in m.dilation):
                 return None

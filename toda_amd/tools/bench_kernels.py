@@ -53,8 +53,6 @@ class Recorder:
     def label(name, a):
         if name in ("toda_spconv_gather_gemm", "toda_spconv_gather_gemm_ordered"):
             return (a[5], a[6], a[2], a[7])          # rows, K, c_gather, c_produce
-        if name == "toda_rulebook_row_order":
-            return (a[1], a[2])
         if name == "toda_spconv_wgrad":
             return (a[4], a[5], a[6], a[7])          # rows, K, cin, cout
         if name in ("toda_rulebook_subm", "toda_rulebook_conv", "toda_gridindex_from_coords", "toda_gridindex_from_conv"):
@@ -87,7 +85,7 @@ def main():
     device = torch.device("cuda", 0)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), dataset).to(device).train()
     batch0 = bench.make_device_batches(dataset, per_gpu, 1, 0, device)[0]
-    rec = Recorder(["toda_spconv_gather_gemm_ordered", "toda_rulebook_row_order", "toda_spconv_wgrad", "toda_rulebook_subm", "toda_rulebook_conv",
+    rec = Recorder(["toda_spconv_gather_gemm_ordered", "toda_spconv_wgrad", "toda_rulebook_subm", "toda_rulebook_conv",
                     "toda_gridindex_from_coords", "toda_gridindex_from_conv", "toda_voxelize_hard", "toda_mean_vfe_fwd",
                     "toda_sparse_to_dense_fwd", "toda_sparse_to_dense_bwd", "toda_center_assign",
                     "toda_spconv_pack_weight"])

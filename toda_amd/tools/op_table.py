@@ -37,7 +37,6 @@ class OpTable:
         self._wrap_py("gather_gemm", self._cost_gather_gemm)
         self._wrap_py("gather_gemm_with_stats", self._cost_gather_gemm)
         self._wrap_py("gather_gemm_classed", self._cost_gather_gemm_classed)
-        self._wrap_py("gather_gemm_subm", self._cost_gather_gemm_subm)
         self._wrap_py("gather_gemm_compact", self._cost_gather_gemm_compact)
         self._wrap_py("wgrad", self._cost_wgrad)
         self._wrap_py("conv3x3_run", self._cost_conv3x3)
@@ -95,16 +94,13 @@ class OpTable:
         return (n_out, K, cg, c_produce), ("pairs", pk, lambda p: (4.0 * (n_src * cg + n_out * c_produce + K * cg * c_produce) + 8.0 * p,
                                                                    2.0 * p * cg * c_produce))
 
-    def _cost_gather_gemm_subm(self, feat, wp, nbr, c_produce, bias=None, stats=None):
-        return self._cost_gather_gemm(feat, wp, nbr, c_produce)
-
     def _cost_gather_gemm_classed(self, feat, wp, nbr, c_produce, order, cls_sorted, ksize, stride, padding):
         return self._cost_gather_gemm(feat, wp, nbr, c_produce)
 
     def _cost_gather_gemm_compact(self, feat, weight, nbr, c_produce, bias=None, transpose=False, flip_k=False, stats=False):
         return self._cost_gather_gemm(feat, None, nbr, c_produce)
 
-    def _cost_wgrad(self, feat, dout, nbr, wshape, tiled=None):
+    def _cost_wgrad(self, feat, dout, nbr, wshape):
         K, n_out = nbr.shape
         cout, cin = wshape[0], wshape[-1]
         pk = self._count_pairs(nbr)

@@ -222,3 +222,43 @@ def test_prefetcher_hands_out_arena_backed_batches_and_the_detector_trains_on_th
         assert l0 == l1, (l0, l1)                      # same kernels on the same bits
         assert torch.equal(g0, g1)
 
+
+
+def test_a_batch_kept_across_next_needs_keep_and_the_pipeline_survives_a_failed_preparation():
+    """(a) tensors of batch t live in an arena slot that next() hands back - InputPrefetcher.keep() copies them out, and the copy
+    still holds batch t's tables after two more batches went through the slots; (b) a preparation that raises gives its slot back and the
+    original error reaches the caller instead of a ZeroDivisionError from the next acquire."""
+    import bench
+    from toda_amd.pcdet.datasets import SyntheticLidarDataset
+    from toda_amd.pcdet.models import InputPrefetcher, build_network
+
+    cfg = bench.load_cfg(bench.WORKLOADS["c2"][0])
+    cfg.DATA_CONFIG.SYNTHETIC.NUM_POINTS = 20000
+    ds = SyntheticLidarDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, training=True)
+    dev_ = torch.device("cuda", 0)
+    net = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds).to(dev_).eval()
+    batches = bench.make_device_batches(ds, 1, 3, 0, dev_, host=True)
+
+    def stream():
+        for b in batches:
+            yield dict(b)
+        yield {"batch_size": 1, "points": torch.zeros(5, 3).pin_memory()}      # malformed: 3 columns, no batch index / features
+        for b in batches:
+            yield dict(b)
+
+    with torch.no_grad(), InputPrefetcher(stream(), net, dev_, eager=False) as pre:
+        first = pre.next()
+        kept = InputPrefetcher.keep(first)
+        ref_coords = first["voxel_coords"].clone()
+        assert kept["voxel_coords"].data_ptr() != first["voxel_coords"].data_ptr()
+        second = pre.next()
+        third = pre.next()
+        torch.cuda.synchronize()
+        assert torch.equal(kept["voxel_coords"], ref_coords)                     # the copy is batch 1 whatever the slots hold by now
+        assert not (second["voxel_coords"].shape == third["voxel_coords"].shape and torch.equal(second["voxel_coords"], third["voxel_coords"]))
+        with pytest.raises(Exception) as err:
+            pre.next()                                                           # the malformed batch
+        assert "ZeroDivision" not in type(err.value).__name__
+        again = pre.next()                                                       # the pipeline goes on with the slots it has
+        torch.cuda.synchronize()
+        assert torch.equal(again["voxel_coords"], ref_coords)

@@ -51,6 +51,32 @@ def test_voxelize_bit_exact(n, c, rng, vs, P, cap):
     assert np.array_equal(v1.cpu().numpy(), v0)  # copies of input rows: bit exact
 
 
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_voxelize_hot_cell_is_exact_and_bounded(shuffled):
+    """60 k identical points (a zero-padded cloud, returns at the origin) next to a normal cloud.  Same voxels as the sequential
+    voxeliser, and in bounded time: pushes on one cell are capped at max_points per wave, not one per point (k^2 / 2 serialised atomics)."""
+    import time
+    from toda_amd import ops
+
+    rng, vs, P, cap = [-75.2, -75.2, -2, 75.2, 75.2, 4], [0.1, 0.1, 0.15], 5, 150000
+    pts = lidar_points(120000, 5, rng, seed=77)
+    hot = np.zeros((60000, 5), np.float32)
+    hot[:, 3] = np.arange(60000, dtype=np.float32)              # distinguishable features: WHICH points are kept is checked too
+    pts = np.concatenate([pts[:40000], hot, pts[40000:]], 0)
+    if shuffled:
+        pts = pts[np.random.default_rng(5).permutation(len(pts))]
+    v0, c0, n0 = O.voxelize_hard(pts, rng, vs, P, cap)
+    x = dev(pts)
+    ops.voxelize(x, rng, vs, P, cap)                            # warm-up (allocations)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    v1, c1, n1 = ops.voxelize(x, rng, vs, P, cap)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.array_equal(c1.cpu().numpy(), c0) and np.array_equal(n1.cpu().numpy(), n0) and np.array_equal(v1.cpu().numpy(), v0)
+    assert dt < 0.25, f"hot cell voxelisation took {dt * 1e3:.1f} ms"
+
+
 def test_voxelize_empty_and_all_outside():
     from toda_amd import ops
 

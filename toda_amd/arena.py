@@ -158,6 +158,9 @@ class IndexArena:
             # batch per GPU step and stays `max_slots - 2` steps ahead, with no queue-to-queue dependency on the GPU
             import time as _t
             cands = [sl for sl in self.slots if not sl.in_use and sl.free_event is not None] or [sl for sl in self.slots if not sl.in_use]
+            if not cands:
+                raise RuntimeError(f"IndexArena: all {n} slots are held by batches that were never released (a consumer keeps more than "
+                                   f"{n - 1} prepared batches, or a preparation failed without abandon()); raise TODA_PREFETCH_MAX_SLOTS or release them")
             pick = cands[self.turn % len(cands)]
             self.turn = (self.turn + 1) % n
             if pick.free_event is not None:
@@ -176,6 +179,14 @@ class IndexArena:
         if ev is None:
             ev = slot.free_event = torch.cuda.Event(blocking=BLOCKING_EVENTS)
         ev.record(stream)
+        slot.in_use = False
+
+    def abandon(self, slot):
+        """A preparation into `slot` failed part-way: give the slot back.  Its persistent buffers may carry marks of the half-built batch
+        (a bitmap with sites set, a hash table with entries) and no recorded way to undo them, so they are declared dirty - their next
+        use clears them in full - and the pending un-mark callbacks, which would read coordinate lists that were never completed, are dropped."""
+        slot.marks.clear()
+        slot.clean.clear()
         slot.in_use = False
 
     def prewarm(self):

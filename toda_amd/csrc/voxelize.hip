@@ -64,17 +64,60 @@ __device__ __forceinline__ bool vox_cell(const float* __restrict__ p, const VoxG
 // 1. push every point on its cell's list.  slot word = {key (high), head point index (low)}; nxt[i] = previous head or -1.
 __global__ void __launch_bounds__(VOX_BLOCK)
 vox_insert_kernel(VoxBatch vb, int row_stride, VoxGeom g, unsigned long long* __restrict__ table, unsigned mask, int n_pad,
-                  int* __restrict__ slot_of, int* __restrict__ nxt) {
+                  int* __restrict__ slot_of, int* __restrict__ nxt, int max_pts) {
+    __shared__ unsigned s_key[VOX_BLOCK / 64][64];
+    __shared__ int s_cnt[VOX_BLOCK / 64][64], s_n[VOX_BLOCK / 64];
     const int b = blockIdx.y;
     const int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
-    if (i >= vb.n[b]) return;
+    const bool live = i < vb.n[b];
     const size_t gi = (size_t)b * n_pad + i;
-    int cc[3];
-    if (!vox_cell(vb.pts[b] + (size_t)i * row_stride, g, cc)) {
-        slot_of[gi] = -1;
+    int cc[3] = {0, 0, 0};
+    const bool inside = live && vox_cell(vb.pts[b] + (size_t)i * row_stride, g, cc);
+    const unsigned key = (unsigned)((cc[2] * g.grid[1] + cc[1]) * g.grid[0] + cc[0]);
+    // Hot cells (a zero-padded cloud, tens of thousands of returns at the origin): k pushes on ONE word cost ~k^2 / 2 serialised
+    // compare-and-swaps and the walk k^2 dependent loads - seconds instead of microseconds.  A point with max_pts or more same-cell points
+    // of smaller index INSIDE ITS OWN WORKGROUP (= 256 consecutive indices) can be neither kept nor a founder, and every later point of the
+    // cell has rank >= max_pts with or without it (those max_pts block-mates are smaller than both), so it is not pushed at all: at most
+    // max_pts pushes per workgroup and cell; same voxels, same kept points, same counts (min(len, max_pts)).
+    //   wave level: one pass per distinct cell of the wave (~64 on a shuffled cloud: ~1.5 k cycles per wave, 3-4 us per 360 k points);
+    //   workgroup level: only when some wave of the workgroup found two points in one cell (rare on real clouds).
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int rank_w = 0, dup = 0;
+    {
+        unsigned long long todo = __ballot(inside);
+        int t = 0;
+        while (todo) {
+            const int lead = __ffsll((long long)todo) - 1;
+            const unsigned lk = (unsigned)__shfl((int)key, lead, 64);
+            const bool same_cell = inside && key == lk;
+            const unsigned long long same = __ballot(same_cell);
+            const int cnt = __popcll(same);
+            if (same_cell) rank_w = __popcll(same & ((1ull << lane) - 1ull));
+            if (lane == lead) {
+                s_key[wv][t] = lk;
+                s_cnt[wv][t] = cnt < max_pts ? cnt : max_pts;
+            }
+            dup |= cnt > 1;
+            ++t;
+            todo &= ~same;
+        }
+        if (lane == 0) s_n[wv] = t;
+    }
+    bool push = inside && rank_w < max_pts;
+    if (__syncthreads_or(dup)) {
+        if (push) {
+            int before = rank_w;
+            for (int w = 0; w < wv && before < max_pts; ++w)
+                for (int t = 0; t < s_n[w]; ++t)
+                    if (s_key[w][t] == key) before += s_cnt[w][t];
+            push = before < max_pts;
+        }
+    }
+    if (!live) return;
+    if (!push) {
+        slot_of[gi] = -1;      // outside the range, or certainly not among its cell's first max_pts points: no part in the lists
         return;
     }
-    const unsigned key = (unsigned)((cc[2] * g.grid[1] + cc[1]) * g.grid[0] + cc[0]);
     unsigned long long* tab = table + (size_t)b * ((size_t)mask + 1);
     unsigned s = hash_u32(key) & mask;
     const unsigned long long mine = ((unsigned long long)key << 32) | (unsigned)i;
@@ -372,7 +415,7 @@ static int vox_run(const float* const* pts_host, const int32_t* n_host, int batc
     const unsigned mask = (unsigned)(w.slots - 1);
     if (n_max > 0)
         hipLaunchKernelGGL(vox_insert_kernel, dim3(cdiv(n_max, VOX_BLOCK), batch), dim3(VOX_BLOCK), 0, s, vb, row_stride, g, table,
-                           mask, w.n_pad, slot_of, nxt);
+                           mask, w.n_pad, slot_of, nxt, max_pts);
     // the walk and emit grids cover every block of the layout: blocks past a sample's points publish / consume zero founders
     hipLaunchKernelGGL(vox_walk_kernel, dim3(w.nblk, batch), dim3(VOX_WALK), 0, s, vb, table, mask, w.n_pad, w.nblk, slot_of, nxt,
                        rnk, aux, len_of, partial);

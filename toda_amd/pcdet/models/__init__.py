@@ -124,6 +124,7 @@ class InputPrefetcher:
             self.arena = _arena.IndexArena(device, n_slots, int(os.environ.get("TODA_PREFETCH_MAX_SLOTS", n_slots)),
                                            host_wait=os.environ.get("TODA_PREFETCH_STREAM_WAIT", "0") != "1")
         self._in_use = None          # slot of the batch the caller is consuming
+        self._poison = os.environ.get("TODA_PREFETCH_DEBUG_POISON", "0") == "1"
         # (Round 4 measured WHERE in the step the index kernels run - start of the forward, behind the sparse forward, at the start of the
         # dense or sparse backward - and whether the side stream waits for the training stream on the GPU or the worker waits on the host:
         # 16.87-16.99 ms per step everywhere.  A batch's ~0.5 ms of index kernels costs ~0.4 ms wherever it lands: the training stream
@@ -178,11 +179,18 @@ class InputPrefetcher:
             gate = self._fwd_done
             if gate is not None and slot is not None:
                 self._arena_mod._host_wait(gate)
-            with self._arena_mod.use_slot(slot):
-                if isinstance(batch, (tuple, list)):      # the (adversarial, original) pair of the stage-2 consistency step
-                    batch = tuple(prepare_batch_on_gpu(b, self.net, self.voxel_cfg) for b in batch)
-                else:
-                    batch = prepare_batch_on_gpu(batch, self.net, self.voxel_cfg)
+            try:
+                with self._arena_mod.use_slot(slot):
+                    if isinstance(batch, (tuple, list)):      # the (adversarial, original) pair of the stage-2 consistency step
+                        batch = tuple(prepare_batch_on_gpu(b, self.net, self.voxel_cfg) for b in batch)
+                    else:
+                        batch = prepare_batch_on_gpu(batch, self.net, self.voxel_cfg)
+            except BaseException:
+                # the slot must not stay "in use" for good (with two slots the NEXT acquire would find none and hide this error);
+                # the caller sees the original exception from next()
+                if slot is not None:
+                    self.arena.abandon(slot)
+                raise
             if self.arena is not None:
                 self.arena.prewarm()         # once: the other slots get the first one's layout (no device allocation after the warm-up steps)
             ev = torch.cuda.Event(blocking=self._arena_mod.BLOCKING_EVENTS)
@@ -200,22 +208,60 @@ class InputPrefetcher:
         self.pending = self.pool.submit(self._prepare) if self.pool is not None else self._prepare()
 
     def next(self):
+        """The next prepared batch.  LIFETIME: with the arena (the default) every device tensor the pipeline built for the PREVIOUS batch -
+        voxels, voxel_coords, voxel_num_points, every neighbour table and the out_indices inside sparse tensors derived from it - lives in
+        a slot that this call hands back: the worker overwrites it as soon as the work enqueued so far on the caller's stream has
+        finished.  A caller that holds a batch across next() (gradient accumulation over two batches, an evaluation loop that collects
+        multi_scale_3d_features, a debugging dump) must take InputPrefetcher.keep(batch) first.  TODA_PREFETCH_DEBUG_POISON=1 fills a
+        released slot with 0xFF so that a stale reader fails loudly instead of reading the next batch's tables."""
         if self.pending is None:
             self.kick()
-        got = self.pending.result() if self.pool is not None else self.pending
-        self.pending = None
+        pend, self.pending = self.pending, None      # cleared first: a preparation that raised must not be handed out again by the next call
+        got = pend.result() if self.pool is not None else pend
         if got is None:
             raise StopIteration
         batch, ev, slot = got
         main = torch.cuda.current_stream()
         if self._in_use is not None:
             # everything that reads the PREVIOUS batch (forward, backward, optimizer) has been enqueued on this stream by now
+            if self._poison:
+                for ch in self._in_use.chunks:
+                    ch.fill_(0xFF)           # on the caller's stream, behind the batch's last reader and before the release event
             self.arena.release(self._in_use, main)
         self._in_use = slot
         if not ev.query():
             main.wait_event(ev)
         _record_stream(batch, main)
         return batch
+
+    @staticmethod
+    def keep(obj, _seen=None):
+        """A copy of a batch (dict / list / tuple / object tree) whose device tensors are owned by the caching allocator instead of an arena
+        slot: safe to hold across next().  Tensors are cloned on the current stream; everything else is shared."""
+        seen = {} if _seen is None else _seen
+        if id(obj) in seen:
+            return seen[id(obj)]
+        if torch.is_tensor(obj):
+            out = obj.clone() if obj.is_cuda else obj
+        elif isinstance(obj, dict):
+            out = {}
+            seen[id(obj)] = out
+            for k, v in obj.items():
+                out[k] = InputPrefetcher.keep(v, seen)
+            return out
+        elif isinstance(obj, (list, tuple)):
+            out = type(obj)(InputPrefetcher.keep(v, seen) for v in obj)
+        elif hasattr(obj, "__dict__") and not isinstance(obj, torch.nn.Module):
+            import copy as _copy
+            out = _copy.copy(obj)
+            seen[id(obj)] = out
+            for k, v in vars(obj).items():
+                setattr(out, k, InputPrefetcher.keep(v, seen))
+            return out
+        else:
+            out = obj
+        seen[id(obj)] = out
+        return out
 
     def close(self):
         """Stop the worker: a pending preparation is waited for and dropped (its side-stream work and pinned buffers would otherwise

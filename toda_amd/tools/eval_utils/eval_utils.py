@@ -21,7 +21,9 @@ def statistics_info(cfg, ret_dict, metric, disp_dict):
 
 def run_inference(model, dataloader, on_batch=None):
     """Eval-mode forward over the loader; yields (batch_dict, pred_dicts, recall_dict).  Raw-point batches are voxelised
-    on the device exactly as in training."""
+    on the device exactly as in training.  LIFETIME: with the device-side input pipeline the yielded batch_dict's voxels, coordinates
+    and neighbour tables (and the indices inside multi_scale_3d_features) are valid until the generator is advanced - a consumer that
+    collects batches takes InputPrefetcher.keep(batch_dict) (pcdet.models); pred_dicts are ordinary tensors and stay valid."""
     dataset = dataloader.dataset
     model.eval()
     first = next(model.parameters(), None)

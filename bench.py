@@ -485,7 +485,8 @@ def run_gpu(args, rank, world, device):
                                                                  max_src_column_width=110))
     comm = None
     if world > 1 and not fwd_only:
-        comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3)
+        comm = comm_report(model, net, step, args, world, device, elapsed / args.steps * 1e3,
+                           backend="gloo, ranks SHARING one GPU (TODA_BENCH_SHARE_GPU rehearsal)" if os.environ.get("TODA_BENCH_SHARE_GPU") == "1" else "rccl")
     return {"host_input": host_input, "step_sizes": step_sizes, "elapsed": elapsed, "per_gpu": per_gpu, "desc": desc, "loss": final_loss, "timer": timer, "cfg": cfg,
             "dataset": dataset, "model": net, "step_ms": step_ms, "comm": comm, "op_rows": op_rows, "issue_s": t_issued, "cpu_s": cpu_busy,
             "host_step_ms": [t * 1e3 for t in host_step_s],
@@ -706,7 +707,7 @@ def launch_ranks(args, argv):
     JSON line) and returns the launcher's exit status (non-zero when any rank failed)."""
     import subprocess
     dry = os.environ.get("TODA_BENCH_DRYRUN") == "1"
-    if not dry:
+    if not dry and os.environ.get("TODA_BENCH_SHARE_GPU") != "1":
         have = torch.cuda.device_count()      # counting devices does not initialise HIP
         if have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible on this node", file=sys.stderr)
@@ -833,12 +834,21 @@ def main(argv=None):
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # TODA_BENCH_SHARE_GPU=1 (REHEARSAL, not a measurement of scaling): every rank uses cuda:0 and the collectives go over gloo on the
+    # device tensors (RCCL refuses two ranks on one device).  What it shows on a 1-GPU box: the N > 1 code path of this file end to end
+    # through the HIP kernels - DDP wrapper, bucketed all-reduce behind the backward, barrier, max over ranks, comm block - and the host
+    # side of a rank (host_issue_ms_per_step, host_cpu_ms_per_step) while a second process competes for the same launch queue.
+    share = os.environ.get("TODA_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1 or os.environ.get("TODA_FORCE_DDP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if os.environ.get("TODA_MIOPEN_FIND", "0") == "1":      # experiment knob: MIOpen find mode for the dense convs
         torch.backends.cudnn.benchmark = True
@@ -872,7 +882,9 @@ def main(argv=None):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": res["desc"], "global_batch": per_gpu * world,
                        "points_per_cloud": {"c3": 180000, "c2": 60000}.get(args.workload, "180000/35000 alternating"),
-                       "parallelism": f"dp{world}", "final_loss": round(res["loss"], 4),
+                       "parallelism": f"dp{world}" + (" (REHEARSAL: all ranks share cuda:0, gloo collectives - not a scaling measurement)"
+                                                        if os.environ.get("TODA_BENCH_SHARE_GPU") == "1" else ""),
+                       "final_loss": round(res["loss"], 4),
                        "input": ("pinned host memory, uploaded every step on the input stream inside the timed region (--input host)"
                                  if res["host_input"] else "raw clouds resident in HBM before the clock starts (--input resident)"),
                        "matrix_path": ("bf16 hi/mid/lo split, 6 terms, fp32 accumulate (sparse gather-GEMMs of the 32/64/128-channel pairs; exact "

@@ -25,27 +25,50 @@ done
 fi
 if [ "$PART" = "counters" ]; then
 cd /tmp && export TMPDIR=/tmp
+pmc() {   # pmc <tag> <counters> <bench args...>: one rocprofv3 pass over bench.py
+  local tag=$1 c=$2; shift 2
+  rm -rf /tmp/r05_pmc_$tag
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r05_pmc_$tag -- python3 $R/bench.py "$@" --no-cpu-baseline > $O/r05_pmc_$tag.log 2>&1 || echo "pass $tag failed"
+}
 for mm in split native; do
+  export TODA_MM=$mm
   for w in c3 c5; do
-    for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU"; do
-      tag=$(echo $c | cut -d' ' -f1)
-      rm -rf /tmp/r05_pmc_${w}_${mm}_$tag
-      TODA_MM=$mm timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r05_pmc_${w}_${mm}_$tag -- python3 $R/bench.py --workload $w --steps 2 --warmup 2 --no-cpu-baseline > $O/r05_pmc_${w}_${mm}_$tag.log 2>&1
-    done
+    pmc ${w}_${mm}_FETCH FETCH_SIZE --workload $w --steps 2 --warmup 2
+    pmc ${w}_${mm}_WRITE WRITE_SIZE --workload $w --steps 2 --warmup 2
+    pmc ${w}_${mm}_BUSY "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" --workload $w --steps 2 --warmup 2
     echo "  $w $mm done"
   done
 done
-S3=$(find /tmp/r05_pmc_c3_split_* -name "*counter_collection.csv"); N3=$(find /tmp/r05_pmc_c3_native_* -name "*counter_collection.csv")
-S5=$(find /tmp/r05_pmc_c5_split_* -name "*counter_collection.csv"); N5=$(find /tmp/r05_pmc_c5_native_* -name "*counter_collection.csv")
+export TODA_MM=split
+# the other lines of record: the SAME step counts as the lines (their batches, hence their launch shapes, follow the step index)
+pmc c2_split_FETCH FETCH_SIZE --workload c2 --steps 2 --warmup 2
+pmc c2_split_WRITE WRITE_SIZE --workload c2 --steps 2 --warmup 2
+for w in c5mix c5cl; do
+  pmc ${w}_split_FETCH FETCH_SIZE --workload $w --steps 50 --warmup 40
+  pmc ${w}_split_WRITE WRITE_SIZE --workload $w --steps 50 --warmup 40
+  echo "  $w done"
+done
+S3=$(find /tmp/r05_pmc_c3_split_* /tmp/r05_pmc_c2_split_* -name "*counter_collection.csv"); N3=$(find /tmp/r05_pmc_c3_native_* -name "*counter_collection.csv")
+S5=$(find /tmp/r05_pmc_c5_split_* /tmp/r05_pmc_c5mix_split_* /tmp/r05_pmc_c5cl_split_* -name "*counter_collection.csv"); N5=$(find /tmp/r05_pmc_c5_native_* -name "*counter_collection.csv")
 python3 $R/toda_amd/tools/pmc_summary.py "gg_split_kernel<2, 1, 4, 2" $O/r05_pmc_split_64x64.json $S3 > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py "gg_split_kernel<1, 1, 2, 2" $O/r05_pmc_split_32x32.json $S3 > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py "gg_split_kernel<4, 1, 8, 2" $O/r05_pmc_split_128x128.json $S5 > /dev/null
+python3 $R/toda_amd/tools/pmc_summary.py "wgrad_split_kernel" $O/r05_pmc_split_wgrad.json $S3 $(find /tmp/r05_pmc_c5_split_* -name "*counter_collection.csv") > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py "gather_gemm_lds_kernel<4, 4, 2" $O/r05_pmc_gather_gemm_64x64.json $N3 > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py "gather_gemm_lds_kernel<2, 2, 2" $O/r05_pmc_gather_gemm_32x32.json $N3 > /dev/null
 python3 $R/toda_amd/tools/pmc_summary.py "gather_gemm_lds_kernel<8, 8, 1" $O/r05_pmc_gather_gemm_128x128.json $N5 > /dev/null
-python3 $R/toda_amd/tools/pmc_summary.py wgrad_kernel $O/r05_pmc_sparse_wgrad.json $S3 > /dev/null
-python3 $R/toda_amd/tools/pmc_summary.py wino_fwd_ws_kernel $O/r05_pmc_wino_fwd.json $S3 > /dev/null
-python3 $R/toda_amd/tools/pmc_summary.py wino_wgrad_kernel $O/r05_pmc_wino_wgrad.json $S3 > /dev/null
+# Winograd kernels, ONE layer shape per process (persistent kernels: the grid is the CU count whatever the shape)
+for sh in 0 1; do
+  tag=$([ $sh = 0 ] && echo 256x94 || echo 128x188)
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
+    t=$(echo $c | cut -d' ' -f1)
+    rm -rf /tmp/r05_pw_${tag}_$t
+    WINO_SHAPE=$sh N_IT=10 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/r05_pw_${tag}_$t -- python3 $R/profiles/scripts/wino_bench.py > $O/r05_pw_${tag}_$t.log 2>&1 || echo "wino pass failed"
+  done
+  W=$(find /tmp/r05_pw_${tag}_* -name "*counter_collection.csv")
+  python3 $R/toda_amd/tools/pmc_summary.py wino_fwd_ws_kernel $O/r05_pmc_wino_fwd_$tag.json $W > /dev/null
+  python3 $R/toda_amd/tools/pmc_summary.py wino_wgrad_kernel $O/r05_pmc_wino_wgrad_$tag.json $W > /dev/null
+done
 fi
 if [ "$PART" = "lines" ]; then
 cd $R

@@ -502,7 +502,7 @@ PMC_FILES = {("native", 64, 64, 27): ("r05_pmc_gather_gemm_64x64.json", "gather_
              ("split", 128, 128, 27): ("r05_pmc_split_128x128.json", "gg_split_kernel<4, 1, 8, 2", 2, 1024),
              ("native", 32, 32, 27): ("r05_pmc_gather_gemm_32x32.json", "gather_gemm_lds_kernel<2, 2, 2", 2, 1024),
              ("split", 32, 32, 27): ("r05_pmc_split_32x32.json", "gg_split_kernel<1, 1, 2, 2", 2, 1024)}
-PMC_SOURCES = ("toda_amd/csrc/spconv.hip", "toda_amd/csrc/spconv_split.cuh")
+PMC_SOURCES = ("toda_amd/csrc/spconv.hip", "toda_amd/csrc/spconv_split.cuh", "toda_amd/csrc/split_common.cuh")
 
 
 def _sha256(path):

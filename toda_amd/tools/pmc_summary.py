@@ -12,7 +12,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SOURCES = ["toda_amd/csrc/spconv.hip", "toda_amd/csrc/spconv_split.cuh", "toda_amd/csrc/conv2d.hip"]
+SOURCES = ["toda_amd/csrc/spconv.hip", "toda_amd/csrc/spconv_split.cuh", "toda_amd/csrc/split_common.cuh", "toda_amd/csrc/conv2d.hip"]
 
 
 def main():

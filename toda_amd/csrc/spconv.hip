@@ -1591,9 +1591,9 @@ static int gather_gemm_impl(const float* in, int n_in, int c_gather, const float
         TODA_CHECK_ARG(k_vol >= 1 && !(cls_sorted && stats), "gather_gemm (split path): no statistics on a class-sorted launch");
         const toda::u32x4* wps = reinterpret_cast<const toda::u32x4*>(wp);
 #define SPL(KK, SS, NN, BB, WW)                                                                                                            \
-    GG_LAUNCH(HIP_KERNEL_NAME(gg_split_kernel<KK, SS, NN, 2, BB, WW>), dim3(cdiv(cdiv(n_out, 32), BB / 64)), dim3(BB), 0, s, in, n_in, wps, \
+    GG_LAUNCH(HIP_KERNEL_NAME(gg_split_kernel<KK, SS, NN, 2, BB, WW, (NN == 2)>), dim3(cdiv(cdiv(n_out, 32), BB / 64)), dim3(BB), 0, s, in, n_in, wps, \
               nbr, n_out, k_vol, c_produce, bias, out, order, stats, cls_sorted, classes)
-        // one 32-channel chunk per stage, 256-thread workgroups (spconv_split.cuh has the numbers)
+        // one 32-channel chunk per stage, 256-thread workgroups; 32 produced channels: loads issued between the matrix groups (spconv_split.cuh has the numbers)
         const int blk = 256;
         const int kc = c_gather / 32, nt = c_produce / 16;
         if (0) {}

@@ -124,7 +124,7 @@ split_pack_batch_kernel(const SplitPackBatch b) {
 // Measured (C3 / C5 levels, ms per launch): ONE chunk per stage wins wherever it was tried - 64 -> 64 @ 389 k rows 0.346 (256 threads,
 // KCS 1: 122 registers, 4 waves per SIMD, 24 KiB of LDS) against 0.354 (768 threads, KCS 2) and 0.367 (256, KCS 2: 168 registers, 3 waves);
 // @ 117 k rows 0.124 / 0.179 / 0.135; strided 64 -> 64 forward 0.104 / 0.154 / 0.122: more resident waves hide more of the gathers.
-template <int KC, int KCS, int NT, int RT, int BLK, int WAVES>
+template <int KC, int KCS, int NT, int RT, int BLK, int WAVES, bool IL = false>
 __global__ void __launch_bounds__(BLK, WAVES)
 gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict__ wps, const int* __restrict__ nbr, int n_out, int K, int cp,
                 const float* __restrict__ bias, float* __restrict__ out, const int* __restrict__ order, double* __restrict__ stats,
@@ -202,6 +202,13 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
                 raw[rt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? base + 64u * i : OOB, 0, 0));
         }
     };
+    auto gather_rt = [&](const int (&src)[RT], int part, bool valid, f32x4 (&raw)[RT][2 * KCS], int rt) {
+        const bool ok = src[rt] >= 0 && valid;
+        const unsigned base = (unsigned)src[rt] * (unsigned)(CG * 4) + (unsigned)(16 * g) + (unsigned)(128 * KCS) * (unsigned)part;
+#pragma unroll
+        for (int i = 0; i < 2 * KCS; ++i)
+            raw[rt][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? base + 64u * i : OOB, 0, 0));
+    };
     auto stage = [&](int st, int buf) {       // the slice of stage st = j SPO + part: global -> LDS, 1 KiB per wave-instruction, no registers
         const int sc = st < KE * SPO ? st : KE * SPO - 1;
         const int ss = kof(sc / SPO) * SPO + sc % SPO;
@@ -240,21 +247,77 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
             // executed tile rows are pairs this way against 0.85 with a test per 16-row tile (C3, 389 k rows) - not worth three bodies
             // (hipcc joins them with 32 accumulator copies per offset)
             u32x4 ah[RT][KCS], am[RT][KCS], al[RT][KCS];
+            f32x4 (&rw)[RT][2 * KCS] = raw;      // this stage's rows
             if (any) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int kc = 0; kc < KCS; ++kc) sp_split8(raw[rt][2 * kc], raw[rt][2 * kc + 1], ah[rt][kc], am[rt][kc], al[rt][kc]);
+                    for (int kc = 0; kc < KCS; ++kc) sp_split8(rw[rt][2 * kc], rw[rt][2 * kc + 1], ah[rt][kc], am[rt][kc], al[rt][kc]);
             }
             SP_STAMP(0);
+            if constexpr (IL) {
+                // IL: the stage's vector-memory instructions are issued BETWEEN the groups of matrix instructions instead of in front of
+                // them (in front, a wave sits in the issue of its ~9 loads for 0.25-0.45 of its time - in-kernel stamps - with its matrix
+                // instructions waiting behind them in program order).  Same relative order (slice, rows, ids): the counted waits below
+                // hold.  Measured (C3 levels, ms per launch): 32 -> 32 @ 682 k 0.230 -> 0.222, 64 -> 32 class-sorted dgrad 0.180 -> 0.166 (plain
+                // 0.351 -> 0.283), but 64 -> 64 0.347 -> 0.347 and the strided 64 -> 64 forward 0.107 -> 0.110: the launches with 32 produced
+                // channels (few matrix instructions per gathered byte) take it, the others do not.  What the ablation builds say about
+                // 64 -> 64 (SP_ABLATE): without matrix instructions 0.232 ms, without row gathers 0.245, without slice DMA 0.307, without the
+                // operand split 0.361 of 0.365 - the L2 -> CU path alone needs two thirds of the kernel's time (4 GB per launch: 1.9 GB of
+                // 64-byte row segments + 2.0 GB of weight slices), the vector pipe is hidden, and what is left is imperfect overlap.
+                constexpr int ITER = KCS * NT, PIECES = RT + 2;      // slice | rows of tile 0 .. RT-1 | ids
+                auto piece = [&](int p) {
+                    if (p == 0) {
+#if !(SP_ABLATE & 4)
+                        stage(k * SPO + part + 1, cur ^ 1);
+#endif
+                    } else if (p <= RT) {
+                        if (part + 1 < SPO) gather_rt(ids_cur, part + 1, true, raw, p - 1);
+                        else gather_rt(ids_nxt, 0, k + 1 < KE, raw, p - 1);
+                    } else if (part == SPO - 1) load_ids(k + 2, ids_new);
+                    asm volatile("" ::: "memory");
+                };
+                if (any) {
+                    const u32x4* __restrict__ wb = wl + cur * SLICE + lane;
+#pragma unroll
+                    for (int st = 0; st < ITER; ++st) {
+                        const int kc = st / NT, n = st % NT;
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, wb[(st * 3 + 0) * 64]), bm = __builtin_bit_cast(bf16x8, wb[(st * 3 + 1) * 64]),
+                                     bl = __builtin_bit_cast(bf16x8, wb[(st * 3 + 2) * 64]);
+#pragma unroll
+                        for (int p = 0; p < PIECES; ++p)
+                            if (p * ITER / PIECES == st) piece(p);
+#define SP_TERM(AA, BB)                                                                                                              \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt)                                                                                \
+        acc[rt][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AA[rt][kc]), BB, acc[rt][n], 0, 0, 0)
+                        SP_TERM(al, bh);
+                        SP_TERM(ah, bl);
+                        SP_TERM(am, bm);
+                        SP_TERM(am, bh);
+                        SP_TERM(ah, bm);
+                        SP_TERM(ah, bh);
+#undef SP_TERM
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < PIECES; ++p) piece(p);
+                }
+            } else {
             // issue order = the order the waits below and at the top of the next stage retire them in: the slice of the next stage (needed
             // by every wave behind the barrier), the rows of the next stage, the ids of offset k + 2
+#if !(SP_ABLATE & 4)
             stage(k * SPO + part + 1, cur ^ 1);
+#endif
             asm volatile("" ::: "memory");
+#if SP_ABLATE & 8
+            if (k < 0)
+#endif
             if (part + 1 < SPO) gather(ids_cur, part + 1, true, raw);
             else gather(ids_nxt, 0, k + 1 < KE, raw);          // in flight under the matrix work below
             asm volatile("" ::: "memory");
+#if !(SP_ABLATE & 16)
             if (part == SPO - 1) load_ids(k + 2, ids_new);
+#endif
             asm volatile("" ::: "memory");
             SP_STAMP(1);
             if (any) {
@@ -284,11 +347,16 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
 #undef SP_TERM
                 }
             }
+            }
             // The barrier only hands over the LDS slice: wait for this wave's share of it (the oldest of the loads above) and leave the
             // rows and ids in flight across the barrier - __syncthreads() would drain them all (vmcnt(0): an LDS-DMA is a pending LDS write)
             SP_STAMP(2);
+#if SP_ABLATE & (4 | 8 | 16)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
             if (part == SPO - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * 2 * KCS + RT) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RT * 2 * KCS) : "memory");
+#endif
             SP_STAMP(3);
             __builtin_amdgcn_s_barrier();
             SP_STAMP(4);

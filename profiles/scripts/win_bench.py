@@ -1,4 +1,5 @@
-"""Line-window gather-GEMM (gg_win_kernel) against the per-offset split kernel on the submanifold levels of C3 / C5: time, max difference,
+"""(Runs with profiles/r05_window_kernel.patch applied: the kernel lost and is not in the tree.)
+Line-window gather-GEMM (gg_win_kernel) against the per-offset split kernel on the submanifold levels of C3 / C5: time, max difference,
 reproducibility.    python profiles/scripts/win_bench.py [c3|c5]"""
 import os, sys
 R = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')

@@ -18,6 +18,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "split_common.cuh"
+
+extern "C" int toda_matrix_path(void);      // spconv.hip: 0 = native fp32 MFMA, 1 = the exact bf16 hi/mid/lo split
 
 namespace toda {
 
@@ -556,6 +559,46 @@ struct PgStage {
     static constexpr int FLOATS = Op::COL ? PG_K * (T + 4) : T * PG_LD;
 };
 
+// Results of a wave's quadrant.  D: column = lane & 15 (operand-2 row), row = 4 * (lane >> 4) + reg (operand-1 row).  Results whose
+// operand-2 index is contiguous in memory go out as 16-byte stores: the quadrant is turned in `img` (a wave-private [T/2][T/2] float
+// image in LDS) and a lane then owns 4 consecutive columns of a row.
+template <int T, class Store>
+__device__ __forceinline__ void pg_epilogue(const pg4 (&acc)[T / 32][T / 32], const Store& st, float* img, int r1_0, int r2_0) {
+    constexpr int WT = T / 32;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fi = lane & 15, fg = lane >> 4;
+    if constexpr (Store::ROWS4) {
+        if (st.vec_ok()) {
+            constexpr int QW = T / 2;              // quadrant width
+#pragma unroll
+            for (int a = 0; a < WT; ++a)
+#pragma unroll
+                for (int b = 0; b < WT; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) img[(a * 16 + 4 * fg + reg) * QW + b * 16 + fi] = acc[a][b][reg];
+            __builtin_amdgcn_wave_barrier();
+            constexpr int LPR = QW / 4;            // lanes per row
+            const int c4 = (lane % LPR) * 4;
+            const long long base = st.prep(r2_0 + wn * QW + c4);
+#pragma unroll
+            for (int it = 0; it < QW / (64 / LPR); ++it) {
+                const int row = it * (64 / LPR) + lane / LPR;
+                st.put4(base, r1_0 + wm * QW + row, *reinterpret_cast<const pg4*>(&img[row * QW + c4]));
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
+        const long long base = st.prep(r2_0 + wn * (T / 2) + b * 16 + fi);
+#pragma unroll
+        for (int a = 0; a < WT; ++a)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) st.put(base, r1_0 + wm * (T / 2) + a * 16 + 4 * fg + reg, acc[a][b][reg]);
+    }
+}
+
 // T = tile rows of both operands (128 or 64): 4 waves of (T / 2) x (T / 2).  The 64-row tile is for the GEMMs whose pixel count
 // gives too few 128 x 128 tiles to fill 256 CUs (the 94 x 94 maps: 278 tiles).
 template <int T, class Op1, class Op2, class Store>
@@ -662,40 +705,207 @@ __device__ __forceinline__ void pg_tile(const Op1& o1, const Op2& o2, const Stor
         __syncthreads();
         buf ^= 1;
     }
-    // D: column = lane & 15 (operand-2 row), row = 4 * (lane >> 4) + reg (operand-1 row)
+    static_assert(PgStage<Op1, T>::FLOATS * 2 >= 2 * (T / 2) * (T / 2) && PgStage<Op2, T>::FLOATS * 2 >= 2 * (T / 2) * (T / 2), "quadrant images must fit the operand buffers");
+    pg_epilogue<T>(acc, st, (wave & 2 ? &s2[0][0] : &s1[0][0]) + (wave & 1) * ((T / 2) * (T / 2)), r1_0, r2_0);      // (the operand images are free after the loop's last barrier)
+}
+
+// ---- the same tile product on the bf16 matrix pipe (matrix path "split", spconv_split.cuh has the arithmetic) ----------------------
+// Every fp32 operand value is taken apart into three bf16 planes WHEN IT IS STAGED (5.5 vector instructions per value once per
+// workgroup, not once per use), six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block, the three 2^-16 terms into their own accumulator
+// set (a contraction over thousands of pixels makes the accumulator large against one instruction's contribution and every matrix
+// instruction rounds it; see wgrad_split_kernel).  A stage = 32 contraction values = ONE matrix-instruction depth.
+// LDS images per plane:  [row][32 bf16] for an operand whose contraction index is contiguous in memory (row stride 80 bytes: the
+// 16 rows of a fragment read hit 16 different 16-byte bank groups), one ds_read_b128 per fragment and plane;  [16 k-pairs][row] of
+// packed (k, k + 1) dwords for a COL operand - a thread holds one contraction index of 8 rows, the thread 8 lanes on holds the next
+// index of the same rows: one DPP row rotation hands each of them the other's half, both pack 4 rows x (k, k + 1) and store one
+// 16-byte line; fragment = four conflict-free ds_read_b32 per plane.  Both layouts give lane group g the contraction indices
+// 8 g .. 8 g + 7 in order.
+// 128 x 128 tiles only, 512 threads: the three planes of both operands, double buffered, are 100-123 KiB of LDS = ONE workgroup per
+// CU; with 256 threads that is one wave per SIMD and a wave's fetch -> split -> store -> barrier -> matrix work runs with nothing
+// beside it (measured: no faster than the fp32 form).  Eight waves share the images (2 per SIMD): wave (wm, wn) owns 64 x 32 of the tile.
+constexpr int PGS_BLOCK = 512;
+template <class Op1, class Op2, class Store>
+__device__ __forceinline__ void pg_tile_split(const Op1& o1, const Op2& o2, const Store& st, int c_begin, int c_end) {
+    static_assert(PG_K == 32, "one bf16 matrix-instruction depth per stage");
+    constexpr int T = 128, TA = 4, TB = 2;      // 16 x 16 result tiles per wave: 64 operand-1 rows x 32 operand-2 rows
+    constexpr int RS = 20;                      // dwords per row of a [row][32 bf16] plane (16 + 4 of padding)
+    constexpr int LC2 = T + 4;                  // dwords per k-pair line of a [16 k-pairs][row] plane
+    constexpr int P1 = Op1::COL ? 16 * LC2 : T * RS, P2 = Op2::COL ? 16 * LC2 : T * RS;      // dwords per plane
+    constexpr int IMG = 2 * 3 * (P1 + P2), EPI = 8 * 64 * 32;
+    __shared__ __attribute__((aligned(16))) unsigned lds[IMG > EPI ? IMG : EPI];
+    unsigned* const s1 = lds;                   // [buffer][plane][P1]
+    unsigned* const s2 = lds + 2 * 3 * P1;
+    typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r1_0 = blockIdx.y * T, r2_0 = blockIdx.x * T;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fi = lane & 15, fg = lane >> 4;
+    // a thread's 8 values of a stage.  contraction-contiguous operand: row t >> 2, contraction values 8 (t & 3) .. + 7.
+    // COL operand: contraction index kc, rows 8 rg .. + 7, with kc ^ 1 on lane ^ 8 (same 16-lane DPP row).
+    const int rg = (t & 7) + 8 * ((t >> 4) & 1), kc = 2 * (t >> 5) + ((t >> 3) & 1);
+    const bool odd = (t >> 3) & 1;
+
+    typename Op1::State q1;
+    typename Op2::State q2;
+    if (Op1::COL) o1.init(q1, r1_0 + 8 * rg);
+    else o1.init(q1, r1_0 + (t >> 2));
+    if (Op2::COL) o2.init(q2, r2_0 + 8 * rg);
+    else o2.init(q2, r2_0 + (t >> 2));
+    float v1[8], v2[8];
+    typename Op1::Cur k1;
+    typename Op2::Cur k2;
+    if constexpr (Op1::CURSOR) o1.cur_set(k1, c_begin);
+    if constexpr (Op2::CURSOR) o2.cur_set(k2, c_begin);
+    auto fetch = [&](int c0) {
+        const int tn = (t & 3) * 8;
+        if constexpr (Op1::COL) o1.load(q1, c0 + kc, v1);
+        else if constexpr (Op1::CURSOR) o1.load(q1, k1, tn, v1);
+        else o1.load(q1, c0 + tn, v1);
+        if constexpr (Op2::COL) o2.load(q2, c0 + kc, v2);
+        else if constexpr (Op2::CURSOR) o2.load(q2, k2, tn, v2);
+        else o2.load(q2, c0 + tn, v2);
+    };
+    // split + store of a thread's share of a stage; img = plane 0 of the buffer, PSZ = dwords per plane
+    auto stash_one = [&](unsigned* img, const int PSZ, const bool col, const float (&v)[8]) {
+        pu4 ph, pm, pl;
+        unsigned* dst;
+        if (!col) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned a, b, c;
+                sp_split2(v[2 * q], v[2 * q + 1], a, b, c);
+                ph[q] = a, pm[q] = b, pl[q] = c;
+            }
+            dst = img + (t >> 2) * RS + (t & 3) * 4;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float send = odd ? v[r] : v[4 + r], keep = odd ? v[4 + r] : v[r];
+                const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+                unsigned a, b, c;
+                sp_split2(odd ? got : keep, odd ? keep : got, a, b, c);      // (even index, odd index) of row 8 rg + 4 odd + r
+                ph[r] = a, pm[r] = b, pl[r] = c;
+            }
+            dst = img + (t >> 5) * LC2 + 8 * rg + 4 * (int)odd;
+        }
+        *reinterpret_cast<pu4*>(dst) = ph;
+        *reinterpret_cast<pu4*>(dst + PSZ) = pm;
+        *reinterpret_cast<pu4*>(dst + 2 * PSZ) = pl;
+    };
+
+    pg4 acc[TA][TB], acc_s[TA][TB];
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[a][b] = acc_s[a][b] = pg4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(c_begin);
+    stash_one(s1, P1, Op1::COL, v1);
+    stash_one(s2, P2, Op2::COL, v2);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += PG_K) {
+        const bool more = c0 + PG_K < c_end;
+        if (more) {
+            if constexpr (Op1::CURSOR) o1.cur_step(k1);
+            if constexpr (Op2::CURSOR) o2.cur_step(k2);
+            fetch(c0 + PG_K);
+        }
+        const unsigned* b1 = s1 + buf * 3 * P1;
+        const unsigned* b2 = s2 + buf * 3 * P2;
+        pu4 fa[TA][3];
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (Op1::COL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[a][p][j] = b1[p * P1 + (4 * fg + j) * LC2 + wm * 64 + a * 16 + fi];
+                } else {
+                    fa[a][p] = *reinterpret_cast<const pu4*>(&b1[p * P1 + (wm * 64 + a * 16 + fi) * RS + 4 * fg]);
+                }
+            }
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            pu4 fb[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                if (Op2::COL) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[p][j] = b2[p * P2 + (4 * fg + j) * LC2 + wn * 32 + b * 16 + fi];
+                } else {
+                    fb[p] = *reinterpret_cast<const pu4*>(&b2[p * P2 + (wn * 32 + b * 16 + fi) * RS + 4 * fg]);
+                }
+            }
+#define PG_TERM(ACC, PA, PB)                                                                                                        \
+    _Pragma("unroll") for (int a = 0; a < TA; ++a) ACC[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                            \
+        __builtin_bit_cast(bf16x8, fa[a][PA]), __builtin_bit_cast(bf16x8, fb[PB]), ACC[a][b], 0, 0, 0)
+            PG_TERM(acc_s, 2, 0);      // lo . hi
+            PG_TERM(acc_s, 0, 2);      // hi . lo
+            PG_TERM(acc_s, 1, 1);      // mid . mid
+            PG_TERM(acc, 1, 0);        // mid . hi
+            PG_TERM(acc, 0, 1);        // hi . mid
+            PG_TERM(acc, 0, 0);        // hi . hi
+#undef PG_TERM
+        }
+        if (more) {
+            stash_one(s1 + (buf ^ 1) * 3 * P1, P1, Op1::COL, v1);
+            stash_one(s2 + (buf ^ 1) * 3 * P2, P2, Op2::COL, v2);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) acc[a][b] = acc_s[a][b] + acc[a][b];
+    // D: column = lane & 15 (operand-2 row), row = 4 * (lane >> 4) + reg (operand-1 row); the wave's block is 64 x 32
     if constexpr (Store::ROWS4) {
-        // Results whose operand-2 index is contiguous in memory go out as 16-byte stores: the wave's quadrant is turned in LDS (the
-        // operand images are free after the loop's last barrier) and a lane then owns 4 consecutive columns of a row.
         if (st.vec_ok()) {
-            constexpr int QW = T / 2;              // quadrant width
-            static_assert(PgStage<Op1, T>::FLOATS * 2 >= 2 * QW * QW && PgStage<Op2, T>::FLOATS * 2 >= 2 * QW * QW, "quadrant images must fit the operand buffers");
-            float* img = (wave & 2 ? &s2[0][0] : &s1[0][0]) + (wave & 1) * (QW * QW);          // [QW rows][QW]: one private image per wave
+            float* img = reinterpret_cast<float*>(lds) + wave * (64 * 32);      // (the images are free after the loop's last barrier)
 #pragma unroll
-            for (int a = 0; a < WT; ++a)
+            for (int a = 0; a < TA; ++a)
 #pragma unroll
-                for (int b = 0; b < WT; ++b)
+                for (int b = 0; b < TB; ++b)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) img[(a * 16 + 4 * fg + reg) * QW + b * 16 + fi] = acc[a][b][reg];
+                    for (int reg = 0; reg < 4; ++reg) img[(a * 16 + 4 * fg + reg) * 32 + b * 16 + fi] = acc[a][b][reg];
             __builtin_amdgcn_wave_barrier();
-            constexpr int LPR = QW / 4;            // lanes per row
-            const int c4 = (lane % LPR) * 4;
-            const long long base = st.prep(r2_0 + wn * QW + c4);
+            const int c4 = (lane & 7) * 4;
+            const long long base = st.prep(r2_0 + wn * 32 + c4);
 #pragma unroll
-            for (int it = 0; it < QW / (64 / LPR); ++it) {
-                const int row = it * (64 / LPR) + lane / LPR;
-                st.put4(base, r1_0 + wm * QW + row, *reinterpret_cast<const pg4*>(&img[row * QW + c4]));
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                st.put4(base, r1_0 + wm * 64 + row, *reinterpret_cast<const pg4*>(&img[row * 32 + c4]));
             }
             return;
         }
     }
 #pragma unroll
-    for (int b = 0; b < WT; ++b) {
-        const long long base = st.prep(r2_0 + wn * (T / 2) + b * 16 + fi);
+    for (int b = 0; b < TB; ++b) {
+        const long long base = st.prep(r2_0 + wn * 32 + b * 16 + fi);
 #pragma unroll
-        for (int a = 0; a < WT; ++a)
+        for (int a = 0; a < TA; ++a)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) st.put(base, r1_0 + wm * (T / 2) + a * 16 + 4 * fg + reg, acc[a][b][reg]);
+            for (int reg = 0; reg < 4; ++reg) st.put(base, r1_0 + wm * 64 + a * 16 + 4 * fg + reg, acc[a][b][reg]);
     }
+}
+
+template <class Op1, class Op2, class Store>
+__global__ void __launch_bounds__(PGS_BLOCK)
+pg_gemm_split_kernel(const Op1 o1, const Op2 o2, const Store st, int c_total, int c_per_split) {
+    const int c_begin = blockIdx.z * c_per_split;
+    const int c_end = min(c_total, c_begin + c_per_split);
+    pg_tile_split(o1, o2, st, c_begin, c_end > c_begin ? c_end : c_begin);      // (an empty split still owns a slab: it stores zeros)
+}
+
+__global__ void __launch_bounds__(PGS_BLOCK)
+pg_s2_dgrad_split_kernel(WS2Dgrad o1, PixS2Dgrad o2, StoreS2Class st) {
+    S2Class c;
+    c.set(blockIdx.z);
+    o1.c = c;
+    o2.c = c;
+    st.py = c.py, st.px = c.px;
+    pg_tile_split(o1, o2, st, 0, o2.Cout << (c.lty + c.ltx));
 }
 
 template <int T, class Op1, class Op2, class Store>
@@ -751,9 +961,22 @@ static int pg_splits(long long n_pixels, int tiles) {
 
 // 128-row tiles when they fill the chip (or when contraction splits do: gz > 1, the weight gradients), 64-row tiles otherwise
 static inline bool pg_small(long long r1, long long r2, int gz) { return gz == 1 && (long long)cdiv(r1, 128) * cdiv(r2, 128) < 768; }
+// matrix path "split" (toda_set_matrix_path): the same accessors and stores around pg_tile_split - 128 x 128 tiles, one 512-thread
+// workgroup per CU, taken when the tile count fills the 256 CUs well enough (a 278-tile grid would run one full round and one of 22)
+static inline bool pg_split_grid(long long r1, long long r2, int gz) {
+    if (toda_matrix_path() != 1) return false;
+    static const int env = getenv("TODA_PG_SPLIT") ? atoi(getenv("TODA_PG_SPLIT")) : 1;
+    if (!env) return false;
+    const long long tiles = (long long)cdiv(r1, 128) * cdiv(r2, 128) * gz;
+    const long long rounds = cdiv(tiles, 256);
+    return tiles * 10 >= rounds * 256 * 7;      // >= 0.7 of the slots of its rounds
+}
 #define PG_LAUNCH(O1, O2, ST, r1, r2, gz, ...)                                                                                             \
     do {                                                                                                                                   \
-        if (pg_small(r1, r2, gz))                                                                                                            \
+        if (pg_split_grid(r1, r2, gz))                                                                                                      \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(pg_gemm_split_kernel<O1, O2, ST>), dim3(cdiv(r2, 128), cdiv(r1, 128), gz), dim3(PGS_BLOCK), 0,  \
+                               (hipStream_t)stream, __VA_ARGS__);                                                                          \
+        else if (pg_small(r1, r2, gz))                                                                                                       \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(pg_gemm_kernel<64, O1, O2, ST>), dim3(cdiv(r2, 64), cdiv(r1, 64), gz), dim3(PG_BLOCK), 0,    \
                                (hipStream_t)stream, __VA_ARGS__);                                                                          \
         else                                                                                                                               \
@@ -795,7 +1018,9 @@ extern "C" int toda_conv3x3s2_dgrad(const float* dy, const float* w, int batch, 
     WS2Dgrad o1{w, cin, cout, S2Class{}};
     PixS2Dgrad o2{dy, batch, cout, H, W, H / 2, W / 2, S2Class{}};
     StoreS2Class st{dx, cin, N, H, W, 0, 0};
-    if ((long long)cdiv(cin, 128) * cdiv(N, 128) * 4 < 768)
+    if (pg_split_grid(cin, N, 4))
+        hipLaunchKernelGGL(pg_s2_dgrad_split_kernel, dim3(cdiv(N, 128), cdiv(cin, 128), 4), dim3(PGS_BLOCK), 0, (hipStream_t)stream, o1, o2, st);
+    else if ((long long)cdiv(cin, 128) * cdiv(N, 128) * 4 < 768)
         hipLaunchKernelGGL(pg_s2_dgrad_kernel<64>, dim3(cdiv(N, 64), cdiv(cin, 64), 4), dim3(PG_BLOCK), 0, (hipStream_t)stream, o1, o2, st);
     else
         hipLaunchKernelGGL(pg_s2_dgrad_kernel<128>, dim3(cdiv(N, 128), cdiv(cin, 128), 4), dim3(PG_BLOCK), 0, (hipStream_t)stream, o1, o2, st);

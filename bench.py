@@ -887,8 +887,8 @@ def main(argv=None):
                        "final_loss": round(res["loss"], 4),
                        "input": ("pinned host memory, uploaded every step on the input stream inside the timed region (--input host)"
                                  if res["host_input"] else "raw clouds resident in HBM before the clock starts (--input resident)"),
-                       "matrix_path": ("bf16 hi/mid/lo split, 6 terms, fp32 accumulate (sparse gather-GEMMs of the 32/64/128-channel pairs; exact "
-                                       "operand split, TODA_MM=split)" if ops.matrix_path() == "split"
+                       "matrix_path": ("bf16 hi/mid/lo split, 6 terms, fp32 accumulate (sparse gather-GEMMs and weight gradients of the 32/64/128-channel "
+                                       "pairs, pixel-GEMMs of the BEV neck; exact operand split, TODA_MM=split)" if ops.matrix_path() == "split"
                                        else "native fp32 MFMA (TODA_MM=native)"),
                        "peak_hbm_gib": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
                        "alloc_retries": int(torch.cuda.memory_stats(device).get("num_alloc_retries", 0)),

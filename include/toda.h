@@ -185,7 +185,9 @@ size_t toda_spconv_packed_weight_floats(int k_vol, int c_gather, int c_produce);
  * pair runs native under either path.  Initial value: environment TODA_MM = native | split (default split: it holds the
  * gates of tests/test_gpu_split.py - oracle parity at the unchanged tolerance, error against fp64 <= 1.5 x native, bit-reproducible).  The packed operand of a
  * supported pair is written in the format of the path current at PACK time (toda_spconv_packed_weight_floats covers both)
- * and must be multiplied under the same path: set the path before packing, re-pack after changing it. */
+ * and must be multiplied under the same path: set the path before packing, re-pack after changing it.  The same switch selects the
+ * arithmetic of toda_spconv_wgrad (32 / 64-channel pairs and 128 x 128) and of toda_conv3x3s2_* / toda_deconv_* (operands split when
+ * they are staged; no packed operand involved; TODA_PG_SPLIT=0 keeps those on the fp32 instructions). */
 int toda_matrix_path(void);
 int toda_set_matrix_path(int mode);
 int toda_spconv_split_supported(int c_gather, int c_produce);

@@ -149,8 +149,7 @@ for key, cin, cout in {'c5': (('spconv3', 32, 64), ('spconv4', 64, 128))}.get(na
     w = torch.randn(cout, 3, 3, 3, cin, device='cuda') * 0.05
     run(key + " fwd", feat, w, rb.nbr_fwd, cout)
     g = torch.randn(rb.n_out, cout, device='cuda')
-    if cin <= 64 and cout <= 64:
-        run_wgrad(key, feat, g, rb.nbr_fwd, tuple(w.shape))
+    run_wgrad(key, feat, g, rb.nbr_fwd, tuple(w.shape))
     run(key + " dgrad(plain)", g, w, rb.nbr_bwd, cin, True, rb.flip_bwd)
     co = rb.class_order()
     if co is not None:

@@ -117,7 +117,7 @@ def test_both_paths_against_the_oracle_and_fp64(cin, cout, paths):
     assert torch.equal(again[0], res["split"][0]) and torch.equal(again[1], res["split"][1])      # bit-reproducible
 
 
-@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64), (128, 128)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (32, 64), (64, 32), (64, 64), (128, 128), (64, 128), (128, 64)])
 @pytest.mark.parametrize("strided", [False, True])
 def test_both_paths_weight_gradient(cin, cout, strided, paths):
     """Weight gradient of a submanifold and of a strided layer: the oracle at the unchanged tolerance, fp64, reproducibility."""

@@ -1808,7 +1808,9 @@ extern "C" int toda_spconv_wgrad(const float* in, int n_in, const float* dout, c
 #define WGS(MM, NN)                                                                                                                       \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<MM, NN>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, \
                        xcd_chunks)
-        if (cin == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<4, 4, true>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, xcd_chunks);
+        if (cin == 128 && cout == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<4, 4, 2, 2>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, xcd_chunks);
+        else if (cin == 64 && cout == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<4, 4, 1, 2>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, xcd_chunks);
+        else if (cin == 128 && cout == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(wgrad_split_kernel<4, 4, 2, 1>), g, dim3(SC_BLOCK), 0, s, in, n_in, dout, nbr, n_out, k_vol, rpc, slab, xcd_chunks);
         else if (cin == 32 && cout == 32) WGS(2, 2);
         else if (cin == 32) WGS(2, 4);
         else if (cout == 32) WGS(4, 2);

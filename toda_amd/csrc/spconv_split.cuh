@@ -455,19 +455,23 @@ gg_split_kernel(const float* __restrict__ in, int n_in, const u32x4* __restrict_
 // (64 x 64 @ 389 k rows: 7.8e-7 against 4.2e-7 of the result's rms), the small terms apart 0.91 x (3.8e-7), three sets (hh alone) 0.55 x
 // but 192 accumulator registers spill; rounded-to-nearest planes instead of truncated ones change nothing (the dropped cross terms are
 // not what is measured).  Same time per launch as one set.
-// COOP (128 x 128, as wgrad_kernel's): the four waves of a workgroup walk the SAME pairs and each owns one 64 x 64 quarter of the weight
-// block (lane channels 8 ii + 4 q .. + 3 of a side: the same 16-byte loads at twice the lane stride); no fold across waves.
-template <int MTB, int NTB, bool COOP = false>
+// QM x QN quarters (128-channel sides, as wgrad_kernel's cooperative form): the weight block is QM x QN quarters of (16 MTB) x (16 NTB); the four
+// waves are 4 / (QM QN) TEAMS per quarter.  The waves of a team's quarter walk the SAME pairs (lane channels (MTB QM) ii + MTB q .. of
+// a side: the same 16-byte loads at a wider lane stride), the teams of a quarter take alternate 64-row batches and are folded in
+// fixed order.  1 x 1: four teams, one block (32 / 64-channel sides); 2 x 2: 128 x 128, no fold; 1 x 2 / 2 x 1: 64 x 128 / 128 x 64, two teams.
+template <int MTB, int NTB, int QM = 1, int QN = 1>
 // 32 x 64 wants 175 registers: two waves per SIMD without spills (0.129 ms at spconv3 of C3) beat three with 13 spilled dwords (0.162)
 __global__ void __launch_bounds__(SC_BLOCK, (MTB * NTB <= 4) ? 4 : ((MTB == 4 && NTB == 2) ? 3 : 2))
 wgrad_split_kernel(const float* __restrict__ in, int n_in, const float* __restrict__ dout, const int* __restrict__ nbr, int n_out, int K,
                    int rows_per_chunk, float* __restrict__ slab, int xcd_chunks) {
     static_assert((MTB == 2 || MTB == 4) && (NTB == 2 || NTB == 4), "32 or 64 channels a side");
-    static_assert(!COOP || (MTB == 4 && NTB == 4), "cooperative quarters of 128 x 128");
-    constexpr int MT = COOP ? 8 : MTB, NT = COOP ? 8 : NTB;      // tiles of the whole sides
+    static_assert(QM * QN == 1 || (MTB == 4 && NTB == 4), "quarters are 64 x 64");
+    static_assert(QM * QN == 1 || QM * QN == 2 || QM * QN == 4, "1, 2 or 4 quarters");
+    constexpr int NQ = QM * QN, TEAMS = (SC_BLOCK / 64) / NQ;
+    constexpr int MT = MTB * QM, NT = NTB * QN;      // tiles of the whole sides
     constexpr int cin = 16 * MT, cout = 16 * NT;
     constexpr int QCAP = 64 + 32;
-    __shared__ float red[COOP ? 1 : MTB * NTB * 4 * 64];
+    __shared__ float red[TEAMS == 1 ? 1 : NQ * MTB * NTB * 4 * 64];
     __shared__ int q_in[SC_BLOCK / 64][QCAP], q_out[SC_BLOCK / 64][QCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ii = lane & 15, g = lane >> 4;
@@ -511,7 +515,8 @@ wgrad_split_kernel(const float* __restrict__ in, int n_in, const float* __restri
         }
     const __amdgpu_buffer_rsrc_t in_rsrc = table_rsrc(in, (unsigned)n_in * (unsigned)cin * 4u);
     const __amdgpu_buffer_rsrc_t dout_rsrc = table_rsrc(dout, (unsigned)n_out * (unsigned)cout * 4u);
-    const int m0 = COOP ? (wv >> 1) * MTB : 0, n0 = COOP ? (wv & 1) * NTB : 0;
+    const int qd = wv % NQ, team = wv / NQ;
+    const int m0 = (qd / QN) * MTB, n0 = (qd % QN) * NTB;
     const unsigned lane_a = (unsigned)(MT * ii + m0) * 4u, lane_b = (unsigned)(NT * ii + n0) * 4u;
     constexpr unsigned row_a = (unsigned)cin * 4u, row_b = (unsigned)cout * 4u;
 
@@ -591,8 +596,8 @@ wgrad_split_kernel(const float* __restrict__ in, int n_in, const float* __restri
     };
 
     int qn = 0;  // wave-uniform queue length (< 32 between batches)
-    constexpr int BSTEP = COOP ? 64 : SC_BLOCK;
-    const int base0 = row_begin + (COOP ? 0 : wv * 64);
+    constexpr int BSTEP = TEAMS * 64;
+    const int base0 = row_begin + team * 64;
     int iv_next = nbr[(size_t)k * n_out + min(base0 + lane, n_out - 1)];  // clamped, unconditional: the ids of the NEXT 64 rows are in flight
     for (int base = base0; base < row_end; base += BSTEP) {               // under this batch's rounds
         const int o = base + lane;
@@ -644,27 +649,28 @@ wgrad_split_kernel(const float* __restrict__ in, int n_in, const float* __restri
 #endif
 
     // fold the 4 waves of the block in fixed order 0+1+2+3, then the chunk's slab (as wgrad_kernel)
-    for (int src = 1; !COOP && src < SC_BLOCK / 64; ++src) {
-        if (wv == src) {
+    for (int src = 1; src < TEAMS; ++src) {
+        float* const rq = red + qd * (MTB * NTB * 4 * 64);
+        if (team == src) {
 #pragma unroll
             for (int m = 0; m < MTB; ++m)
 #pragma unroll
                 for (int n = 0; n < NTB; ++n)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) red[((m * NTB + n) * 4 + reg) * 64 + lane] = acc[m][n][reg];
+                    for (int reg = 0; reg < 4; ++reg) rq[((m * NTB + n) * 4 + reg) * 64 + lane] = acc[m][n][reg];
         }
         __syncthreads();
-        if (wv == 0) {
+        if (team == 0) {
 #pragma unroll
             for (int m = 0; m < MTB; ++m)
 #pragma unroll
                 for (int n = 0; n < NTB; ++n)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[m][n][reg] += red[((m * NTB + n) * 4 + reg) * 64 + lane];
+                    for (int reg = 0; reg < 4; ++reg) acc[m][n][reg] += rq[((m * NTB + n) * 4 + reg) * 64 + lane];
         }
         __syncthreads();
     }
-    if (!COOP && wv != 0) return;
+    if (team != 0) return;
     // D: col = lane & 15 -> produced-channel tile column, row = 4 (lane >> 4) + reg -> gathered-channel tile row
     float* dst = slab + (size_t)chunk * cout * K * cin;
 #pragma unroll
@@ -680,7 +686,7 @@ wgrad_split_kernel(const float* __restrict__ in, int n_in, const float* __restri
 }
 
 static inline bool wgrad_split_shape_ok(int cin, int cout) {
-    return ((cin == 32 || cin == 64) && (cout == 32 || cout == 64)) || (cin == 128 && cout == 128);
+    return ((cin == 32 || cin == 64) && (cout == 32 || cout == 64)) || ((cin == 64 || cin == 128) && (cout == 64 || cout == 128));
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------

@@ -181,7 +181,7 @@ size_t toda_spconv_packed_weight_floats(int k_vol, int c_gather, int c_produce);
  * pcdet/models/backbones_3d/spconv_backbone.py:77-125,191-240), process-wide: 0 = native - fp32 operands on
  * v_mfma_f32_16x16x4_f32; 1 = split - every fp32 operand taken apart EXACTLY into three bf16 values (hi + mid + lo = x),
  * six of the nine cross products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (the three dropped ones are below
- * 2^-24 of the product), 6/16 of the matrix cycles, for the channel pairs toda_spconv_split_supported names; every other
+ * 2^-22 of the product each, 2^-25 on average: the size of an fp32 product's own rounding), 6/16 of the matrix cycles, for the channel pairs toda_spconv_split_supported names; every other
  * pair runs native under either path.  Initial value: environment TODA_MM = native | split (default split: it holds the
  * gates of tests/test_gpu_split.py - oracle parity at the unchanged tolerance, error against fp64 <= 1.5 x native, bit-reproducible).  The packed operand of a
  * supported pair is written in the format of the path current at PACK time (toda_spconv_packed_weight_floats covers both)
